@@ -1,0 +1,84 @@
+/* ss_hip.h — C ABI of libss_hip.so: the MI355X (gfx950) audio-observation path of SoundSpaces.
+ *
+ * Every entry point replaces one piece of reference Python (paths relative to the
+ * facebookresearch/sound-spaces checkout) and is what a ctypes/cffi binding on the
+ * reference side would bind:
+ *
+ *   ss_fftconv_binaural_f32  <- SoundSpacesSim._compute_audiogoal: the two
+ *                               scipy.signal.fftconvolve calls + slicing, all three windowing
+ *                               branches, the distractor add and the silent / empty-RIR zeros
+ *                               (soundspaces/simulator.py:608-666); also
+ *                               ContinuousSoundSpacesSim._convolve_with_rir
+ *                               (soundspaces/continuous_simulator.py:428-456)
+ *   ss_spectrogram_f32       <- SpectrogramSensor.compute_spectrogram
+ *                               (soundspaces/tasks/nav.py:86-100): librosa.stft(512,160,400) ->
+ *                               abs -> block_reduce(4,4,mean) -> log1p -> stack(axis=-1)
+ *   ss_audio_obs_f32         <- get_current_spectrogram_observation on a cache miss
+ *                               (soundspaces/simulator.py:690-701), both stages fused
+ *   ss_source_windows_f32    <- the FFT of the source clip that fftconvolve recomputes on every
+ *                               call (simulator.py:630) hoisted out and cached per (sound, window)
+ *
+ * Conventions: all pointers are DEVICE pointers owned by the caller (no torch types, no host
+ * buffers); `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ * asynchronous on that stream; return 0 on success, SS_EINVAL for bad arguments, or the negated
+ * hipError_t of the failing runtime call.  The library keeps only immutable per-device twiddle /
+ * window tables, built on first use (thread-safe).
+ */
+#ifndef SS_HIP_H
+#define SS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_EINVAL (-1)
+#define SS_PAD_REFLECT 0   /* librosa < 0.10 default (the reference's era), torch.stft default */
+#define SS_PAD_CONSTANT 1  /* librosa >= 0.10 default */
+
+/* Geometry constants of the partitioned convolution. */
+int ss_block_len(void);        /* kB = 16384 real samples per partition block                     */
+int ss_spec_floats(void);      /* floats per stored window spectrum = 2 * 16384                   */
+int ss_version(void);
+
+/* Build (idempotent) the constant tables for the current HIP device. */
+int ss_init(void);
+
+/* Source-window spectra.  win_desc[w] = {src_offset, src_len, start, wrap} (int32 x4):
+ * window w holds samples src[src_offset + start + n], n in [0, 2*kB), zero outside [0, src_len)
+ * (wrap != 0: indices >= src_len continue from the start of the clip, SS2.0 semantics).
+ * For the convolution out[t] = sum_k h[k] x[t0+t-k] the window of partition offset m starts at
+ * start = t0 + (m-1)*kB.  spec_out receives W * ss_spec_floats() floats (opaque kernel order). */
+int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out, int n_windows,
+                          void* stream);
+
+/* Batched binaural convolution.  One unit = one (env, rotation) observation.
+ * unit_desc[n] = 8 x int32, two terms k = 0 (source), 1 (distractor):
+ *   [4k+0] RIR bank index, or -1 if the term is absent (both absent = silent unit -> exact zeros)
+ *   [4k+1] slot (index into spec, in windows) of the spectrum for partition offset m_min
+ *   [4k+2] m_min   [4k+3] number of consecutive offsets stored
+ * RIR bank addressing: sample j of ear c of entry r is
+ *   rir[r*rir_unit_stride + c*rir_chan_stride + j*rir_elem_stride], j < rir_len[r]
+ *   (planar [R,2,L]: (2L, L, 1);  wav-interleaved [R,L,2]: (2L, 1, 2)).
+ * Bank rows must be ZERO for rir_len[r] <= j < rir_cap (rir_cap = L of the bank): the kernel reads
+ * up to rir_cap without per-sample length checks; rir_len only selects how many blocks are transformed.
+ * out: [n_units, 2, out_len]; the first n_valid samples of every row are computed, the rest zeroed
+ * (SS2.0 pads 0.25 s steps to 1 s).  n_valid <= 3*kB. */
+int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_len,
+                            const int* unit_desc, float* out, int n_units,
+                            long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
+                            int rir_cap, int n_valid, int out_len, void* stream);
+
+/* Spectrogram of x [n_units, 2, len] -> out [n_units, 65, ceil((1+len/160)/4), 2] (channel-last). */
+int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream);
+
+/* Fused observation: convolution + spectrogram.  audiogoal may be NULL when out_len <= kB (the
+ * waveform then never leaves the CU); for longer rows it is required (used as the hand-off). */
+int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
+                     float* audiogoal, float* spectrogram, int n_units,
+                     long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
+                     int rir_cap, int n_valid, int out_len, int pad_mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS_HIP_H */

@@ -1,0 +1,167 @@
+// ss_hip.hip — host side of libss_hip.so: table construction and kernel launches (gfx950 only).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/ss_hip.h"
+#include "ss_kernels.hpp"
+#include "ss_tables.hpp"
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+struct DeviceTables {
+    bool ready = false;
+    ssk::Tables tb{};
+};
+DeviceTables g_tables[kMaxDevices];
+std::mutex g_mu;
+
+inline int hip_err(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
+
+int get_tables(ssk::Tables* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_err(e);
+    if (dev < 0 || dev >= kMaxDevices) return SS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceTables& d = g_tables[dev];
+    if (!d.ready) {
+        const std::vector<float> host = ssk_host::build_tables();
+        float* dev_buf = nullptr;
+        e = hipMalloc(&dev_buf, host.size() * sizeof(float));
+        if (e != hipSuccess) return hip_err(e);
+        e = hipMemcpy(dev_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dev_buf); return hip_err(e); }
+        d.tb.twM = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTwMOff);
+        d.tb.twItem = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTwItemOff);
+        d.tb.tw512 = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTw512Off);
+        d.tb.win = dev_buf + ssk_host::kWinOff;
+        d.ready = true;
+    }
+    *out = d.tb;
+    return 0;
+}
+
+inline int n_frames_of(int len) { return 1 + len / ssk::kHop; }
+inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kPool; }
+
+template <bool FUSE>
+int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, hipStream_t st) {
+    if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
+    hipLaunchKernelGGL(ssk::k_conv<FUSE>, dim3(2 * n_units, nb_y), dim3(ssk::kT), 0, st, p);
+    return hip_err(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+int ss_block_len(void) { return ssk::kB; }
+int ss_spec_floats(void) { return 2 * ssk::kSpecComplex; }
+int ss_version(void) { return 1; }
+
+int ss_init(void) {
+    ssk::Tables tb;
+    return get_tables(&tb);
+}
+
+int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out, int n_windows, void* stream) {
+    if (n_windows == 0) return 0;
+    if (!src || !win_desc || !spec_out || n_windows < 0) return SS_EINVAL;
+    ssk::SrcParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.src = src;
+    p.desc = win_desc;
+    p.spec = reinterpret_cast<float4*>(spec_out);
+    hipLaunchKernelGGL(ssk::k_source_windows, dim3(n_windows), dim3(ssk::kT), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
+static int fill_conv(ssk::ConvParams& p, const float* spec, const float* rir, const int* rir_len,
+                     const int* unit_desc, long long us, int cs, int es, int cap, int n_valid, int out_len) {
+    if (!spec || !rir || !rir_len || !unit_desc) return SS_EINVAL;
+    if (n_valid < 0 || out_len <= 0 || n_valid > out_len || n_valid > 3 * ssk::kB) return SS_EINVAL;
+    if (es < 1 || cs < 0 || us < 0 || cap < 0) return SS_EINVAL;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.spec = reinterpret_cast<const float4*>(spec);
+    p.rir = rir;
+    p.rir_len = rir_len;
+    p.desc = unit_desc;
+    p.out = nullptr;
+    p.sgram = nullptr;
+    p.rir_unit_stride = us;
+    p.rir_chan_stride = cs;
+    p.rir_elem_stride = es;
+    p.rir_cap = cap;
+    p.n_valid = n_valid;
+    p.out_len = out_len;
+    p.n_frames = n_frames_of(out_len);
+    p.t4 = t4_of(out_len);
+    p.pad_mode = 0;
+    return 0;
+}
+
+int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
+                            float* out, int n_units, long long rir_unit_stride, int rir_chan_stride,
+                            int rir_elem_stride, int rir_cap, int n_valid, int out_len, void* stream) {
+    if (n_units == 0) return 0;
+    if (!out || n_units < 0) return SS_EINVAL;
+    ssk::ConvParams p;
+    int rc = fill_conv(p, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
+                       rir_cap, n_valid, out_len);
+    if (rc) return rc;
+    p.out = out;
+    const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
+    return launch_conv<false>(p, n_units, nb_y, static_cast<hipStream_t>(stream));
+}
+
+int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream) {
+    if (n_units == 0) return 0;
+    if (!x || !out || n_units < 0 || len < ssk::kNfft / 2 + 1) return SS_EINVAL;   // reflect pad needs len > 256
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    ssk::SpecParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.x = x;
+    p.out = out;
+    p.len = len;
+    p.n_frames = n_frames_of(len);
+    p.t4 = t4_of(len);
+    p.pad_mode = pad_mode;
+    const int blocks_per_row = (p.t4 + 3) / 4;
+    hipLaunchKernelGGL(ssk::k_spectrogram, dim3(2 * n_units * blocks_per_row), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
+int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
+                     float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
+                     int rir_chan_stride, int rir_elem_stride, int rir_cap, int n_valid, int out_len,
+                     int pad_mode, void* stream) {
+    if (n_units == 0) return 0;
+    if (!spectrogram || n_units < 0) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (out_len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    ssk::ConvParams p;
+    int rc = fill_conv(p, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
+                       rir_cap, n_valid, out_len);
+    if (rc) return rc;
+    p.pad_mode = pad_mode;
+    if (out_len <= ssk::kB && p.t4 <= 26) {             // fused: waveform stays in LDS
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_conv<true>(p, n_units, 1, static_cast<hipStream_t>(stream));
+    }
+    if (!audiogoal) return SS_EINVAL;                   // long rows hand over through HBM/L2
+    rc = ss_fftconv_binaural_f32(spec, rir, rir_len, unit_desc, audiogoal, n_units, rir_unit_stride,
+                                 rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, stream);
+    if (rc) return rc;
+    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+}
+
+}  // extern "C"

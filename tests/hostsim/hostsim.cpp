@@ -1,0 +1,134 @@
+// hostsim.cpp — TEST INFRASTRUCTURE: runs the HIP kernels of sound-spaces_amd/csrc on the host, one workgroup
+// at a time, each thread a ucontext fiber, so tests/test_hostsim.py can compare them with the oracle on CPU.
+#include <ucontext.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+
+#include "hip_shim.h"
+#include "../../sound-spaces_amd/csrc/ss_kernels.hpp"
+#include "../../sound-spaces_amd/csrc/ss_tables.hpp"
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace {
+constexpr size_t kStack = 128 * 1024;
+ucontext_t g_main;
+std::vector<ucontext_t> g_ctx;
+std::vector<char> g_stacks;
+std::vector<char> g_done;
+std::vector<int> g_barriers;
+int g_cur = 0;
+std::function<void()> g_body;
+
+void fiber_entry() {
+    g_body();
+    g_done[g_cur] = 1;
+    swapcontext(&g_ctx[g_cur], &g_main);
+}
+
+// run one workgroup: every fiber is resumed round-robin until its next barrier (or its end)
+int run_block(int nthreads, const std::function<void()>& body) {
+    g_body = body;
+    g_ctx.assign(nthreads, ucontext_t{});
+    if (g_stacks.size() < kStack * nthreads) g_stacks.resize(kStack * nthreads);
+    g_done.assign(nthreads, 0);
+    g_barriers.assign(nthreads, 0);
+    for (int i = 0; i < nthreads; ++i) {
+        getcontext(&g_ctx[i]);
+        g_ctx[i].uc_stack.ss_sp = g_stacks.data() + kStack * i;
+        g_ctx[i].uc_stack.ss_size = kStack;
+        g_ctx[i].uc_link = &g_main;
+        makecontext(&g_ctx[i], fiber_entry, 0);
+    }
+    blockDim.x = nthreads;
+    for (;;) {
+        int live = 0;
+        for (int i = 0; i < nthreads; ++i) {
+            if (g_done[i]) continue;
+            g_cur = i;
+            threadIdx.x = i;
+            swapcontext(&g_main, &g_ctx[i]);
+            live += !g_done[i];
+        }
+        if (!live) break;
+    }
+    for (int i = 1; i < nthreads; ++i)
+        if (g_barriers[i] != g_barriers[0]) {
+            std::fprintf(stderr, "hostsim: divergent barrier count (thread %d: %d vs %d)\n", i, g_barriers[i], g_barriers[0]);
+            return -2;
+        }
+    return 0;
+}
+
+ssk::Tables host_tables() {
+    static std::vector<float> tab = ssk_host::build_tables();
+    ssk::Tables tb;
+    tb.twM = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTwMOff);
+    tb.twItem = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTwItemOff);
+    tb.tw512 = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTw512Off);
+    tb.win = tab.data() + ssk_host::kWinOff;
+    return tb;
+}
+}  // namespace
+
+void hostsim_syncthreads() {
+    ++g_barriers[g_cur];
+    const int me = g_cur;
+    swapcontext(&g_ctx[me], &g_main);
+    threadIdx.x = me;
+}
+
+extern "C" {
+
+int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
+    ssk::SrcParams p;
+    p.src = src; p.desc = desc; p.spec = reinterpret_cast<float4*>(spec); p.tb = host_tables();
+    gridDim = dim3{(unsigned)n_windows, 1, 1};
+    for (int w = 0; w < n_windows; ++w) {
+        blockIdx = dim3{(unsigned)w, 0, 0};
+        int rc = run_block(ssk::kT, [&] { ssk::k_source_windows(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hs_conv(int fuse, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
+            float* sgram, int n_units, long long us, int cs, int es, int cap, int n_valid, int out_len, int pad_mode) {
+    ssk::ConvParams p;
+    p.spec = reinterpret_cast<const float4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
+    p.out = out; p.sgram = sgram; p.tb = host_tables();
+    p.rir_unit_stride = us; p.rir_chan_stride = cs; p.rir_elem_stride = es; p.rir_cap = cap;
+    p.n_valid = n_valid; p.out_len = out_len;
+    p.n_frames = 1 + out_len / ssk::kHop;
+    p.t4 = (p.n_frames + 3) / 4;
+    p.pad_mode = pad_mode;
+    const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
+    if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
+    gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
+    for (int j = 0; j < nb_y; ++j)
+        for (int b = 0; b < 2 * n_units; ++b) {
+            blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
+            int rc = run_block(ssk::kT, [&] { if (fuse) ssk::k_conv<true>(p); else ssk::k_conv<false>(p); });
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mode) {
+    ssk::SpecParams p;
+    p.x = x; p.out = out; p.tb = host_tables();
+    p.len = len; p.n_frames = 1 + len / ssk::kHop; p.t4 = (p.n_frames + 3) / 4; p.pad_mode = pad_mode;
+    const int bpr = (p.t4 + 3) / 4;
+    gridDim = dim3{(unsigned)(2 * n_units * bpr), 1, 1};
+    for (int b = 0; b < 2 * n_units * bpr; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(256, [&] { ssk::k_spectrogram(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

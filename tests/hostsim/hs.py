@@ -1,0 +1,99 @@
+"""TEST INFRASTRUCTURE: ctypes front-end of tests/hostsim/libss_hostsim.so (the HIP kernels compiled for
+the host, see hostsim.cpp).  Mirrors the call sequence of the product renderer so descriptor planning is
+exercised too."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from ss_amd import planning as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(HERE, "libss_hostsim.so")
+        srcs = [os.path.join(HERE, f) for f in ("hostsim.cpp", "hip_shim.h")]
+        csrc = os.path.join(HERE, "..", "..", "sound-spaces_amd", "csrc")
+        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                                   "-include", "hip_shim.h", "hostsim.cpp", "-o", so], cwd=HERE)
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
+        interleaved=False):
+    """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
+    {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent).
+    Returns (audiogoal [N,2,out_len], spectrogram [N,65,T4,2] or None)."""
+    L = lib()
+    rir_bank = np.ascontiguousarray(rir_bank, dtype=np.float32)
+    R, _, cap = rir_bank.shape
+    nbh_max = max(1, P.ceil_div(cap, P.KB))
+    nby = max(1, P.ceil_div(n_valid, P.KB))
+    offs = np.cumsum([0] + [len(s) for s in sources])
+    flat = np.concatenate([np.asarray(s, np.float32) for s in sources]).astype(np.float32)
+    cache, rows = {}, []
+
+    def slot_of(sound, t0, wrap):
+        key = (sound, t0, wrap)
+        if key not in cache:
+            ws = P.plan_window_set(len(sources[sound]), t0, nbh_max, nby, wrap)
+            cache[key] = (sum(len(r) for r in rows), ws)
+            rows.append(P.window_desc_rows(ws, int(offs[sound]), len(sources[sound]), wrap))
+        return cache[key]
+
+    desc = np.zeros((len(units), 8), np.int32)
+    for n, u in enumerate(units):
+        if u.get("rir", -1) < 0:
+            desc[n] = P.unit_desc_row()
+            continue
+        s0, ws = slot_of(u["sound"], u["t0"], u.get("wrap", False))
+        if u.get("dis_rir", -1) >= 0:
+            d0, dws = slot_of(u["dis_sound"], u.get("dis_t0", 0), False)
+            desc[n] = P.unit_desc_row(u["rir"], s0, ws, u["dis_rir"], d0, dws)
+        else:
+            desc[n] = P.unit_desc_row(u["rir"], s0, ws)
+    wd = np.concatenate(rows) if rows else np.zeros((0, 4), np.int32)
+    wd = np.ascontiguousarray(wd, np.int32)
+    spec = np.zeros((max(1, len(wd)), P.SPEC_FLOATS), np.float32)
+    rc = L.hs_source_windows(_p(flat, ctypes.c_float), _p(wd, ctypes.c_int), _p(spec, ctypes.c_float), len(wd))
+    assert rc == 0, rc
+    N = len(units)
+    out = np.full((N, 2, out_len), np.nan, np.float32)
+    t4 = P.spectrogram_shape(out_len)[1]
+    sg = np.full((N, 65, t4, 2), np.nan, np.float32)
+    rl = np.ascontiguousarray(rir_len, np.int32)
+    if interleaved:
+        bank = np.ascontiguousarray(rir_bank.transpose(0, 2, 1))     # [R, cap, 2] wav layout
+        us, cs, es = 2 * cap, 1, 2
+    else:
+        bank, us, cs, es = rir_bank, 2 * cap, cap, 1
+    rc = L.hs_conv(int(fuse), _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
+                   _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
+                   N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode)
+    assert rc == 0, rc
+    if want_spectrogram and not fuse:
+        rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode)
+        assert rc == 0, rc
+    return out, (sg if (fuse or want_spectrogram) else None)
+
+
+def spectrogram(x, pad_mode=0):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    N, _, n = x.shape
+    sg = np.full((N, 65, P.spectrogram_shape(n)[1], 2), np.nan, np.float32)
+    rc = L.hs_spectrogram(_p(x, ctypes.c_float), _p(sg, ctypes.c_float), N, n, pad_mode)
+    assert rc == 0, rc
+    return sg

@@ -86,7 +86,7 @@ def test_unified_window_formula(name):
     # direct O(L*T) evaluation on three 96-sample output slices
     for a in (0, 7777, sr - 96):
         got = O.conv_window_direct(d["source"], d["rir"], t0 + a, 96)
-        assert O.relerr(got, ref[:, a:a + 96]) < 2e-6
+        assert np.abs(got - ref[:, a:a + 96]).max() < 2e-6 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap"])
@@ -99,7 +99,7 @@ def test_unified_window_formula_continuous(name):
     assert not ref[:, ns:].any()
     for a in (0, 1500, ns - 96):
         got = O.conv_window_direct(src3, d["rir"], d["sample_index"] + a, 96, wrap=True)
-        assert O.relerr(got, ref[:, a:a + 96]) < 2e-6
+        assert np.abs(got - ref[:, a:a + 96]).max() < 2e-6 * np.abs(ref).max()
 
 
 # ---- librosa.stft / skimage.block_reduce restatements, independent checks ----
