@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py — audio env-steps/s of the SoundSpaces audio-observation hot path on MI355X.
+
+A *step* = one pass of the hot path over one batch of synthetic input: for every env of the batch, RIR (resident
+in an HBM bank larger than the Infinity Cache) -> 2-ear FFT convolution with the env's source clip -> truncate to
+1 s -> STFT(512/160/400) -> |.| -> 4x4 mean pool -> log1p -> spectrogram [65, T4, 2] in device memory
+(reference: soundspaces/simulator.py:608-701 + soundspaces/tasks/nav.py:86-100, cache-miss path).
+Workload = BASELINE.json's metric shape: 128 envs, 16 kHz, 1-s clips, 2-channel RIRs of 1 s.
+
+  python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+N>1: every rank renders its own 128 envs (weak scaling, units are independent) and the per-rank spectrogram slabs
+are all-gathered over RCCL on a side stream (the exchange step BASELINE.json names); --exchange none times the
+collective-free DD-PPO arrangement instead.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sound-spaces_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def bytes_per_unit(sr, rir_len, t4):
+    """SURVEY.md 8(d) algorithmic bytes per env-step."""
+    b_rir = 2 * rir_len * 4
+    b_spec = 65 * t4 * 2 * 4
+    return {"fused": b_rir + b_spec, "conv": b_rir + 2 * sr * 4, "spec": 2 * sr * 4 + b_spec}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (scipy.signal.fftconvolve x2 + numpy restatement of librosa.stft/block_reduce),
+# one process per core like habitat.VectorEnv, timed for a bounded wall-clock budget.  Runs BEFORE CUDA init.
+def _cpu_worker(args):
+    seed, sr, seconds = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    from oracle import ss_oracle as O
+    rng = np.random.default_rng(seed)
+    src = O.synth_sources(rng, sr, k=4)
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=8)]
+    n, t_end = 0, time.perf_counter() + seconds
+    t0 = time.perf_counter()
+    while time.perf_counter() < t_end:
+        a = O.compute_audiogoal(src[n % 4], rirs[n % 8], sr)
+        O.compute_spectrogram(a)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(sr, seconds):
+    cores = os.cpu_count() or 1
+    one = _cpu_worker((0, sr, min(4.0, seconds)))
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(100 + i, sr, seconds) for i in range(cores)])
+    total = sum(n / dt for n, dt in res)
+    return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (scipy fftconvolve x2 + numpy STFT/pool/log1p), {cores} processes x {seconds:.0f} s, "
+                      f"sr={sr}, 1-s clip, 1-s RIR, caches off; 1 core: {one[0] / one[1]:.1f} env-steps/s"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def synth_rir_bank_device(torch, n, sr, length, device, seed):
+    """SURVEY 8(d) synthetic RIR bank generated on the GPU: decaying Gaussian noise + direct-path impulse,
+    peak-normalised to 0.5; float32 planar [n, 2, length]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    k = torch.arange(length, device=device, dtype=torch.float32)
+    out = torch.empty((n, 2, length), dtype=torch.float32, device=device)
+    chunk = 256
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        rt60 = torch.empty((m, 1, 1), device=device).uniform_(0.2, 0.8, generator=g)
+        gain = torch.empty((m, 2, 1), device=device).uniform_(0.5, 1.0, generator=g)
+        delay = torch.randint(0, int(0.0107 * sr), (m, 2, 1), device=device, generator=g)
+        h = torch.randn((m, 2, length), device=device, generator=g) * torch.exp(-6.9 * k / (rt60 * sr)) * 0.1 * gain
+        h = torch.where(k.view(1, 1, -1) < delay, torch.zeros_like(h), h)
+        h.scatter_add_(2, delay, gain)
+        h *= 0.5 / h.abs().amax(dim=(1, 2), keepdim=True)
+        out[lo:lo + m] = h
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=128, help="envs (units) per GPU per step")
+    ap.add_argument("--sr", type=int, default=16000)
+    ap.add_argument("--bank-mib", type=int, default=512, help="RIR bank size per GPU (> 256 MiB Infinity Cache)")
+    ap.add_argument("--sounds", type=int, default=102)
+    ap.add_argument("--exchange", choices=["allgather", "none"], default="allgather")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    sr, N = args.sr, args.envs
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sr, args.cpu_seconds)          # before any CUDA context exists (fork-safe)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import ss_oracle as O
+    from ss_amd import planning as P
+    from ss_amd.dist import SlabExchange
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic, HBM-resident inputs --------------------------------------------------------------
+    rng = np.random.default_rng(1000 + rank)
+    L = sr                                                   # RIR length = fallback shape (simulator.py:621)
+    R = max(64, (args.bank_mib << 20) // (2 * L * 4))
+    r = BatchedAudioRenderer(sr, device=dev)
+    for i, clip in enumerate(O.synth_sources(rng, sr, k=args.sounds)):
+        r.add_source(f"sound{i}", clip)
+    bank = synth_rir_bank_device(torch, R, sr, L, dev, seed=7 + rank)
+    r.set_rir_bank(RirBank(bank, torch.full((R,), L, dtype=torch.int32, device=dev)))
+    total = args.warmup + args.steps
+    descs = [r.plan_arrays(rng.integers(0, args.sounds, N), np.zeros(N, np.int64), rng.integers(0, R, N))
+             for _ in range(total)]
+    t4 = r.spectrogram_shape[1]
+    ex = SlabExchange((N,) + r.spectrogram_shape, device=dev) if (world > 1 and args.exchange == "allgather") else None
+    sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(2)]
+    ag_buf = torch.empty((N, 2, sr), dtype=torch.float32, device=dev) if (args.with_audiogoal or sr > P.KB) else None
+
+    def step(k):
+        if ex is not None:
+            r.render(descs[k], spectrogram_out=ex.next_local(), audiogoal_out=ag_buf)
+            ex.gather()
+        else:
+            r.render(descs[k], spectrogram_out=sg_buf[k & 1], audiogoal_out=ag_buf)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    if ex is not None:
+        ex.wait()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    ev0.record()
+    for k in range(args.warmup, total):
+        step(k)
+    ev1.record()
+    if ex is not None:
+        ex.wait()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps           # avg launch duration on the launch stream
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- secondary measurement: the convolution kernel alone (audiogoal written), same inputs -------------
+    conv_ms = None
+    if rank == 0:
+        ag = torch.empty((N, 2, sr), dtype=torch.float32, device=dev)
+        for k in range(min(10, total)):
+            r.render_audiogoal(descs[k], out=ag)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = min(100, args.steps)
+        e0.record()
+        for k in range(reps):
+            r.render_audiogoal(descs[args.warmup + k], out=ag)
+        e1.record()
+        torch.cuda.synchronize()
+        conv_ms = e0.elapsed_time(e1) / reps
+
+    if rank == 0:
+        b = bytes_per_unit(sr, L, t4)
+        fused = sr <= P.KB
+        dom_bytes = (b["fused"] if fused else b["conv"]) * N
+        ach = dom_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
+            "value": round(world * N * args.steps / elapsed, 1),
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N} envs/GPU x 1 rotation, sr={sr}, 1-s source clips ({args.sounds} sounds), "
+                                   f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident), "
+                                   "cache-miss path, spectrogram [65,%d,2] f32 out" % t4,
+                       "envs_per_gpu": N, "sampling_rate": sr, "rir_len": L,
+                       "exchange": (args.exchange if world > 1 else "none"), "kernel": "k_conv<fused>" if fused else
+                       "k_conv + k_spectrogram"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_conv<FUSE=true>" if fused else "k_conv<FUSE=false>+k_spectrogram",
+                         "bytes_per_unit": b["fused"] if fused else b["conv"], "units_per_launch": N,
+                         "avg_launch_ms": round(kernel_ms, 5)},
+        }
+        if conv_ms is not None:
+            a2 = b["conv"] * N / (conv_ms * 1e-3) / 1e9
+            out["roofline_conv_only"] = {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel": "k_conv<FUSE=false>",
+                                         "bytes_per_unit": b["conv"], "avg_launch_ms": round(conv_ms, 5)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

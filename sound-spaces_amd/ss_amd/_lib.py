@@ -1,0 +1,47 @@
+"""ctypes binding of libss_hip.so (include/ss_hip.h).  There is NO fallback: if the HIP library is
+missing or a call fails, the error is raised — the product never computes this path on the CPU."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libss_hip.so"))
+
+EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source_windows_f32",
+           "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32")
+
+_lib = None
+
+
+class SsHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SsHipError(f"{SO_PATH} not found: build it with `python sound-spaces_amd/build.py` "
+                         "(or __graft_entry__.build()); there is no CPU fallback for this path")
+    lib = ctypes.CDLL(SO_PATH)
+    c_int, c_ll, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+    lib.ss_block_len.restype = c_int
+    lib.ss_spec_floats.restype = c_int
+    lib.ss_version.restype = c_int
+    lib.ss_init.restype = c_int
+    lib.ss_source_windows_f32.argtypes = [vp, vp, vp, c_int, vp]
+    lib.ss_fftconv_binaural_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_spectrogram_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp]
+    lib.ss_audio_obs_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    for name in EXPORTS:
+        getattr(lib, name).restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = "invalid argument" if rc == -1 else f"hipError_t {-rc}"
+        raise SsHipError(f"{what} failed: {kind}")

@@ -1,0 +1,84 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+The audio path shards perfectly over (env, rotation) units — each unit reads its own RIR, sources are a small
+replicated bank — so ranks own contiguous blocks of units and render them with no data-path collective, exactly like
+the reference's DD-PPO where each rank owns its envs (ss_baselines/av_nav/ddppo/ddppo_trainer.py:140-142).
+The one exchange step (new; BASELINE.json north_star) is the all-gather of the per-rank spectrogram slab
+[N/G, 65, T4, 2] into the learner-side [N, 65, T4, 2] tensor.  The slab is small (1.7 MB for 128 envs @16 kHz), so the
+gather is issued on a side stream and double-buffered: step k's gather overlaps step k+1's convolution kernel.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_units: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of units owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_units, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def owner_of(unit: int, n_units: int, world: int) -> int:
+    base, rem = divmod(n_units, world)
+    edge = rem * (base + 1)
+    return unit // (base + 1) if unit < edge else rem + (unit - edge) // max(base, 1)
+
+
+class SlabExchange:
+    """All-gather of equally-shaped per-rank slabs, double-buffered on a side stream (GPU) or inline (CPU/gloo)."""
+
+    def __init__(self, slab_shape, dtype=torch.float32, device="cuda", group: Optional[dist.ProcessGroup] = None,
+                 depth: int = 2):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device(device)
+        self.slab_shape = tuple(slab_shape)
+        full = (self.world * self.slab_shape[0],) + self.slab_shape[1:]
+        self.depth = depth
+        self.local = [torch.empty(self.slab_shape, dtype=dtype, device=self.device) for _ in range(depth)]
+        self.full = [torch.empty(full, dtype=dtype, device=self.device) for _ in range(depth)]
+        self._k = 0
+        self._cuda = self.device.type == "cuda"
+        if self._cuda:
+            self.stream = torch.cuda.Stream(device=self.device)
+            self.ready = [torch.cuda.Event() for _ in range(depth)]     # gather k finished
+            self.filled = [torch.cuda.Event() for _ in range(depth)]    # slab k written by the compute stream
+
+    def next_local(self) -> torch.Tensor:
+        """Buffer the renderer should write this step's slab into (waits for the gather that last used it)."""
+        i = self._k % self.depth
+        if self._cuda and self._k >= self.depth:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[i])
+        return self.local[i]
+
+    def gather(self) -> torch.Tensor:
+        """Issue the all-gather of the slab handed out by the last next_local(); returns the [world*n, ...] tensor
+        (valid on the side stream after self.ready[i]; call wait() before consuming on the compute stream)."""
+        i = self._k % self.depth
+        self._k += 1
+        if self.world == 1:
+            self.full[i] = self.local[i]
+            return self.full[i]
+        if self._cuda:
+            self.filled[i].record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(self.filled[i])
+                dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
+                self.ready[i].record(self.stream)
+        else:
+            try:
+                dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
+            except (RuntimeError, NotImplementedError):
+                parts = list(self.full[i].chunk(self.world, dim=0))
+                dist.all_gather(parts, self.local[i], group=self.group)
+        return self.full[i]
+
+    def wait(self) -> None:
+        """Make the compute stream wait for the most recent gather."""
+        if self._cuda and self.world > 1 and self._k > 0:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[(self._k - 1) % self.depth])

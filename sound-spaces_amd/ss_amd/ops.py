@@ -1,0 +1,158 @@
+"""Tensor-level entry points of the HIP audio path + their registration as PyTorch custom ops
+(``torch.ops.ss_hip.*``).  PyTorch is plumbing here: device memory, streams, dispatch.  Every op runs the
+hand-written gfx950 kernels of csrc/ through the C ABI (include/ss_hip.h) on the caller's current stream;
+nothing syncs the host.
+
+Reference call sites replaced (facebookresearch/sound-spaces):
+  fftconv_binaural  soundspaces/simulator.py:629-647,649-664  (scipy.signal.fftconvolve per ear + slicing)
+  spectrogram       soundspaces/tasks/nav.py:86-100           (librosa.stft -> abs -> 4x4 mean -> log1p)
+  audio_obs         soundspaces/simulator.py:690-701          (both, fused; cache-miss path)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .planning import KB, SPEC_FLOATS, ceil_div, spectrogram_shape
+
+PAD_REFLECT, PAD_CONSTANT = 0, 1
+_PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.SsHipError(f"{name} must live on the GPU (got {t.device}); this path has no CPU implementation")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def _bank_strides(rir_bank: torch.Tensor, interleaved: bool):
+    if rir_bank.dim() != 3:
+        raise ValueError("rir_bank must be [R,2,L] (planar) or [R,L,2] (wav-interleaved)")
+    if interleaved:
+        R, cap, two = rir_bank.shape
+        assert two == 2
+        return 2 * cap, 1, 2, cap
+    R, two, cap = rir_bank.shape
+    assert two == 2
+    return 2 * cap, cap, 1, cap
+
+
+def init() -> None:
+    """Build the per-device constant tables (idempotent); also the explicit 'is the HIP path alive' probe."""
+    _lib.check(_lib.load().ss_init(), "ss_init")
+
+
+def source_windows_into(src: torch.Tensor, win_desc: torch.Tensor, spec_out: torch.Tensor) -> None:
+    _chk(src, torch.float32, "src"); _chk(win_desc, torch.int32, "win_desc"); _chk(spec_out, torch.float32, "spec_out")
+    W = win_desc.shape[0]
+    assert win_desc.shape == (W, 4) and spec_out.numel() >= W * SPEC_FLOATS
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().ss_source_windows_f32(src.data_ptr(), win_desc.data_ptr(), spec_out.data_ptr(), W,
+                                                     _stream()), "ss_source_windows_f32")
+
+
+def source_windows(src: torch.Tensor, win_desc: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((win_desc.shape[0], SPEC_FLOATS), dtype=torch.float32, device=src.device)
+    source_windows_into(src, win_desc, out)
+    return out
+
+
+def fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid: int, interleaved: bool = False) -> None:
+    _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
+    _chk(unit_desc, torch.int32, "unit_desc"); _chk(out, torch.float32, "out")
+    N, two, out_len = out.shape
+    assert two == 2 and unit_desc.shape == (N, 8)
+    us, cs, es, cap = _bank_strides(rir_bank, interleaved)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().ss_fftconv_binaural_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
+                                                       unit_desc.data_ptr(), out.data_ptr(), N, us, cs, es, cap,
+                                                       n_valid, out_len, _stream()), "ss_fftconv_binaural_f32")
+
+
+def fftconv_binaural(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, interleaved: bool = False):
+    out = torch.empty((unit_desc.shape[0], 2, out_len), dtype=torch.float32, device=spec.device)
+    fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid, interleaved)
+    return out
+
+
+def spectrogram_into(x: torch.Tensor, out: torch.Tensor, pad_mode="reflect") -> None:
+    _chk(x, torch.float32, "x"); _chk(out, torch.float32, "out")
+    N, two, n = x.shape
+    assert two == 2 and tuple(out.shape) == (N,) + spectrogram_shape(n)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ss_spectrogram_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], _stream()),
+                   "ss_spectrogram_f32")
+
+
+def spectrogram(x: torch.Tensor, pad_mode="reflect") -> torch.Tensor:
+    out = torch.empty((x.shape[0],) + spectrogram_shape(x.shape[2]), dtype=torch.float32, device=x.device)
+    spectrogram_into(x, out, pad_mode)
+    return out
+
+
+def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
+                   pad_mode="reflect", interleaved: bool = False) -> None:
+    """Fused observation.  ``audiogoal`` may be None when out_len <= KB (waveform never leaves the CU)."""
+    _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
+    _chk(unit_desc, torch.int32, "unit_desc"); _chk(spectrogram_out, torch.float32, "spectrogram_out")
+    N = unit_desc.shape[0]
+    assert tuple(spectrogram_out.shape) == (N,) + spectrogram_shape(out_len)
+    ag_ptr = None
+    if audiogoal is not None:
+        _chk(audiogoal, torch.float32, "audiogoal")
+        assert tuple(audiogoal.shape) == (N, 2, out_len)
+        ag_ptr = audiogoal.data_ptr()
+    us, cs, es, cap = _bank_strides(rir_bank, interleaved)
+    with torch.cuda.device(spec.device):
+        _lib.check(_lib.load().ss_audio_obs_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
+                                                unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N, us, cs,
+                                                es, cap, n_valid, out_len, _PAD[pad_mode], _stream()),
+                   "ss_audio_obs_f32")
+
+
+def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pad_mode="reflect",
+              want_audiogoal: bool = False, interleaved: bool = False):
+    N = unit_desc.shape[0]
+    need_ag = want_audiogoal or out_len > KB
+    ag = torch.empty((N, 2, out_len), dtype=torch.float32, device=spec.device) if need_ag else None
+    sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
+    audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved)
+    return ag, sg
+
+
+# ---- torch.ops.ss_hip.* ------------------------------------------------------------------------------
+def _register():
+    lib = torch.library.Library("ss_hip", "DEF")
+    lib.define("source_windows(Tensor src, Tensor win_desc) -> Tensor")
+    lib.define("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, "
+               "int out_len, bool interleaved=False) -> Tensor")
+    lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
+    lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+               "int pad_mode=0, bool interleaved=False) -> (Tensor, Tensor)")
+    lib.impl("source_windows", source_windows, "CUDA")
+    lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
+    lib.impl("spectrogram", lambda x, pad_mode=0: spectrogram(x, pad_mode), "CUDA")
+
+    def _audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode=0, interleaved=False):
+        ag, sg = audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode, True, interleaved)
+        return ag, sg
+    lib.impl("audio_obs", _audio_obs, "CUDA")
+
+    # shape functions (Meta) so the ops compose with tracing / fake tensors
+    lib.impl("source_windows", lambda src, wd: src.new_empty((wd.shape[0], SPEC_FLOATS)), "Meta")
+    lib.impl("fftconv_binaural", lambda spec, b, l, d, n_valid, out_len, interleaved=False:
+             spec.new_empty((d.shape[0], 2, out_len)), "Meta")
+    lib.impl("spectrogram", lambda x, pad_mode=0: x.new_empty((x.shape[0],) + spectrogram_shape(x.shape[2])), "Meta")
+    lib.impl("audio_obs", lambda spec, b, l, d, n_valid, out_len, pad_mode=0, interleaved=False:
+             (spec.new_empty((d.shape[0], 2, out_len)), spec.new_empty((d.shape[0],) + spectrogram_shape(out_len))),
+             "Meta")
+    return lib
+
+
+_TORCH_LIB = _register()

@@ -1,0 +1,226 @@
+"""BatchedAudioRenderer — the batched, device-resident replacement for the per-env, per-step audio code of
+``SoundSpacesSim`` (soundspaces/simulator.py:608-701) and ``ContinuousSoundSpacesSim``
+(soundspaces/continuous_simulator.py:413-462).
+
+One *unit* = one (env, rotation) observation.  The renderer owns
+
+* a source bank: every mono clip once in HBM (the reference keeps ``_source_sound_dict``, simulator.py:595-600),
+* an RIR bank: float32 planar ``[R, 2, cap]`` rows, zero padded, resident in HBM (the reference re-reads a wav
+  per step, simulator.py:615-618),
+* a cache of source-window spectra keyed ``(sound, t0, wrap)`` (the reference recomputes the source FFT inside
+  every ``fftconvolve`` call),
+
+and turns N unit requests into one kernel launch that writes ``[N, 65, T4, 2]`` spectrograms (and optionally the
+``[N, 2, sr]`` waveforms) on the caller's stream.  No host sync, no CPU arithmetic: if the HIP library is absent the
+constructor raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from . import planning as P
+
+
+class SourceBank:
+    """Mono source clips, float32, already resampled to the simulator rate (librosa.load(sr=...) upstream)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.names: Dict[str, int] = {}
+        self.lengths: List[int] = []
+        self.offsets: List[int] = []
+        self._host: List[np.ndarray] = []
+        self._flat: Optional[torch.Tensor] = None
+
+    def add(self, name: str, clip: np.ndarray) -> int:
+        if name in self.names:
+            return self.names[name]
+        clip = np.ascontiguousarray(clip, dtype=np.float32).reshape(-1)
+        sid = len(self.lengths)
+        self.names[name] = sid
+        self.offsets.append(sum(self.lengths))
+        self.lengths.append(int(clip.shape[0]))
+        self._host.append(clip)
+        self._flat = None
+        return sid
+
+    def flat(self) -> torch.Tensor:
+        if self._flat is None:
+            self._flat = torch.from_numpy(np.concatenate(self._host)).to(self.device)
+        return self._flat
+
+    def __len__(self):
+        return len(self.lengths)
+
+
+class RirBank:
+    """Binaural RIRs, planar float32 ``[R, 2, cap]`` on the device, rows zero beyond their own length
+    (the precondition of ss_fftconv_binaural_f32)."""
+
+    def __init__(self, data: torch.Tensor, lengths: torch.Tensor):
+        assert data.dim() == 3 and data.shape[1] == 2 and data.dtype == torch.float32 and data.is_contiguous()
+        assert lengths.dtype == torch.int32 and lengths.shape == (data.shape[0],)
+        self.data, self.lengths = data, lengths
+        self.cap = int(data.shape[2])
+
+    @staticmethod
+    def from_arrays(rirs: Sequence[Optional[np.ndarray]], device, cap: Optional[int] = None) -> "RirBank":
+        """rirs[i]: float array [L, 2] (wav layout, what scipy.io.wavfile.read returns) or [2, L];
+        None or an empty array = unreadable / empty file -> zero RIR (simulator.py:619-624)."""
+        norm = []
+        for r in rirs:
+            if r is None or np.size(r) == 0:
+                norm.append(np.zeros((2, 0), np.float32))
+                continue
+            r = np.asarray(r, dtype=np.float32)
+            norm.append(np.ascontiguousarray(r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r))
+        longest = max([a.shape[1] for a in norm] + [2])
+        cap = cap or longest
+        cap += cap & 1                       # even capacity: 8-byte aligned rows for the float2 loads
+        assert cap >= longest
+        host = np.zeros((len(norm), 2, cap), np.float32)
+        for i, a in enumerate(norm):
+            host[i, :, :a.shape[1]] = a
+        lens = np.array([a.shape[1] for a in norm], np.int32)
+        return RirBank(torch.from_numpy(host).to(device), torch.from_numpy(lens).to(device))
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+
+@dataclass
+class UnitRequest:
+    """What one env contributes per step (the reference state read by _compute_audiogoal):
+    sound / t0 from (_current_sound, _audio_index) or (_current_sample_index); rir = bank slot of
+    (scene, azimuth, receiver, source); silent = _episode_step_count > _duration."""
+    sound: int = 0
+    t0: int = 0
+    rir: int = -1
+    silent: bool = False
+    dis_sound: int = -1
+    dis_rir: int = -1
+
+
+class BatchedAudioRenderer:
+    def __init__(self, sampling_rate: int, device="cuda", pad_mode: str = "reflect",
+                 step_time: Optional[float] = None, wrap: bool = False, spec_capacity: int = 64):
+        """step_time None -> SoundSpaces 1.0 semantics (1-s observations).  step_time = 0.25 with wrap=True ->
+        SoundSpaces 2.0 (_convolve_with_rir): int(sr*step_time) samples computed, zero-padded to 1 s."""
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ops._lib.SsHipError("BatchedAudioRenderer needs an MI355X (device='cuda'); there is no CPU path")
+        ops.init()
+        self.sr = int(sampling_rate)
+        self.out_len = self.sr
+        self.n_valid = self.sr if step_time is None else int(self.sr * step_time)
+        self.wrap = bool(wrap)
+        self.pad_mode = pad_mode
+        self.nby = max(1, P.ceil_div(self.n_valid, P.KB))
+        self.sources = SourceBank(self.device)
+        self.rirs: Optional[RirBank] = None
+        self._spec = torch.empty((spec_capacity, P.SPEC_FLOATS), dtype=torch.float32, device=self.device)
+        self._n_slots = 0
+        self._windows: Dict[Tuple[int, int, bool], Tuple[int, P.WindowSet]] = {}
+        self.spectrogram_shape = P.spectrogram_shape(self.out_len)
+
+    # ---- banks ---------------------------------------------------------------------------------------
+    def add_source(self, name: str, clip: np.ndarray) -> int:
+        return self.sources.add(name, clip)
+
+    def set_rir_bank(self, bank: RirBank) -> None:
+        if self.rirs is not None and bank.cap != self.rirs.cap:
+            self.clear_window_cache()            # the set of needed partition offsets depends on the capacity
+        self.rirs = bank
+
+    def clear_window_cache(self) -> None:
+        self._windows.clear()
+        self._n_slots = 0
+
+    # ---- planning --------------------------------------------------------------------------------------
+    def _ensure_windows(self, keys) -> None:
+        new = [k for k in dict.fromkeys(keys) if k not in self._windows]
+        if not new:
+            return
+        nbh_max = max(1, P.ceil_div(self.rirs.cap, P.KB))
+        rows, first = [], self._n_slots
+        for (sid, t0, wrap) in new:
+            ws = P.plan_window_set(self.sources.lengths[sid], t0, nbh_max, self.nby, wrap)
+            self._windows[(sid, t0, wrap)] = (self._n_slots, ws)
+            rows.append(P.window_desc_rows(ws, self.sources.offsets[sid], self.sources.lengths[sid], wrap))
+            self._n_slots += ws.count
+        if self._n_slots > self._spec.shape[0]:
+            grown = torch.empty((max(self._n_slots, 2 * self._spec.shape[0]), P.SPEC_FLOATS),
+                                dtype=torch.float32, device=self.device)
+            grown[:first] = self._spec[:first]
+            self._spec = grown
+        wd = np.concatenate(rows) if rows else np.zeros((0, 4), np.int32)
+        if len(wd):
+            wd_dev = torch.from_numpy(np.ascontiguousarray(wd)).to(self.device)
+            ops.source_windows_into(self.sources.flat(), wd_dev, self._spec[first:first + len(wd)])
+
+    def plan(self, units: Sequence[UnitRequest]) -> torch.Tensor:
+        """-> int32 [N, 8] unit descriptors on the device; computes any missing source-window spectra."""
+        assert self.rirs is not None, "set_rir_bank() first"
+        keys = []
+        for u in units:
+            if not u.silent and u.rir >= 0:
+                keys.append((u.sound, u.t0, self.wrap))
+                if u.dis_rir >= 0:
+                    keys.append((u.dis_sound, 0, False))          # distractor: whole clip, full conv (:659-664)
+        self._ensure_windows(keys)
+        desc = np.zeros((len(units), 8), np.int32)
+        for n, u in enumerate(units):
+            if u.silent or u.rir < 0:
+                desc[n] = P.unit_desc_row()
+                continue
+            s0, ws = self._windows[(u.sound, u.t0, self.wrap)]
+            if u.dis_rir >= 0:
+                d0, dws = self._windows[(u.dis_sound, 0, False)]
+                desc[n] = P.unit_desc_row(u.rir, s0, ws, u.dis_rir, d0, dws)
+            else:
+                desc[n] = P.unit_desc_row(u.rir, s0, ws)
+        return torch.from_numpy(desc).to(self.device, non_blocking=True)
+
+    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> torch.Tensor:
+        """Vector form of plan() for the common no-distractor case (rir < 0 = silent)."""
+        return self.plan([UnitRequest(int(s), int(t), int(r)) for s, t, r in zip(sound, t0, rir)])
+
+    # ---- rendering ---------------------------------------------------------------------------------------
+    def render(self, unit_desc: torch.Tensor, want_audiogoal: bool = False,
+               audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
+        """One launch (two for rows longer than one partition block) on the current stream.
+        Returns (audiogoal [N,2,sr] or None, spectrogram [N,65,T4,2])."""
+        N = unit_desc.shape[0]
+        need_ag = want_audiogoal or audiogoal_out is not None or self.out_len > P.KB
+        ag = audiogoal_out
+        if need_ag and ag is None:
+            ag = torch.empty((N, 2, self.out_len), dtype=torch.float32, device=self.device)
+        sg = spectrogram_out
+        if sg is None:
+            sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
+        ops.audio_obs_into(self._spec, self.rirs.data, self.rirs.lengths, unit_desc, ag, sg, self.n_valid,
+                           self.out_len, self.pad_mode)
+        return (ag if (want_audiogoal or audiogoal_out is not None) else None), sg
+
+    def render_audiogoal(self, unit_desc: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """AudioGoalSensor-only configurations (soundspaces/tasks/nav.py:37-60)."""
+        if out is None:
+            out = torch.empty((unit_desc.shape[0], 2, self.out_len), dtype=torch.float32, device=self.device)
+        ops.fftconv_binaural_into(self._spec, self.rirs.data, self.rirs.lengths, unit_desc, out, self.n_valid)
+        return out
+
+    def render_crossfaded(self, desc_last: torch.Tensor, desc_cur: torch.Tensor):
+        """SS2.0 CROSSFADE (continuous_simulator.py:47-53, 422-424): the step is convolved with the previous and the
+        current RIR and blended by a linear ramp over int(0.05*sr)+1 samples.  Two convolution launches, a torch
+        blend on the first 801/2206 samples, then the stand-alone spectrogram kernel."""
+        a_last = self.render_audiogoal(desc_last)
+        a_cur = self.render_audiogoal(desc_cur)
+        n = int(0.05 * self.sr)
+        w2 = torch.arange(n + 1, device=self.device, dtype=torch.float32) / n
+        a_cur[:, :, :n + 1] = a_last[:, :, :n + 1] * w2.flip(0) + a_cur[:, :, :n + 1] * w2
+        return a_cur, ops.spectrogram(a_cur, self.pad_mode)

@@ -1,0 +1,155 @@
+"""The HIP kernel sources, compiled for the host by tests/hostsim (fibers instead of lanes), against the
+oracle and the reference-generated golden vectors.  This checks the index algebra of the kernels (LDS
+layouts, radix passes, Hermitian item pairing, partition planning) on CPU; the same cases run on the real
+MI355X in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import ss_oracle as O
+from golden_util import golden, case_inputs, case_outputs
+from ss_amd import planning as P
+
+hs = pytest.importorskip("hostsim.hs")
+
+TOL = 1e-4      # north-star tolerance: max|got-ref| / max|ref|  (fp32)
+
+
+def planar(rir_wav, cap=None):
+    """[L,2] wav layout -> [1,2,cap] zero-padded planar bank"""
+    L = rir_wav.shape[0]
+    cap = cap or (L + (L & 1))
+    b = np.zeros((1, 2, cap), np.float32)
+    b[0, :, :L] = rir_wav.T
+    return b
+
+
+def check(got, ref, tol=TOL):
+    assert not np.isnan(got).any()
+    assert O.relerr(got, ref) <= tol, O.relerr(got, ref)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+SIM_CASES = [c for c in golden()[1] if c.startswith(("clip1s", "multi_")) and not c.endswith("44k")]
+
+
+@pytest.mark.parametrize("name", SIM_CASES)
+def test_sim_branches_vs_reference_vectors(name):
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [d["rir"].shape[0]], [dict(sound=0, t0=t0, rir=0)],
+                     sr, sr, fuse=True)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+def test_unfused_equals_fused_and_interleaved_layout():
+    d = case_inputs("clip1s_ragged")
+    sr = d["sr"]
+    bank = planar(d["rir"])
+    u = [dict(sound=0, t0=0, rir=0)]
+    a1, s1 = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, fuse=True)
+    a2, s2 = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, fuse=False, want_spectrogram=True)
+    a3, _ = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, interleaved=True)
+    np.testing.assert_array_equal(a1, a2)
+    np.testing.assert_array_equal(a1, a3)
+    np.testing.assert_array_equal(s1, s2)
+
+
+def test_distractor_silent_and_zero_rir_in_one_batch():
+    d = case_inputs("distractor")
+    sr = d["sr"]
+    bank = np.concatenate([planar(d["rir"]), planar(d["distractor_rir"]), np.zeros((1, 2, sr), np.float32)])
+    units = [dict(sound=0, t0=0, rir=0, dis_sound=1, dis_t0=0, dis_rir=1),   # source + distractor
+             dict(rir=-1),                                                     # silent (simulator.py:610)
+             dict(sound=0, t0=0, rir=2),                                       # unreadable RIR -> zero RIR
+             dict(sound=0, t0=0, rir=0)]                                       # plain
+    # entry 2 has rir_len 0 ("empty RIR file") and a zero row
+    out, sg = hs.run([d["source"], d["distractor"]], bank, [sr, sr, 0], units, sr, sr, fuse=True)
+    ref_a, ref_s, stride = case_outputs("distractor")
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+    for n in (1, 2):
+        assert not out[n].any() and not sg[n].any()          # exact zeros (belief_predictor.py keys on them)
+    ref_plain, _, st = case_outputs("clip1s")
+    check(out[3][:, ::st], ref_plain)
+
+
+def test_zero_rir_with_full_length():
+    d = case_inputs("clip1s")
+    sr = d["sr"]
+    out, sg = hs.run([d["source"]], np.zeros((1, 2, sr), np.float32), [sr], [dict(sound=0, t0=0, rir=0)],
+                     sr, sr, fuse=True)
+    assert not out.any() and not sg.any()
+
+
+@pytest.mark.parametrize("name", ["savi_i0", "savi_i2"])
+def test_savi_dataset_variant(name):
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    t0 = P.window_start_savi_dataset(d["rir"].shape[0], sr, d["audio_index"])
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [d["rir"].shape[0]], [dict(sound=0, t0=t0, rir=0)],
+                     sr, sr, fuse=True)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+@pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap"])
+def test_continuous_simulator_windows(name):
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    out, sg = hs.run([src3], planar(d["rir"]), [d["rir"].shape[0]],
+                     [dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=True)],
+                     ns, sr, fuse=True)
+    assert not out[0][:, ns:].any()
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+def test_44k_three_output_blocks_three_rir_blocks():
+    d = case_inputs("clip1s_44k")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("clip1s_44k")
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [sr], [dict(sound=0, t0=0, rir=0)], sr, sr,
+                     fuse=False, want_spectrogram=True)
+    assert sg.shape[1:] == (65, 69, 2)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+def test_long_rir_two_blocks_multisecond_steady():
+    """RIR longer than one partition block (1.5 s at 16 kHz) in the steady branch: negative offsets m."""
+    d = case_inputs("multi_L1.5_i4")
+    sr = d["sr"]
+    assert d["rir"].shape[0] > P.KB
+    ws = P.plan_window_set(len(d["source"]), 4 * sr, 2, 1)
+    assert (ws.m_min, ws.count) == (-1, 2)
+
+
+def test_spectrogram_kernel_pad_modes_and_edges():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 2, 16000)).astype(np.float32)
+    x[1, :, :300] = 0.0
+    for pm, name in ((0, "reflect"), (1, "constant")):
+        got = hs.spectrogram(x, pad_mode=pm)
+        for n in range(2):
+            check(got[n], O.compute_spectrogram(x[n], pad_mode=name))
+    assert hs.spectrogram(np.ones((1, 2, 16000), np.float32)).shape == (1, 65, 26, 2)   # nav.py:77 KAT
+
+
+def test_window_planning():
+    # 1-s clip at 16 kHz: only m = 0 is non-zero
+    ws = P.plan_window_set(16000, 0, 1, 1)
+    assert (ws.m_min, ws.count, ws.starts) == (0, 1, (-P.KB,))
+    # 44.1 kHz: three RIR blocks x three output blocks, m in 0..2 (negative offsets are all-zero windows)
+    ws = P.plan_window_set(44100, 0, 3, 3)
+    assert (ws.m_min, ws.count) == (0, 3)
+    # source exhausted -> nothing to do
+    assert P.plan_window_set(16000, 5 * P.KB, 1, 1).count == 0
+    row = P.unit_desc_row()
+    assert row[0] == -1 and row[4] == -1
