@@ -52,10 +52,13 @@ def test_sim_branches_vs_reference_vectors(name):
     ag, sg = r.render(r.plan([UnitRequest(0, t0, 0)]), want_audiogoal=True)
     check(ag[0].cpu().numpy()[:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
-    # unfused path and torch custom-op path give the same bits
+    # unfused kernels and the torch custom-op path agree with the fused kernel to fp32 rounding (the two
+    # template instantiations contract FMAs differently, so not bit-for-bit)
     ag2 = r.render_audiogoal(r.plan([UnitRequest(0, t0, 0)]))
-    assert torch.equal(ag, ag2)
-    assert torch.equal(torch.ops.ss_hip.spectrogram(ag2, 0), sg)
+    scale = float(ag.abs().max())
+    assert float((ag - ag2).abs().max()) <= 2e-6 * scale
+    sg2 = torch.ops.ss_hip.spectrogram(ag2, 0)
+    assert float((sg - sg2).abs().max()) <= 1e-5 * float(sg.abs().max())
 
 
 def test_distractor_silent_zero_rir_batch():
