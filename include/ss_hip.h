@@ -34,6 +34,8 @@ extern "C" {
 #define SS_EINVAL (-1)
 #define SS_PAD_REFLECT 0   /* librosa < 0.10 default (the reference's era), torch.stft default */
 #define SS_PAD_CONSTANT 1  /* librosa >= 0.10 default */
+/* flags: promises from the caller that let the library pick a leaner kernel */
+#define SS_FLAG_NO_DISTRACTOR 1  /* term 1 of every unit descriptor is absent ([4] == -1); it is then ignored */
 
 /* Geometry constants of the partitioned convolution. */
 int ss_block_len(void);        /* kB = 16384 real samples per partition block                     */
@@ -66,7 +68,7 @@ int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out
 int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_len,
                             const int* unit_desc, float* out, int n_units,
                             long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
-                            int rir_cap, int n_valid, int out_len, void* stream);
+                            int rir_cap, int n_valid, int out_len, int flags, void* stream);
 
 /* Spectrogram of x [n_units, 2, len] -> out [n_units, 65, ceil((1+len/160)/4), 2] (channel-last). */
 int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream);
@@ -76,7 +78,7 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units,
                      long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
-                     int rir_cap, int n_valid, int out_len, int pad_mode, void* stream);
+                     int rir_cap, int n_valid, int out_len, int pad_mode, int flags, void* stream);
 
 #ifdef __cplusplus
 }

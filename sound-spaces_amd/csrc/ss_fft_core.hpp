@@ -27,7 +27,7 @@
 // with those of the matching inverse pass: keeping ~30 values alive across the whole kernel costs
 // scratch spills at the 128-VGPR budget of a 1024-thread workgroup.  (No-op in the host-side test build.)
 #if defined(__HIP_DEVICE_COMPILE__)
-#define SSK_OPAQUE2(v) asm volatile("" : "+v"((v).x), "+v"((v).y))
+#define SSK_OPAQUE2(v) asm volatile("" : "+v"(v))
 #define SSK_OPAQUE1(v) asm volatile("" : "+v"(v))
 #else
 #define SSK_OPAQUE2(v) (void)(v)
@@ -35,6 +35,24 @@
 #endif
 
 namespace ssk {
+
+// Complex value = native 2-vector so that it lives in an aligned VGPR pair and can be the operand of the
+// CDNA packed-f32 instructions (v_pk_add/mul/fma_f32 process both halves of a pair per issue slot).
+typedef float c32 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c32 mk2(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+
+// Wave-scope synchronisation for LDS regions owned by a single wave: the LDS unit executes one wave's
+// instructions in issue order, so only the compiler has to be kept from reordering (no s_barrier).
+__device__ __forceinline__ void wave_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#elif defined(SSK_HOSTSIM)
+    hostsim_wave_sync();
+#endif
+}
 
 constexpr int kM = 16384;            // complex points of one block FFT
 constexpr int kB = 16384;            // real samples of one partition block (FFT covers 2*kB)
@@ -44,69 +62,110 @@ constexpr int kSpecComplex = 16384;  // complex values of one stored block spect
 constexpr int kTwM = 1024;           // entries of twM:  exp(-2*pi*i*t/16384), t < 1024
 constexpr int kTwItem = 2048;        // entries of twItem: exp(-2*pi*i*gA(q)/32768), q < 2048
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// ---- complex primitives ---------------------------------------------------------------------------
+// The kernels are VALU-issue bound, so every primitive is ONE packed instruction (two for a complex
+// multiply): the op_sel / neg operand modifiers of v_pk_*_f32 do the half swaps and sign flips that
+// conjugation and multiplication by +-i need, which the compiler otherwise materialises as v_mov/v_xor.
+//   op_sel[k]    : which half of source k feeds the LOW result lane  (0 = .x, 1 = .y)
+//   op_sel_hi[k] : which half of source k feeds the HIGH result lane (default 1 = .y)
+//   neg_lo/neg_hi: negate source k for the low / high lane
+// The host (test) build computes the same values in plain C++.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSK_PK2(NAME, ASM, EXPR)                                                                    \
+    __device__ __forceinline__ c32 NAME(c32 a, c32 b) {                                             \
+        c32 r;                                                                                      \
+        asm(ASM : "=v"(r) : "v"(a), "v"(b));                                                        \
+        return r;                                                                                   \
+    }
+#else
+#define SSK_PK2(NAME, ASM, EXPR) \
+    __device__ __forceinline__ c32 NAME(c32 a, c32 b) { return EXPR; }
+#endif
+
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return a + b; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return a - b; }
+// a + conj(b), a - conj(b)
+SSK_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]", mk2(a.x + b.x, a.y - b.y))
+SSK_PK2(sub_conj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]", mk2(a.x - b.x, a.y + b.y))
+// a - i*b, a + i*b
+SSK_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]", mk2(a.x + b.y, a.y - b.x))
+SSK_PK2(add_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]", mk2(a.x - b.y, a.y + b.x))
+// conj(a + i*b), conj(a - i*b)
+SSK_PK2(conj_add_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]",
+        mk2(a.x - b.y, -a.y - b.x))
+SSK_PK2(conj_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]", mk2(a.x + b.y, -a.y + b.x))
+
+// a * w and a * conj(w): (a.x*w.x, a.x*w.y) then fused (-+a.y*w.y, +-a.y*w.x)
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    return mk2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+#endif
 }
-// a * conj(b)
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+__device__ __forceinline__ c32 cmulc(c32 a, c32 w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+#else
+    return mk2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+#endif
 }
-// a * (INV ? conj(b) : b)
+// same with a compile-time constant twiddle held in an SGPR pair (costs no VGPRs)
+__device__ __forceinline__ c32 cmul_k(c32 a, float wx, float wy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const c32 w = mk2(wx, wy);
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+#else
+    return mk2(a.x * wx - a.y * wy, a.x * wy + a.y * wx);
+#endif
+}
 template <bool INV>
-__device__ __forceinline__ float2 cmul_dir(float2 a, float2 b) { return INV ? cmulc(a, b) : cmul(a, b); }
+__device__ __forceinline__ c32 cmul_dir(c32 a, c32 w) { return INV ? cmulc(a, w) : cmul(a, w); }
 
 // 4-point DFT in place, natural-order outputs.  INV = conjugate kernel (no scaling).
-template <bool INV>
-__device__ __forceinline__ void bfly4(float2& a, float2& b, float2& c, float2& d) {
-    const float2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+// CROT: input c is to be multiplied by -+i first (the W16^4 twiddle), folded into the first add/sub.
+template <bool INV, bool CROT = false>
+__device__ __forceinline__ void bfly4(c32& a, c32& b, c32& c, c32& d) {
+    c32 t0, t1;
+    if (!CROT) { t0 = cadd(a, c); t1 = csub(a, c); }
+    else if (!INV) { t0 = add_mi(a, c); t1 = add_pi(a, c); }     // c' = -i c
+    else { t0 = add_pi(a, c); t1 = add_mi(a, c); }               // c' = +i c
+    const c32 t2 = cadd(b, d), t3 = csub(b, d);
     a = cadd(t0, t2);
     c = csub(t0, t2);
-    if (!INV) {
-        b = make_float2(t1.x + t3.y, t1.y - t3.x);   // t1 - i*t3
-        d = make_float2(t1.x - t3.y, t1.y + t3.x);   // t1 + i*t3
-    } else {
-        b = make_float2(t1.x - t3.y, t1.y + t3.x);
-        d = make_float2(t1.x + t3.y, t1.y - t3.x);
-    }
+    if (!INV) { b = add_mi(t1, t3); d = add_pi(t1, t3); }
+    else { b = add_pi(t1, t3); d = add_mi(t1, t3); }
 }
 
-// x *= exp(-+2*pi*i*m/16) for the seven exponents a 4x4 Cooley-Tukey step needs.
-template <bool INV, int MEXP>
-__device__ __forceinline__ float2 tw16(float2 a) {
+// 16-point DFT of x[0..15]; result in NATURAL order in x (X[r] = sum_j x[j] W^{jr}).  80 packed instructions.
+template <bool INV>
+__device__ __forceinline__ void fft16(c32 (&x)[16]) {
     constexpr float C = 0.92387953251128674f;   // cos(pi/8)
     constexpr float S = 0.38268343236508977f;   // sin(pi/8)
     constexpr float H = 0.70710678118654752f;   // sqrt(1/2)
-    // forward twiddle value (re, im); inverse uses the conjugate
-    if (MEXP == 0) return a;
-    if (MEXP == 4) return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);          // -+i
-    if (MEXP == 2) return INV ? make_float2(H * (a.x - a.y), H * (a.x + a.y))
-                              : make_float2(H * (a.x + a.y), H * (a.y - a.x));            // (H, -+H)
-    if (MEXP == 6) return INV ? make_float2(-H * (a.x + a.y), H * (a.x - a.y))
-                              : make_float2(H * (a.y - a.x), -H * (a.x + a.y));           // (-H, -+H)
-    float2 w = make_float2(1.f, 0.f);
-    if (MEXP == 1) w = make_float2(C, -S);
-    if (MEXP == 3) w = make_float2(S, -C);
-    if (MEXP == 9) w = make_float2(-C, S);
-    return cmul_dir<INV>(a, w);
-}
-
-// 16-point DFT of x[0..15]; result in NATURAL order in x (X[r] = sum_j x[j] W^{jr}).
-template <bool INV>
-__device__ __forceinline__ void fft16(float2 (&x)[16]) {
+    constexpr float sg = INV ? 1.f : -1.f;      // forward twiddles are exp(-i...), inverse their conjugates
     // j = 4*j1 + j0, r = r1 + 4*r0
 #pragma unroll
     for (int j0 = 0; j0 < 4; ++j0) bfly4<INV>(x[j0], x[j0 + 4], x[j0 + 8], x[j0 + 12]);
-    // x[j0 + 4*r1] now holds A[j0][r1]; twiddle by W16^{j0*r1}
-    x[5] = tw16<INV, 1>(x[5]);   x[9] = tw16<INV, 2>(x[9]);    x[13] = tw16<INV, 3>(x[13]);
-    x[6] = tw16<INV, 2>(x[6]);   x[10] = tw16<INV, 4>(x[10]);  x[14] = tw16<INV, 6>(x[14]);
-    x[7] = tw16<INV, 3>(x[7]);   x[11] = tw16<INV, 6>(x[11]);  x[15] = tw16<INV, 9>(x[15]);
-#pragma unroll
-    for (int r1 = 0; r1 < 4; ++r1) bfly4<INV>(x[4 * r1], x[4 * r1 + 1], x[4 * r1 + 2], x[4 * r1 + 3]);
-    // x[4*r1 + r0] = X[r1 + 4*r0]  -> transpose the 4x4 register tile
-    float2 t;
+    // x[j0 + 4*r1] now holds A[j0][r1]; twiddle by W16^{j0*r1} (x[10]: W16^4 = -+i is folded into its butterfly)
+    x[5] = cmul_k(x[5], C, sg * S);    x[9] = cmul_k(x[9], H, sg * H);     x[13] = cmul_k(x[13], S, sg * C);
+    x[6] = cmul_k(x[6], H, sg * H);                                          x[14] = cmul_k(x[14], -H, sg * H);
+    x[7] = cmul_k(x[7], S, sg * C);    x[11] = cmul_k(x[11], -H, sg * H);   x[15] = cmul_k(x[15], -C, -sg * S);
+    bfly4<INV>(x[0], x[1], x[2], x[3]);
+    bfly4<INV>(x[4], x[5], x[6], x[7]);
+    bfly4<INV, true>(x[8], x[9], x[10], x[11]);
+    bfly4<INV>(x[12], x[13], x[14], x[15]);
+    // x[4*r1 + r0] = X[r1 + 4*r0]  -> transpose the 4x4 register tile (pure renaming once unrolled)
+    c32 t;
     t = x[1];  x[1] = x[4];   x[4] = t;
     t = x[2];  x[2] = x[8];   x[8] = t;
     t = x[3];  x[3] = x[12];  x[12] = t;
@@ -115,18 +174,19 @@ __device__ __forceinline__ void fft16(float2 (&x)[16]) {
     t = x[11]; x[11] = x[14]; x[14] = t;
 }
 
-// x[r] *= w^r (INV: conj(w)^r), r = 1..15, powers built by a depth<=4 product chain.
+// x[r] *= w^r (INV: conj(w)^r), r = 1..15; powers of w by a depth<=4 product chain.  58 packed instructions.
 template <bool INV>
-__device__ __forceinline__ void twiddle16(float2 (&x)[16], float2 w) {
-    if (INV) w = cconj(w);
-    const float2 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
-    x[1] = cmul(x[1], w);  x[2] = cmul(x[2], w2);  x[3] = cmul(x[3], w3);  x[4] = cmul(x[4], w4);
-    const float2 w5 = cmul(w4, w), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
-    x[5] = cmul(x[5], w5);  x[6] = cmul(x[6], w6);  x[7] = cmul(x[7], w7);  x[8] = cmul(x[8], w8);
-    x[9] = cmul(x[9], cmul(w8, w));    x[10] = cmul(x[10], cmul(w5, w5));
-    x[11] = cmul(x[11], cmul(w8, w3)); x[12] = cmul(x[12], cmul(w6, w6));
-    x[13] = cmul(x[13], cmul(w8, w5)); x[14] = cmul(x[14], cmul(w7, w7));
-    x[15] = cmul(x[15], cmul(w8, w7));
+__device__ __forceinline__ void twiddle16(c32 (&x)[16], c32 w) {
+    const c32 w2 = cmul(w, w), w3 = cmul(w2, w), w4 = cmul(w2, w2);
+    x[1] = cmul_dir<INV>(x[1], w);   x[2] = cmul_dir<INV>(x[2], w2);
+    x[3] = cmul_dir<INV>(x[3], w3);  x[4] = cmul_dir<INV>(x[4], w4);
+    const c32 w5 = cmul(w4, w), w6 = cmul(w3, w3), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+    x[5] = cmul_dir<INV>(x[5], w5);  x[6] = cmul_dir<INV>(x[6], w6);
+    x[7] = cmul_dir<INV>(x[7], w7);  x[8] = cmul_dir<INV>(x[8], w8);
+    x[9] = cmul_dir<INV>(x[9], cmul(w8, w));     x[10] = cmul_dir<INV>(x[10], cmul(w5, w5));
+    x[11] = cmul_dir<INV>(x[11], cmul(w8, w3));  x[12] = cmul_dir<INV>(x[12], cmul(w6, w6));
+    x[13] = cmul_dir<INV>(x[13], cmul(w8, w5));  x[14] = cmul_dir<INV>(x[14], cmul(w7, w7));
+    x[15] = cmul_dir<INV>(x[15], cmul(w8, w7));
 }
 
 // ---- LDS layouts ------------------------------------------------------------
@@ -152,13 +212,13 @@ __device__ __forceinline__ int item_gA(int q) {
 
 // pass 2 (forward, in place, layout A): a' = t>>6, low2 = t&63
 template <bool INV>
-__device__ __forceinline__ void pass2(float2* lds, const float2* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass2(c32* lds, const c32* __restrict__ twM, int t) {
     // posA(a'*1024 + b*64 + low2) = a'*1040 + low2 + 65*b : one base register + immediate offsets
-    float2* base = lds + (t >> 6) * 1040 + (t & 63);
-    float2 x[16];
+    c32* base = lds + (t >> 6) * 1040 + (t & 63);
+    c32 x[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) x[b] = base[65 * b];
-    float2 w = twM[16 * (t & 63)];
+    c32 w = twM[16 * (t & 63)];
     SSK_OPAQUE2(w);
     if (INV) twiddle16<true>(x, w);
     fft16<INV>(x);
@@ -168,15 +228,15 @@ __device__ __forceinline__ void pass2(float2* lds, const float2* __restrict__ tw
 }
 
 // pass 3 forward: read layout A, write layout B.  thread = d*256 + ab.
-__device__ __forceinline__ void pass3_fwd(float2* lds, const float2* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass3_fwd(c32* lds, const c32* __restrict__ twM, int t) {
     const int d = t >> 8, ab = t & 255;
-    const float2* src = lds + 65 * ab + d;           // posA(ab*64 + 4c + d) = 65*ab + d + 4c
-    float2* dst = lds + 4352 * d + 17 * ab;          // posB(d, ab, c)
-    float2 x[16];
+    const c32* src = lds + 65 * ab + d;           // posA(ab*64 + 4c + d) = 65*ab + d + 4c
+    c32* dst = lds + 4352 * d + 17 * ab;          // posB(d, ab, c)
+    c32 x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = src[4 * c];
     fft16<false>(x);
-    float2 w = twM[256 * d];
+    c32 w = twM[256 * d];
     SSK_OPAQUE2(w);
     twiddle16<false>(x, w);
     __syncthreads();                       // every layout-A read done before layout-B writes
@@ -185,14 +245,14 @@ __device__ __forceinline__ void pass3_fwd(float2* lds, const float2* __restrict_
 }
 
 // pass 3 inverse: read layout B, write layout A.
-__device__ __forceinline__ void pass3_inv(float2* lds, const float2* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass3_inv(c32* lds, const c32* __restrict__ twM, int t) {
     const int d = t >> 8, ab = t & 255;
-    const float2* src = lds + 4352 * d + 17 * ab;
-    float2* dst = lds + 65 * ab + d;
-    float2 x[16];
+    const c32* src = lds + 4352 * d + 17 * ab;
+    c32* dst = lds + 65 * ab + d;
+    c32 x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = src[c];
-    float2 w = twM[256 * d];
+    c32 w = twM[256 * d];
     SSK_OPAQUE2(w);
     twiddle16<true>(x, w);
     fft16<true>(x);
@@ -203,82 +263,87 @@ __device__ __forceinline__ void pass3_inv(float2* lds, const float2* __restrict_
 
 // ---- Hermitian split / merge on one bin pair (k, 16384-k) ---------------------
 // Forward:  (Vk, Vp) -> (X2[k], X2[16384-k]) = 2 * rFFT_32768 bins,  wk = exp(-2 pi i k / 32768).
-__device__ __forceinline__ void herm_fwd(float2& vk, float2& vp, float2 wk) {
-    const float2 P = make_float2(vk.x + vp.x, vk.y - vp.y);     // Vk + conj(Vp)
-    const float2 Q = make_float2(vk.x - vp.x, vk.y + vp.y);     // Vk - conj(Vp)
-    const float2 wq = cmul(wk, Q);
-    const float2 R = make_float2(wq.y, -wq.x);                  // -i * wk * Q
-    vk = cadd(P, R);
-    vp = make_float2(P.x - R.x, -(P.y - R.y));                  // conj(P - R)
+//   P = Vk + conj(Vp), Q = Vk - conj(Vp), R = -i*wk*Q:  X2[k] = P + R,  X2[16384-k] = conj(P - R)
+__device__ __forceinline__ void herm_fwd(c32& vk, c32& vp, c32 wk) {
+    const c32 P = add_conj(vk, vp), Q = sub_conj(vk, vp);
+    const c32 wq = cmul(Q, wk);
+    vk = add_mi(P, wq);
+    vp = conj_add_pi(P, wq);
 }
 // Inverse:  (Yk, Yp) -> (V'2[k], V'2[16384-k]),  V' = packed spectrum of the real output.
-__device__ __forceinline__ void herm_inv(float2& yk, float2& yp, float2 wk) {
-    const float2 P = make_float2(yk.x + yp.x, yk.y - yp.y);
-    const float2 Q = make_float2(yk.x - yp.x, yk.y + yp.y);
-    const float2 wq = cmulc(Q, wk);                             // conj(wk) * Q
-    const float2 R = make_float2(-wq.y, wq.x);                  // i * conj(wk) * Q
-    yk = cadd(P, R);
-    yp = make_float2(P.x - R.x, -(P.y - R.y));
+//   R' = +i*conj(wk)*Q:  V'2[k] = P + R',  V'2[16384-k] = conj(P - R')
+__device__ __forceinline__ void herm_inv(c32& yk, c32& yp, c32 wk) {
+    const c32 P = add_conj(yk, yp), Q = sub_conj(yk, yp);
+    const c32 wq = cmulc(Q, wk);
+    yk = add_pi(P, wq);
+    yp = conj_add_mi(P, wq);
 }
 
-// exp(-2 pi i d / 8), d = 0..3
-__device__ __forceinline__ float2 w8(int d) {
+// wg * exp(-2 pi i d / 8), d = 0..3
+template <int D>
+__device__ __forceinline__ c32 mul_w8(c32 wg) {
     constexpr float H = 0.70710678118654752f;
-    return d == 0 ? make_float2(1.f, 0.f) : d == 1 ? make_float2(H, -H)
-         : d == 2 ? make_float2(0.f, -1.f) : make_float2(-H, -H);
+    if (D == 0) return wg;
+    if (D == 1) return cmul_k(wg, H, -H);
+    if (D == 2) return mk2(wg.y, -wg.x);
+    return cmul_k(wg, -H, -H);
 }
 
 // Pass 4 forward on one item: read the two radix-4 groups from layout B, finish the
 // 16384-point FFT, and turn the 8 bins into 2*rFFT_32768 bins:
 //   v[j]   (j<4)  = X2[gA + 4096 j]
 //   v[4+j] (j<4)  = X2[gB + 4096 j]         (item 0: v[0] = (X2[0], X2[16384]) both real)
-__device__ __forceinline__ void item_load_fwd(const float2* lds, const float2* __restrict__ twItem,
-                                              int q, float2 (&v)[8]) {
+__device__ __forceinline__ void item_load_fwd(const c32* lds, const c32* __restrict__ twItem,
+                                              int q, c32 (&v)[8]) {
     const int gA = item_gA(q);
     const int gB = (q == 0) ? 2048 : 4096 - gA;
-    const float2* pa = lds + 17 * group_ab(gA) + group_c(gA);
-    const float2* pb = lds + 17 * group_ab(gB) + group_c(gB);
+    const c32* pa = lds + 17 * group_ab(gA) + group_c(gA);
+    const c32* pb = lds + 17 * group_ab(gB) + group_c(gB);
 #pragma unroll
     for (int d = 0; d < 4; ++d) { v[d] = pa[4352 * d]; v[4 + d] = pb[4352 * d]; }
     bfly4<false>(v[0], v[1], v[2], v[3]);
     bfly4<false>(v[4], v[5], v[6], v[7]);
-    float2 wg = twItem[q];                 // exp(-2 pi i gA / 32768)
+    c32 wg = twItem[q];                 // exp(-2 pi i gA / 32768)
     SSK_OPAQUE2(wg);
     if (q != 0) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) herm_fwd(v[d], v[7 - d], cmul(wg, w8(d)));
+        herm_fwd(v[0], v[7], wg);
+        herm_fwd(v[1], v[6], mul_w8<1>(wg));
+        herm_fwd(v[2], v[5], mul_w8<2>(wg));
+        herm_fwd(v[3], v[4], mul_w8<3>(wg));
     } else {
-        constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f;
-        const float2 v0 = v[0];
-        v[0] = make_float2(2.f * (v0.x + v0.y), 2.f * (v0.x - v0.y));      // X2[0], X2[16384]
-        herm_fwd(v[1], v[3], w8(1));                                       // k = 4096
-        float2 dup = v[2]; herm_fwd(v[2], dup, w8(2));                     // k = 8192 (self)
-        herm_fwd(v[4], v[7], make_float2(C, -S));                          // k = 2048
-        herm_fwd(v[5], v[6], make_float2(S, -C));                          // k = 6144
+        constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, H = 0.70710678118654752f;
+        const c32 v0 = v[0];
+        v[0] = mk2(2.f * (v0.x + v0.y), 2.f * (v0.x - v0.y));      // X2[0], X2[16384]
+        herm_fwd(v[1], v[3], mk2(H, -H));                          // k = 4096
+        c32 dup = v[2]; herm_fwd(v[2], dup, mk2(0.f, -1.f));       // k = 8192 (self)
+        herm_fwd(v[4], v[7], mk2(C, -S));                          // k = 2048
+        herm_fwd(v[5], v[6], mk2(S, -C));                          // k = 6144
     }
 }
 
 // Inverse of the above: y[] holds Y2 bins in the same slot order; produce packed
 // spectrum V'2, run the inverse radix-4 and write both groups back to layout B.
-__device__ __forceinline__ void item_store_inv(float2* lds, const float2* __restrict__ twItem,
-                                               int q, float2 (&y)[8]) {
+__device__ __forceinline__ void item_store_inv(c32* lds, const c32* __restrict__ twItem,
+                                               int q, c32 (&y)[8]) {
     const int gA = item_gA(q);
     const int gB = (q == 0) ? 2048 : 4096 - gA;
-    float2* pa = lds + 17 * group_ab(gA) + group_c(gA);
-    float2* pb = lds + 17 * group_ab(gB) + group_c(gB);
-    float2 wg = twItem[q];
+    c32* pa = lds + 17 * group_ab(gA) + group_c(gA);
+    c32* pb = lds + 17 * group_ab(gB) + group_c(gB);
+    c32 wg = twItem[q];
     SSK_OPAQUE2(wg);
     if (q != 0) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) herm_inv(y[d], y[7 - d], cmul(wg, w8(d)));
+        herm_inv(y[0], y[7], wg);
+        herm_inv(y[1], y[6], mul_w8<1>(wg));
+        herm_inv(y[2], y[5], mul_w8<2>(wg));
+        herm_inv(y[3], y[4], mul_w8<3>(wg));
     } else {
-        constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f;
-        const float2 y0 = y[0];                                            // (Y2[0], Y2[16384])
-        y[0] = make_float2(y0.x + y0.y, y0.x - y0.y);
-        herm_inv(y[1], y[3], w8(1));
-        float2 dup = y[2]; herm_inv(y[2], dup, w8(2));
-        herm_inv(y[4], y[7], make_float2(C, -S));
-        herm_inv(y[5], y[6], make_float2(S, -C));
+        constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, H = 0.70710678118654752f;
+        const c32 y0 = y[0];                                            // (Y2[0], Y2[16384])
+        y[0] = mk2(y0.x + y0.y, y0.x - y0.y);
+        herm_inv(y[1], y[3], mk2(H, -H));
+        c32 dup = y[2]; herm_inv(y[2], dup, mk2(0.f, -1.f));
+        herm_inv(y[4], y[7], mk2(C, -S));
+        herm_inv(y[5], y[6], mk2(S, -C));
     }
     bfly4<true>(y[0], y[1], y[2], y[3]);
     bfly4<true>(y[4], y[5], y[6], y[7]);

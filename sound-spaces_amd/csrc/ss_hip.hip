@@ -34,9 +34,9 @@ int get_tables(ssk::Tables* out) {
         if (e != hipSuccess) return hip_err(e);
         e = hipMemcpy(dev_buf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(dev_buf); return hip_err(e); }
-        d.tb.twM = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTwMOff);
-        d.tb.twItem = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTwItemOff);
-        d.tb.tw512 = reinterpret_cast<const float2*>(dev_buf + ssk_host::kTw512Off);
+        d.tb.twM = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwMOff);
+        d.tb.twItem = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwItemOff);
+        d.tb.tw512 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTw512Off);
         d.tb.win = dev_buf + ssk_host::kWinOff;
         d.ready = true;
     }
@@ -48,9 +48,12 @@ inline int n_frames_of(int len) { return 1 + len / ssk::kHop; }
 inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kPool; }
 
 template <bool FUSE>
-int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, hipStream_t st) {
+int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
-    hipLaunchKernelGGL(ssk::k_conv<FUSE>, dim3(2 * n_units, nb_y), dim3(ssk::kT), 0, st, p);
+    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.rir_cap <= ssk::kB;
+    const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
+    if (simple) hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }
 
@@ -75,7 +78,7 @@ int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out
     if (rc) return rc;
     p.src = src;
     p.desc = win_desc;
-    p.spec = reinterpret_cast<float4*>(spec_out);
+    p.spec = reinterpret_cast<ssk::f32x4*>(spec_out);
     hipLaunchKernelGGL(ssk::k_source_windows, dim3(n_windows), dim3(ssk::kT), 0,
                        static_cast<hipStream_t>(stream), p);
     return hip_err(hipGetLastError());
@@ -88,7 +91,7 @@ static int fill_conv(ssk::ConvParams& p, const float* spec, const float* rir, co
     if (es < 1 || cs < 0 || us < 0 || cap < 0) return SS_EINVAL;
     int rc = get_tables(&p.tb);
     if (rc) return rc;
-    p.spec = reinterpret_cast<const float4*>(spec);
+    p.spec = reinterpret_cast<const ssk::f32x4*>(spec);
     p.rir = rir;
     p.rir_len = rir_len;
     p.desc = unit_desc;
@@ -108,7 +111,7 @@ static int fill_conv(ssk::ConvParams& p, const float* spec, const float* rir, co
 
 int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                             float* out, int n_units, long long rir_unit_stride, int rir_chan_stride,
-                            int rir_elem_stride, int rir_cap, int n_valid, int out_len, void* stream) {
+                            int rir_elem_stride, int rir_cap, int n_valid, int out_len, int flags, void* stream) {
     if (n_units == 0) return 0;
     if (!out || n_units < 0) return SS_EINVAL;
     ssk::ConvParams p;
@@ -117,7 +120,7 @@ int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_
     if (rc) return rc;
     p.out = out;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
-    return launch_conv<false>(p, n_units, nb_y, static_cast<hipStream_t>(stream));
+    return launch_conv<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream));
 }
 
 int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream) {
@@ -142,7 +145,7 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
                      int rir_chan_stride, int rir_elem_stride, int rir_cap, int n_valid, int out_len,
-                     int pad_mode, void* stream) {
+                     int pad_mode, int flags, void* stream) {
     if (n_units == 0) return 0;
     if (!spectrogram || n_units < 0) return SS_EINVAL;
     if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
@@ -155,11 +158,11 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
     if (out_len <= ssk::kB && p.t4 <= 26) {             // fused: waveform stays in LDS
         p.out = audiogoal;
         p.sgram = spectrogram;
-        return launch_conv<true>(p, n_units, 1, static_cast<hipStream_t>(stream));
+        return launch_conv<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
     }
     if (!audiogoal) return SS_EINVAL;                   // long rows hand over through HBM/L2
     rc = ss_fftconv_binaural_f32(spec, rir, rir_len, unit_desc, audiogoal, n_units, rir_unit_stride,
-                                 rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, stream);
+                                 rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, flags, stream);
     if (rc) return rc;
     return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
 }

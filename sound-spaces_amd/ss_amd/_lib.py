@@ -32,9 +32,9 @@ def load() -> ctypes.CDLL:
     lib.ss_version.restype = c_int
     lib.ss_init.restype = c_int
     lib.ss_source_windows_f32.argtypes = [vp, vp, vp, c_int, vp]
-    lib.ss_fftconv_binaural_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_fftconv_binaural_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, vp]
     lib.ss_spectrogram_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp]
-    lib.ss_audio_obs_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_audio_obs_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib

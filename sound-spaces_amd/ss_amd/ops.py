@@ -16,6 +16,7 @@ from . import _lib
 from .planning import KB, SPEC_FLOATS, ceil_div, spectrogram_shape
 
 PAD_REFLECT, PAD_CONSTANT = 0, 1
+FLAG_NO_DISTRACTOR = 1      # SS_FLAG_NO_DISTRACTOR: every unit descriptor has term 1 absent
 _PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
 
 
@@ -63,7 +64,8 @@ def source_windows(src: torch.Tensor, win_desc: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid: int, interleaved: bool = False) -> None:
+def fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid: int, interleaved: bool = False,
+                          flags: int = 0) -> None:
     _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
     _chk(unit_desc, torch.int32, "unit_desc"); _chk(out, torch.float32, "out")
     N, two, out_len = out.shape
@@ -72,12 +74,13 @@ def fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid: int,
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().ss_fftconv_binaural_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
                                                        unit_desc.data_ptr(), out.data_ptr(), N, us, cs, es, cap,
-                                                       n_valid, out_len, _stream()), "ss_fftconv_binaural_f32")
+                                                       n_valid, out_len, flags, _stream()), "ss_fftconv_binaural_f32")
 
 
-def fftconv_binaural(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, interleaved: bool = False):
+def fftconv_binaural(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, interleaved: bool = False,
+                     flags: int = 0):
     out = torch.empty((unit_desc.shape[0], 2, out_len), dtype=torch.float32, device=spec.device)
-    fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid, interleaved)
+    fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid, interleaved, flags)
     return out
 
 
@@ -97,7 +100,7 @@ def spectrogram(x: torch.Tensor, pad_mode="reflect") -> torch.Tensor:
 
 
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
-                   pad_mode="reflect", interleaved: bool = False) -> None:
+                   pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
     """Fused observation.  ``audiogoal`` may be None when out_len <= KB (waveform never leaves the CU)."""
     _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
     _chk(unit_desc, torch.int32, "unit_desc"); _chk(spectrogram_out, torch.float32, "spectrogram_out")
@@ -112,17 +115,17 @@ def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_ou
     with torch.cuda.device(spec.device):
         _lib.check(_lib.load().ss_audio_obs_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
                                                 unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N, us, cs,
-                                                es, cap, n_valid, out_len, _PAD[pad_mode], _stream()),
+                                                es, cap, n_valid, out_len, _PAD[pad_mode], flags, _stream()),
                    "ss_audio_obs_f32")
 
 
 def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pad_mode="reflect",
-              want_audiogoal: bool = False, interleaved: bool = False):
+              want_audiogoal: bool = False, interleaved: bool = False, flags: int = 0):
     N = unit_desc.shape[0]
     need_ag = want_audiogoal or out_len > KB
     ag = torch.empty((N, 2, out_len), dtype=torch.float32, device=spec.device) if need_ag else None
     sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
-    audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved)
+    audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved, flags)
     return ag, sg
 
 

@@ -106,6 +106,16 @@ class UnitRequest:
     dis_rir: int = -1
 
 
+@dataclass
+class Plan:
+    """Device-side unit descriptors of one batch + what the host knows about them."""
+    desc: torch.Tensor            # int32 [N, 8]
+    flags: int = 0                # ops.FLAG_* promises (e.g. no unit carries a distractor term)
+
+    def __len__(self):
+        return int(self.desc.shape[0])
+
+
 class BatchedAudioRenderer:
     def __init__(self, sampling_rate: int, device="cuda", pad_mode: str = "reflect",
                  step_time: Optional[float] = None, wrap: bool = False, spec_capacity: int = 64):
@@ -163,8 +173,8 @@ class BatchedAudioRenderer:
             wd_dev = torch.from_numpy(np.ascontiguousarray(wd)).to(self.device)
             ops.source_windows_into(self.sources.flat(), wd_dev, self._spec[first:first + len(wd)])
 
-    def plan(self, units: Sequence[UnitRequest]) -> torch.Tensor:
-        """-> int32 [N, 8] unit descriptors on the device; computes any missing source-window spectra."""
+    def plan(self, units: Sequence[UnitRequest]) -> Plan:
+        """-> unit descriptors (int32 [N, 8]) on the device; computes any missing source-window spectra."""
         assert self.rirs is not None, "set_rir_bank() first"
         keys = []
         for u in units:
@@ -174,6 +184,7 @@ class BatchedAudioRenderer:
                     keys.append((u.dis_sound, 0, False))          # distractor: whole clip, full conv (:659-664)
         self._ensure_windows(keys)
         desc = np.zeros((len(units), 8), np.int32)
+        flags = ops.FLAG_NO_DISTRACTOR
         for n, u in enumerate(units):
             if u.silent or u.rir < 0:
                 desc[n] = P.unit_desc_row()
@@ -182,20 +193,21 @@ class BatchedAudioRenderer:
             if u.dis_rir >= 0:
                 d0, dws = self._windows[(u.dis_sound, 0, False)]
                 desc[n] = P.unit_desc_row(u.rir, s0, ws, u.dis_rir, d0, dws)
+                flags = 0
             else:
                 desc[n] = P.unit_desc_row(u.rir, s0, ws)
-        return torch.from_numpy(desc).to(self.device, non_blocking=True)
+        return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), flags)
 
-    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> torch.Tensor:
+    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> Plan:
         """Vector form of plan() for the common no-distractor case (rir < 0 = silent)."""
         return self.plan([UnitRequest(int(s), int(t), int(r)) for s, t, r in zip(sound, t0, rir)])
 
     # ---- rendering ---------------------------------------------------------------------------------------
-    def render(self, unit_desc: torch.Tensor, want_audiogoal: bool = False,
+    def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
         """One launch (two for rows longer than one partition block) on the current stream.
         Returns (audiogoal [N,2,sr] or None, spectrogram [N,65,T4,2])."""
-        N = unit_desc.shape[0]
+        N = len(plan)
         need_ag = want_audiogoal or audiogoal_out is not None or self.out_len > P.KB
         ag = audiogoal_out
         if need_ag and ag is None:
@@ -203,18 +215,19 @@ class BatchedAudioRenderer:
         sg = spectrogram_out
         if sg is None:
             sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
-        ops.audio_obs_into(self._spec, self.rirs.data, self.rirs.lengths, unit_desc, ag, sg, self.n_valid,
-                           self.out_len, self.pad_mode)
+        ops.audio_obs_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
+                           self.out_len, self.pad_mode, flags=plan.flags)
         return (ag if (want_audiogoal or audiogoal_out is not None) else None), sg
 
-    def render_audiogoal(self, unit_desc: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def render_audiogoal(self, plan: Plan, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """AudioGoalSensor-only configurations (soundspaces/tasks/nav.py:37-60)."""
         if out is None:
-            out = torch.empty((unit_desc.shape[0], 2, self.out_len), dtype=torch.float32, device=self.device)
-        ops.fftconv_binaural_into(self._spec, self.rirs.data, self.rirs.lengths, unit_desc, out, self.n_valid)
+            out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
+        ops.fftconv_binaural_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, out, self.n_valid,
+                                  flags=plan.flags)
         return out
 
-    def render_crossfaded(self, desc_last: torch.Tensor, desc_cur: torch.Tensor):
+    def render_crossfaded(self, desc_last: Plan, desc_cur: Plan):
         """SS2.0 CROSSFADE (continuous_simulator.py:47-53, 422-424): the step is convolved with the previous and the
         current RIR and blended by a linear ramp over int(0.05*sr)+1 samples.  Two convolution launches, a torch
         blend on the first 801/2206 samples, then the stand-alone spectrogram kernel."""

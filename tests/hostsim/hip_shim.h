@@ -1,16 +1,14 @@
 // hip_shim.h — TEST INFRASTRUCTURE: just enough of the HIP device vocabulary to compile the kernel
-// headers of sound-spaces_amd/csrc for the HOST, so their index algebra can be checked against the
-// oracle without a GPU.  Threads of a workgroup run as cooperative fibers (hostsim.cpp); __syncthreads()
-// yields to the scheduler.  Never part of the product; the product only runs the gfx950 build.
+// headers of sound-spaces_amd/csrc for the HOST (clang++, for ext_vector_type), so their index algebra can be
+// checked against the oracle without a GPU.  Threads of a workgroup run as cooperative fibers (hostsim.cpp);
+// __syncthreads() / wave_sync() are real barriers over the workgroup's / the 64-lane wave's fibers.
+// Never part of the product; the product only runs the gfx950 build.
 #pragma once
+#define SSK_HOSTSIM 1
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 
-struct float2 { float x, y; };
-struct float4 { float x, y, z, w; };
-static inline float2 make_float2(float x, float y) { return float2{x, y}; }
-static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 { unsigned x = 1, y = 1, z = 1; };
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -22,5 +20,6 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __launch_bounds__(...)
 
 void hostsim_syncthreads();
+void hostsim_wave_sync();
 #define __syncthreads() hostsim_syncthreads()
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }

@@ -19,23 +19,42 @@ ucontext_t g_main;
 std::vector<ucontext_t> g_ctx;
 std::vector<char> g_stacks;
 std::vector<char> g_done;
-std::vector<int> g_barriers;
-int g_cur = 0;
+int g_cur = 0, g_nthreads = 0;
+long g_progress = 0;
 std::function<void()> g_body;
+
+struct Barrier { int count = 0; long generation = 0; };
+Barrier g_block_barrier;
+std::vector<Barrier> g_wave_barrier;
+
+void yield_fiber() {
+    const int me = g_cur;
+    swapcontext(&g_ctx[me], &g_main);
+    threadIdx.x = me;
+}
+
+void barrier_wait(Barrier& b, int expected) {
+    const long gen = b.generation;
+    if (++b.count == expected) { b.count = 0; ++b.generation; ++g_progress; return; }
+    while (b.generation == gen) yield_fiber();
+}
 
 void fiber_entry() {
     g_body();
     g_done[g_cur] = 1;
+    ++g_progress;
     swapcontext(&g_ctx[g_cur], &g_main);
 }
 
-// run one workgroup: every fiber is resumed round-robin until its next barrier (or its end)
+// run one workgroup: fibers are resumed round-robin; barriers are generation counters
 int run_block(int nthreads, const std::function<void()>& body) {
     g_body = body;
+    g_nthreads = nthreads;
     g_ctx.assign(nthreads, ucontext_t{});
     if (g_stacks.size() < kStack * nthreads) g_stacks.resize(kStack * nthreads);
     g_done.assign(nthreads, 0);
-    g_barriers.assign(nthreads, 0);
+    g_block_barrier = Barrier{};
+    g_wave_barrier.assign((nthreads + 63) / 64, Barrier{});
     for (int i = 0; i < nthreads; ++i) {
         getcontext(&g_ctx[i]);
         g_ctx[i].uc_stack.ss_sp = g_stacks.data() + kStack * i;
@@ -46,6 +65,7 @@ int run_block(int nthreads, const std::function<void()>& body) {
     blockDim.x = nthreads;
     for (;;) {
         int live = 0;
+        const long before = g_progress;
         for (int i = 0; i < nthreads; ++i) {
             if (g_done[i]) continue;
             g_cur = i;
@@ -54,38 +74,33 @@ int run_block(int nthreads, const std::function<void()>& body) {
             live += !g_done[i];
         }
         if (!live) break;
-    }
-    for (int i = 1; i < nthreads; ++i)
-        if (g_barriers[i] != g_barriers[0]) {
-            std::fprintf(stderr, "hostsim: divergent barrier count (thread %d: %d vs %d)\n", i, g_barriers[i], g_barriers[0]);
+        if (g_progress == before) {
+            std::fprintf(stderr, "hostsim: deadlock (divergent barriers) with %d live threads\n", live);
             return -2;
         }
+    }
     return 0;
 }
 
 ssk::Tables host_tables() {
     static std::vector<float> tab = ssk_host::build_tables();
     ssk::Tables tb;
-    tb.twM = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTwMOff);
-    tb.twItem = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTwItemOff);
-    tb.tw512 = reinterpret_cast<const float2*>(tab.data() + ssk_host::kTw512Off);
+    tb.twM = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwMOff);
+    tb.twItem = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwItemOff);
+    tb.tw512 = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTw512Off);
     tb.win = tab.data() + ssk_host::kWinOff;
     return tb;
 }
 }  // namespace
 
-void hostsim_syncthreads() {
-    ++g_barriers[g_cur];
-    const int me = g_cur;
-    swapcontext(&g_ctx[me], &g_main);
-    threadIdx.x = me;
-}
+void hostsim_syncthreads() { barrier_wait(g_block_barrier, g_nthreads); }
+void hostsim_wave_sync() { barrier_wait(g_wave_barrier[g_cur / 64], 64); }
 
 extern "C" {
 
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
-    p.src = src; p.desc = desc; p.spec = reinterpret_cast<float4*>(spec); p.tb = host_tables();
+    p.src = src; p.desc = desc; p.spec = reinterpret_cast<ssk::f32x4*>(spec); p.tb = host_tables();
     gridDim = dim3{(unsigned)n_windows, 1, 1};
     for (int w = 0; w < n_windows; ++w) {
         blockIdx = dim3{(unsigned)w, 0, 0};
@@ -95,10 +110,10 @@ int hs_source_windows(const float* src, const int* desc, float* spec, int n_wind
     return 0;
 }
 
-int hs_conv(int fuse, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
+int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
             float* sgram, int n_units, long long us, int cs, int es, int cap, int n_valid, int out_len, int pad_mode) {
     ssk::ConvParams p;
-    p.spec = reinterpret_cast<const float4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
+    p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
     p.out = out; p.sgram = sgram; p.tb = host_tables();
     p.rir_unit_stride = us; p.rir_chan_stride = cs; p.rir_elem_stride = es; p.rir_cap = cap;
     p.n_valid = n_valid; p.out_len = out_len;
@@ -111,7 +126,10 @@ int hs_conv(int fuse, const float* spec, const float* rir, const int* rir_len, c
     for (int j = 0; j < nb_y; ++j)
         for (int b = 0; b < 2 * n_units; ++b) {
             blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
-            int rc = run_block(ssk::kT, [&] { if (fuse) ssk::k_conv<true>(p); else ssk::k_conv<false>(p); });
+            int rc = run_block(ssk::kT, [&] {
+                if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
+                else { if (simple) ssk::k_conv<false, true>(p); else ssk::k_conv<false, false>(p); }
+            });
             if (rc) return rc;
         }
     return 0;

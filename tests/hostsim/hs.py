@@ -21,8 +21,9 @@ def lib():
         csrc = os.path.join(HERE, "..", "..", "sound-spaces_amd", "csrc")
         srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                                   "-include", "hip_shim.h", "hostsim.cpp", "-o", so], cwd=HERE)
+            cxx = os.environ.get("SS_HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")   # needs ext_vector_type
+            subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                                   "-Wno-pass-failed", "-include", "hip_shim.h", "hostsim.cpp", "-o", so], cwd=HERE)
         _LIB = ctypes.CDLL(so)
     return _LIB
 
@@ -32,7 +33,7 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False):
+        interleaved=False, simple=True):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent).
     Returns (audiogoal [N,2,out_len], spectrogram [N,65,T4,2] or None)."""
@@ -79,7 +80,8 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         us, cs, es = 2 * cap, 1, 2
     else:
         bank, us, cs, es = rir_bank, 2 * cap, cap, 1
-    rc = L.hs_conv(int(fuse), _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
+    simple = int(simple and not any(u.get("dis_rir", -1) >= 0 for u in units) and cap <= P.KB and nby == 1)
+    rc = L.hs_conv(int(fuse), simple, _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
                    _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
                    N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode)
     assert rc == 0, rc

@@ -52,9 +52,12 @@ def test_unfused_equals_fused_and_interleaved_layout():
     a1, s1 = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, fuse=True)
     a2, s2 = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, fuse=False, want_spectrogram=True)
     a3, _ = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, interleaved=True)
+    a4, s4 = hs.run([d["source"]], bank, [d["rir"].shape[0]], u, sr, sr, fuse=True, simple=False)   # loop kernel
     np.testing.assert_array_equal(a1, a2)
     np.testing.assert_array_equal(a1, a3)
+    np.testing.assert_array_equal(a1, a4)
     np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(s1, s4)
 
 
 def test_distractor_silent_and_zero_rir_in_one_batch():
