@@ -144,6 +144,19 @@ def conv_window_direct(source, rir, t0, out_len, wrap=False):
     return out
 
 
+def conv_window_fft(source, rir, t0, out_len):
+    """The unified formula evaluated with scipy (fast): full convolution of x[:t0+out_len] sliced at t0.
+    Equals every non-wrapping reference branch for the matching t0 (tests/test_oracle.py)."""
+    seg = np.asarray(source)[: max(0, t0 + out_len)]
+    if rir.shape[0] == 0 or seg.shape[0] == 0:
+        return np.zeros((rir.shape[1], out_len), np.float32)
+    full = _convolve_channels(seg, rir)
+    out = np.zeros((rir.shape[1], out_len), full.dtype)
+    avail = full[:, t0:t0 + out_len]
+    out[:, :avail.shape[1]] = avail
+    return out
+
+
 # --------------------------------------------------------------------------
 # A3: SpectrogramSensor.compute_spectrogram  (soundspaces/tasks/nav.py:86-100)
 # --------------------------------------------------------------------------

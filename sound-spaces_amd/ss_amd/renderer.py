@@ -237,3 +237,82 @@ class BatchedAudioRenderer:
         w2 = torch.arange(n + 1, device=self.device, dtype=torch.float32) / n
         a_cur[:, :, :n + 1] = a_last[:, :, :n + 1] * w2.flip(0) + a_cur[:, :, :n + 1] * w2
         return a_cur, ops.spectrogram(a_cur, self.pad_mode)
+
+
+class RirStore:
+    """HBM-resident RIR bank with a fixed number of slots, filled on demand and evicted LRU.
+
+    The reference re-reads ``<rir_dir>/<azimuth>/<recv>_<src>.wav`` from disk on every cache-missing step
+    (simulator.py:615-618); here the first visit of a pose pays that read + one H2D copy and later visits read HBM.
+    Live RIRs (SS2.0 / habitat_sim audio sensor: a new RIR every step) use a per-env key with ``refresh=True``.
+    Rows are zeroed beyond the RIR's length (precondition of the kernel); RIRs longer than ``cap`` are truncated,
+    which is exact for 1-s clips as long as cap >= sr (only h[0:sr] reaches y[0:sr])."""
+
+    def __init__(self, slots: int, cap: int, device):
+        cap += cap & 1
+        self.bank = RirBank(torch.zeros((slots, 2, cap), dtype=torch.float32, device=device),
+                            torch.zeros((slots,), dtype=torch.int32, device=device))
+        self.slots, self.cap = slots, cap
+        self._slot_of: Dict[object, int] = {}      # insertion order == LRU order (oldest first)
+        self._free: List[int] = list(range(slots - 1, -1, -1))
+        self.hits = self.misses = 0
+
+    def _upload(self, slot: int, rir: Optional[np.ndarray]) -> None:
+        row = np.zeros((2, self.cap), np.float32)
+        n = 0
+        if rir is not None and np.size(rir):
+            r = np.asarray(rir, dtype=np.float32)
+            r = r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
+            n = min(r.shape[1], self.cap)
+            row[:, :n] = r[:, :n]
+        self.bank.data[slot].copy_(torch.from_numpy(row))
+        self.bank.lengths[slot] = n
+
+    def slot(self, key, loader, refresh: bool = False) -> int:
+        """Bank slot of ``key``; ``loader()`` -> float array [L,2] / [2,L] or None is only called on a miss
+        (or always with ``refresh=True``: live RIRs that change every step keep their slot)."""
+        if key in self._slot_of:
+            slot = self._slot_of.pop(key)
+            self._slot_of[key] = slot                   # most recently used
+            if refresh:
+                self._upload(slot, loader())
+            else:
+                self.hits += 1
+            return slot
+        self.misses += 1
+        if self._free:
+            slot = self._free.pop()
+        else:
+            victim = next(iter(self._slot_of))
+            slot = self._slot_of.pop(victim)
+        self._slot_of[key] = slot
+        self._upload(slot, loader())
+        return slot
+
+
+class AudioEngine:
+    """Renderer + RIR store + source registry: what ``ss_amd.sim_audio`` talks to (one per process / GPU)."""
+
+    def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
+                 **renderer_kwargs):
+        self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
+        self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device)
+        self.renderer.set_rir_bank(self.store.bank)
+
+    def source_id(self, name: str, clip: np.ndarray) -> int:
+        return self.renderer.add_source(name, clip)
+
+    def rir_slot(self, key, loader, refresh: bool = False) -> int:
+        return self.store.slot(key, loader, refresh)
+
+    def observe(self, units: Sequence[UnitRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
+                spectrogram_out=None, audiogoal_out=None) -> Dict[str, torch.Tensor]:
+        plan = self.renderer.plan(units)
+        if not want_spectrogram:
+            return {"audiogoal": self.renderer.render_audiogoal(plan, out=audiogoal_out)}
+        ag, sg = self.renderer.render(plan, want_audiogoal=want_audiogoal, audiogoal_out=audiogoal_out,
+                                      spectrogram_out=spectrogram_out)
+        out = {"spectrogram": sg}
+        if ag is not None:
+            out["audiogoal"] = ag
+        return out

@@ -1,0 +1,156 @@
+"""Simulator-side audio of SoundSpaces on the HIP path.
+
+``HipSimAudio`` re-implements, for one simulator instance, the three audio methods the task sensors call
+
+    sim.get_current_audiogoal_observation()                    soundspaces/simulator.py:678-688
+    sim.get_current_spectrogram_observation(audiogoal2spec)    soundspaces/simulator.py:690-701
+    sim._compute_audiogoal()                                   soundspaces/simulator.py:608-666
+
+with the arithmetic done by the batched renderer (one unit per call in this *eager* mode).  ``attach()``
+installs them on a live ``SoundSpacesSim`` so the reference's own sensors keep working unchanged.  The two memo
+caches live on the simulator object under the reference's attribute names, so the simulator's own
+``reconfigure`` (simulator.py:395-397) keeps clearing them.
+
+``VectorAudioObserver`` is the *batched* mode: it collects one request per env of an in-process vector env
+(ss_baselines/common/sync_vector_env.py) and renders all of them in one launch straight into a device tensor —
+what replaces the per-env sensor call + ``batch_obs`` (ss_baselines/common/utils.py:126-153) for the audio keys.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from .renderer import UnitRequest
+
+
+def wav_rir_reader(path: str) -> Optional[np.ndarray]:
+    """simulator.py:615-624: float32 [L,2] from a wav, or None (-> zero RIR) when unreadable / empty."""
+    from scipy.io import wavfile
+    try:
+        _, rir = wavfile.read(path)
+    except (ValueError, FileNotFoundError, OSError):
+        logging.warning("%s file is not readable", path)
+        return None
+    if len(rir) == 0:
+        logging.debug("Empty RIR file at %s", path)
+        return None
+    return np.asarray(rir, dtype=np.float32)
+
+
+class HipSimAudio:
+    def __init__(self, sim, engine, rir_reader: Callable[[str], Optional[np.ndarray]] = wav_rir_reader):
+        """engine: ss_amd.renderer.AudioEngine (or any object with source_id / rir_slot / observe)."""
+        self.sim = sim
+        self.engine = engine
+        self.rir_reader = rir_reader
+        for name in ("_audiogoal_cache", "_spectrogram_cache"):
+            if not isinstance(getattr(sim, name, None), dict):
+                setattr(sim, name, {})
+
+    # ---- state -> request ------------------------------------------------------------------------------
+    @property
+    def sr(self) -> int:
+        return int(self.sim.config.AUDIO.RIR_SAMPLING_RATE)
+
+    def _rir_slot(self, source_index) -> int:
+        sim = self.sim
+        if sim.config.USE_RENDERED_OBSERVATIONS:
+            path = os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle),
+                                "{}_{}.wav".format(sim._receiver_position_index, source_index))      # :615-616
+            return self.engine.rir_slot(path, lambda: self.rir_reader(path))
+        # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded
+        rir = np.transpose(np.array(sim._sim.get_sensor_observations()["audio_sensor"]))
+        return self.engine.rir_slot(("live", id(sim), source_index), lambda: rir, refresh=True)
+
+    def unit_request(self) -> UnitRequest:
+        """The request _compute_audiogoal would serve right now.  Advances ``_audio_index`` exactly where the
+        reference does (:634-635: multi-second sounds only, not when silent)."""
+        sim, sr = self.sim, self.sr
+        if sim._episode_step_count > sim._duration:                                                  # :610
+            return UnitRequest(silent=True)
+        clip = sim.current_source_sound
+        sound = self.engine.source_id(sim._current_sound, clip)
+        rir = self._rir_slot(sim._source_position_index)
+        if clip.shape[0] == sr:                                                                      # :629
+            t0 = 0
+        else:
+            index = sim._audio_index                                                                 # :634
+            sim._audio_index = (sim._audio_index + 1) % sim._audio_length                            # :635
+            t0 = index * sr
+        req = UnitRequest(sound=sound, t0=t0, rir=rir)
+        if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :649
+            dclip = sim._source_sound_dict[sim._current_distractor_sound]
+            req.dis_sound = self.engine.source_id(sim._current_distractor_sound, dclip)
+            req.dis_rir = self._rir_slot(sim._distractor_position_index)
+        return req
+
+    def _joint_index(self):
+        sim = self.sim
+        return (sim._source_position_index, sim._receiver_position_index, sim.azimuth_angle)       # :683
+
+    # ---- the reference API ----------------------------------------------------------------------------------
+    def _compute(self, want_spectrogram: bool):
+        out = self.engine.observe([self.unit_request()], want_audiogoal=True, want_spectrogram=want_spectrogram)
+        ag = out["audiogoal"][0].cpu().numpy()
+        sg = out["spectrogram"][0].cpu().numpy() if want_spectrogram else None
+        return ag, sg
+
+    def get_current_audiogoal_observation(self):
+        sim = self.sim
+        if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :679-681
+            return self._compute(False)[0]
+        key = self._joint_index()
+        if key not in sim._audiogoal_cache:
+            sim._audiogoal_cache[key] = self._compute(False)[0]
+        return sim._audiogoal_cache[key]
+
+    def get_current_spectrogram_observation(self, audiogoal2spectrogram=None):
+        """``audiogoal2spectrogram`` is accepted for signature compatibility; when it is (or wraps) this package's
+        ``SpectrogramSensor.compute_spectrogram`` (or is None) the fused kernel result is used, any other callable is
+        applied to the audiogoal on the host, exactly like the reference would."""
+        sim = self.sim
+        foreign = audiogoal2spectrogram is not None and not getattr(audiogoal2spectrogram, "_ss_hip_fused", False)
+        if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :691-693
+            if foreign:
+                return audiogoal2spectrogram(self.get_current_audiogoal_observation())
+            return self._compute(True)[1]
+        key = self._joint_index()
+        if key not in sim._spectrogram_cache:
+            if foreign:
+                sim._spectrogram_cache[key] = audiogoal2spectrogram(self.get_current_audiogoal_observation())
+            elif key in sim._audiogoal_cache:        # waveform already cached (AudioGoalSensor ran first)
+                from .sensors import SpectrogramSensor
+                sim._spectrogram_cache[key] = SpectrogramSensor.compute_spectrogram(sim._audiogoal_cache[key])
+            else:                                    # one fused launch fills both caches
+                ag, sg = self._compute(True)
+                sim._audiogoal_cache[key] = ag
+                sim._spectrogram_cache[key] = sg
+        return sim._spectrogram_cache[key]
+
+
+def attach(sim, engine, rir_reader=wav_rir_reader) -> HipSimAudio:
+    """Install the HIP audio path on a live SoundSpacesSim: the task sensors (the reference's or ss_amd's) keep
+    calling ``sim.get_current_*_observation`` and now reach the GPU renderer."""
+    backend = HipSimAudio(sim, engine, rir_reader)
+    sim.get_current_audiogoal_observation = backend.get_current_audiogoal_observation
+    sim.get_current_spectrogram_observation = backend.get_current_spectrogram_observation
+    sim._compute_audiogoal = lambda: backend._compute(False)[0]
+    sim._ss_hip_audio = backend
+    return backend
+
+
+class VectorAudioObserver:
+    """Batched mode: one launch per vector step for all envs of this process."""
+
+    def __init__(self, engine, backends: List[HipSimAudio], want_audiogoal: bool = False):
+        self.engine, self.backends, self.want_audiogoal = engine, backends, want_audiogoal
+
+    def observe(self, spectrogram_out=None, audiogoal_out=None):
+        """-> {"spectrogram": device tensor [N,65,T4,2], ("audiogoal": [N,2,sr])}; cache-free (every env renders its
+        current pose), i.e. the reference's HAS_DISTRACTOR_SOUND / continuous behaviour."""
+        units = [b.unit_request() for b in self.backends]
+        return self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
+                                   want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)

@@ -1,0 +1,148 @@
+"""The Habitat plugin boundary: sensor classes, simulator audio adapter with the reference's cache
+semantics, batched observer, RIR store.  CPU only: the engine is an oracle-backed test double (tests/fakes.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ss_oracle as O
+from fakes import FakeSim, OracleEngine, NS
+from ss_amd import sensors, sim_audio
+from ss_amd.habitat_compat import SensorTypes, registry
+from ss_amd.renderer import RirStore, UnitRequest
+
+SR = 16000
+
+
+def make(has_distractor=False, seconds=1):
+    rng = np.random.default_rng(3)
+    sounds = {"telephone.wav": O.synth_sources(rng, SR, k=1, seconds=seconds)[0],
+              "dist.wav": O.synth_sources(rng, SR, k=1)[0]}
+    h = O.synth_rir(rng, SR, n=4)
+    rirs = {"rirs/replica/apartment_0/90/3_7.wav": np.ascontiguousarray(h[0].T),
+            "rirs/replica/apartment_0/180/3_7.wav": np.ascontiguousarray(h[1].T),
+            "rirs/replica/apartment_0/90/3_11.wav": np.ascontiguousarray(h[2].T),
+            "rirs/replica/apartment_0/90/5_7.wav": None}                         # unreadable
+    sim = FakeSim(SR, sounds, rirs, has_distractor)
+    eng = OracleEngine(SR)
+    backend = sim_audio.attach(sim, eng, rir_reader=sim.reader)
+    return sim, eng, backend, sounds, rirs
+
+
+def test_sensor_contract():
+    sim, *_ = make()
+    ag = sensors.AudioGoalSensor(sim=sim, config=NS())
+    sg = sensors.SpectrogramSensor(sim=sim, config=NS())
+    assert (ag.uuid, sg.uuid) == ("audiogoal", "spectrogram")                     # nav.py:44,71
+    assert ag.sensor_type == SensorTypes.PATH and sg.sensor_type == SensorTypes.PATH
+    assert ag.observation_space.shape == (2, SR) and ag.observation_space.dtype == np.float32
+    assert sg.observation_space.shape == (65, 26, 2) and sg.observation_space.dtype == np.float32
+    assert ag.observation_space.low == np.finfo(np.float32).min
+    sim.config.AUDIO.RIR_SAMPLING_RATE = 44100
+    assert sensors.SpectrogramSensor(sim=sim, config=NS()).observation_space.shape == (65, 69, 2)
+    assert registry.get_sensor("AudioGoalSensor") is sensors.AudioGoalSensor
+    assert registry.get_sensor("SpectrogramSensor") is sensors.SpectrogramSensor
+    assert sensors.SpectrogramSensor.cls_uuid == "spectrogram"
+
+
+def test_eager_mode_matches_reference_and_caches():
+    sim, eng, backend, sounds, rirs = make()
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    s1 = sg_sensor.get_observation(observations=None, episode=None)
+    a1 = ag_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 1                                                         # one fused launch fills both caches
+    ref = O.compute_audiogoal(sounds["telephone.wav"], rirs["rirs/replica/apartment_0/90/3_7.wav"], SR)
+    assert O.relerr(a1, ref) < 1e-5 and O.relerr(s1, O.compute_spectrogram(ref)) < 1e-5
+    assert s1.shape == (65, 26, 2) and a1.shape == (2, SR)
+    assert sg_sensor.get_observation(observations=None, episode=None) is s1      # cached object, like the reference
+    sim._rotation_angle = 180                                                     # azimuth 180 -> new key
+    s2 = sg_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 2 and not np.array_equal(s1, s2)
+    sim._audiogoal_cache, sim._spectrogram_cache = dict(), dict()                 # what reconfigure does (:395-397)
+    sg_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 3
+
+
+def test_silent_and_unreadable_rir_give_exact_zeros():
+    sim, eng, backend, *_ = make()
+    sim._episode_step_count, sim._duration = 501, 500
+    assert not backend.get_current_spectrogram_observation().any()
+    sim._episode_step_count = 0
+    sim._receiver_position_index = 5                                              # -> 5_7.wav unreadable
+    assert not backend.get_current_audiogoal_observation().any()
+
+
+def test_multisecond_index_advances_once_per_compute():
+    sim, eng, backend, sounds, rirs = make(seconds=3)
+    rir = rirs["rirs/replica/apartment_0/90/3_7.wav"]
+    ref_sim = O.CachedSimAudio()
+    idx = 0
+    for step, rot in enumerate((270, 90, 0)):                                      # azimuth 90, 270(miss file->zeros), 0
+        sim._rotation_angle = rot
+        got = backend.get_current_spectrogram_observation(sensors.SpectrogramSensor.compute_spectrogram)
+        assert sim._audio_index == (step + 1) % 3
+        if rot == 270:
+            a = O.compute_audiogoal(sounds["telephone.wav"], rir, SR, audio_index=idx)
+            assert O.relerr(got, O.compute_spectrogram(a)) < 1e-5
+        idx = O.next_audio_index(idx, 3 * SR, SR)
+    # cache hit does not advance (the reference quirk: the cached entry freezes the window first seen at a pose)
+    sim._rotation_angle = 270
+    before = sim._audio_index
+    backend.get_current_spectrogram_observation()
+    assert sim._audio_index == before
+
+
+def test_distractor_bypasses_caches():
+    sim, eng, backend, sounds, rirs = make(has_distractor=True)
+    sim._current_distractor_sound = "dist.wav"
+    a1 = backend.get_current_audiogoal_observation()
+    a2 = backend.get_current_audiogoal_observation()
+    assert eng.calls == 2 and not sim._audiogoal_cache                            # simulator.py:679-681
+    ref = O.compute_audiogoal(sounds["telephone.wav"], rirs["rirs/replica/apartment_0/90/3_7.wav"], SR,
+                              distractor=sounds["dist.wav"],
+                              distractor_rir=rirs["rirs/replica/apartment_0/90/3_11.wav"])
+    assert O.relerr(a1, ref) < 1e-5 and np.array_equal(a1, a2)
+
+
+def test_foreign_spectrogram_callable_is_applied_on_host():
+    sim, eng, backend, *_ = make()
+    got = backend.get_current_spectrogram_observation(lambda a: a.sum(axis=1))
+    assert got.shape == (2,)
+
+
+def test_vector_observer_batches_all_envs_in_one_launch():
+    sims = [make()[0] for _ in range(5)]
+    eng = OracleEngine(SR)
+    backends = [sim_audio.HipSimAudio(s, eng, rir_reader=s.reader) for s in sims]
+    sims[2]._episode_step_count = 999                                             # one silent env
+    obs = sim_audio.VectorAudioObserver(eng, backends, want_audiogoal=True).observe()
+    assert eng.calls == 1
+    assert tuple(obs["spectrogram"].shape) == (5, 65, 26, 2) and tuple(obs["audiogoal"].shape) == (5, 2, SR)
+    assert not obs["spectrogram"][2].any() and obs["spectrogram"][0].any()
+    assert torch.equal(obs["spectrogram"][0], obs["spectrogram"][1])
+
+
+def test_rir_store_lru_and_refresh():
+    st = RirStore(slots=3, cap=100, device="cpu")
+    loads = []
+
+    def loader(tag, n):
+        def f():
+            loads.append(tag)
+            return np.full((n, 2), float(len(loads)), np.float32)
+        return f
+    a = st.slot("a", loader("a", 10)); b = st.slot("b", loader("b", 20)); c = st.slot("c", loader("c", 30))
+    assert len({a, b, c}) == 3 and st.misses == 3
+    assert st.slot("a", loader("a", 10)) == a and st.hits == 1 and loads == ["a", "b", "c"]
+    d = st.slot("d", loader("d", 200))                                            # evicts LRU = "b"; truncated to cap
+    assert d == b and int(st.bank.lengths[d]) == 100
+    assert st.slot("b", loader("b", 20)) == c                                     # now "c" is the oldest
+    assert int(st.bank.lengths[c]) == 20 and not st.bank.data[c, :, 20:].any()    # rows zero beyond their length
+    live = st.slot(("live", 1), loader("l", 5))
+    assert st.slot(("live", 1), loader("l2", 7), refresh=True) == live and int(st.bank.lengths[live]) == 7
+    assert st.slot("none", lambda: None) is not None                              # unreadable -> zero RIR, length 0
+
+
+def test_unit_request_defaults():
+    u = UnitRequest()
+    assert u.rir == -1 and not u.silent and u.dis_rir == -1
