@@ -62,6 +62,15 @@ constexpr int kSpecComplex = 16384;  // complex values of one stored block spect
 constexpr int kTwM = 1024;           // entries of twM:  exp(-2*pi*i*t/16384), t < 1024
 constexpr int kTwItem = 2048;        // entries of twItem: exp(-2*pi*i*gA(q)/32768), q < 2048
 
+// v_sqrt_f32 (1 ulp) instead of the correctly-rounded software sequence; plenty for the 1e-4 budget
+__device__ __forceinline__ float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
 // ---- complex primitives ---------------------------------------------------------------------------
 // The kernels are VALU-issue bound, so every primitive is ONE packed instruction (two for a complex
 // multiply): the op_sel / neg operand modifiers of v_pk_*_f32 do the half swaps and sign flips that
@@ -174,6 +183,51 @@ __device__ __forceinline__ void fft16(c32 (&x)[16]) {
     t = x[11]; x[11] = x[14]; x[14] = t;
 }
 
+// Forward 16-point DFT when x[8..15] are known to be zero (zero-padded RIR block): the first radix-4 stage
+// collapses to 4 instructions per column.  64 packed instructions.
+__device__ __forceinline__ void fft16_fwd_lo8(c32 (&x)[16]) {
+    constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int j0 = 0; j0 < 4; ++j0) {
+        const c32 a = x[j0], b = x[j0 + 4];
+        x[j0] = cadd(a, b);  x[j0 + 8] = csub(a, b);  x[j0 + 4] = add_mi(a, b);  x[j0 + 12] = add_pi(a, b);
+    }
+    x[5] = cmul_k(x[5], C, -S);   x[9] = cmul_k(x[9], H, -H);     x[13] = cmul_k(x[13], S, -C);
+    x[6] = cmul_k(x[6], H, -H);                                    x[14] = cmul_k(x[14], -H, -H);
+    x[7] = cmul_k(x[7], S, -C);   x[11] = cmul_k(x[11], -H, -H);  x[15] = cmul_k(x[15], -C, S);
+    bfly4<false>(x[0], x[1], x[2], x[3]);
+    bfly4<false>(x[4], x[5], x[6], x[7]);
+    bfly4<false, true>(x[8], x[9], x[10], x[11]);
+    bfly4<false>(x[12], x[13], x[14], x[15]);
+    c32 t;
+    t = x[1];  x[1] = x[4];   x[4] = t;
+    t = x[2];  x[2] = x[8];   x[8] = t;
+    t = x[3];  x[3] = x[12];  x[12] = t;
+    t = x[6];  x[6] = x[9];   x[9] = t;
+    t = x[7];  x[7] = x[13];  x[13] = t;
+    t = x[11]; x[11] = x[14]; x[14] = t;
+}
+
+// cos / sin of 2*pi*m/64, m < 48: the pass-3 twiddles exp(-+2 pi i d c'/64), d <= 3, c' <= 15, as literals
+__device__ constexpr float kCos64[48] = {
+    1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+__device__ constexpr float kSin64[48] = {
+    0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f, 1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f};
+
+// x[r] *= exp(-+2 pi i D r / 64): 30 instructions with literal twiddles (SGPR operands), no chain, no loads.
+template <bool INV, int D>
+__device__ __forceinline__ void twiddle16_const(c32 (&x)[16]) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) x[r] = cmul_k(x[r], kCos64[D * r], (INV ? 1.f : -1.f) * kSin64[D * r]);
+}
+// d = t>>8 is wave-uniform (256 threads per d): select the literal set with a scalar branch; d == 0 is the identity
+template <bool INV>
+__device__ __forceinline__ void twiddle16_d(c32 (&x)[16], int d_uniform) {
+    if (d_uniform == 1) twiddle16_const<INV, 1>(x);
+    else if (d_uniform == 2) twiddle16_const<INV, 2>(x);
+    else if (d_uniform == 3) twiddle16_const<INV, 3>(x);
+}
+
 // x[r] *= w^r (INV: conj(w)^r), r = 1..15; powers of w by a depth<=4 product chain.  58 packed instructions.
 template <bool INV>
 __device__ __forceinline__ void twiddle16(c32 (&x)[16], c32 w) {
@@ -228,7 +282,7 @@ __device__ __forceinline__ void pass2(c32* lds, const c32* __restrict__ twM, int
 }
 
 // pass 3 forward: read layout A, write layout B.  thread = d*256 + ab.
-__device__ __forceinline__ void pass3_fwd(c32* lds, const c32* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass3_fwd(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
     const c32* src = lds + 65 * ab + d;           // posA(ab*64 + 4c + d) = 65*ab + d + 4c
     c32* dst = lds + 4352 * d + 17 * ab;          // posB(d, ab, c)
@@ -236,25 +290,21 @@ __device__ __forceinline__ void pass3_fwd(c32* lds, const c32* __restrict__ twM,
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = src[4 * c];
     fft16<false>(x);
-    c32 w = twM[256 * d];
-    SSK_OPAQUE2(w);
-    twiddle16<false>(x, w);
+    twiddle16_d<false>(x, __builtin_amdgcn_readfirstlane(d));
     __syncthreads();                       // every layout-A read done before layout-B writes
 #pragma unroll
     for (int c = 0; c < 16; ++c) dst[c] = x[c];
 }
 
 // pass 3 inverse: read layout B, write layout A.
-__device__ __forceinline__ void pass3_inv(c32* lds, const c32* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass3_inv(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
     const c32* src = lds + 4352 * d + 17 * ab;
     c32* dst = lds + 65 * ab + d;
     c32 x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = src[c];
-    c32 w = twM[256 * d];
-    SSK_OPAQUE2(w);
-    twiddle16<true>(x, w);
+    twiddle16_d<true>(x, __builtin_amdgcn_readfirstlane(d));
     fft16<true>(x);
     __syncthreads();
 #pragma unroll

@@ -40,7 +40,7 @@ __device__ __forceinline__ void pass1_fwd(c32* lds, const c32* __restrict__ twM,
     c32 x[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) x[a] = (HALF && a >= 8) ? mk2(0.f, 0.f) : load(t + 1024 * a);
-    fft16<false>(x);
+    if (HALF) fft16_fwd_lo8(x); else fft16<false>(x);
     c32 w = twM[t];
     SSK_OPAQUE2(w);
     twiddle16<false>(x, w);
@@ -69,7 +69,7 @@ __device__ __forceinline__ void fwd_passes(c32* lds, const Tables& tb, int t) {
     __syncthreads();
     pass2<false>(lds, tb.twM, t);
     __syncthreads();
-    pass3_fwd(lds, tb.twM, t);
+    pass3_fwd(lds, t);
     __syncthreads();
 }
 
@@ -79,7 +79,7 @@ __device__ __forceinline__ void items_to_time(c32* lds, const Tables& tb, int t,
     item_store_inv(lds, tb.twItem, t, acc[0]);
     item_store_inv(lds, tb.twItem, t + 1024, acc[1]);
     __syncthreads();
-    pass3_inv(lds, tb.twM, t);
+    pass3_inv(lds, t);
     __syncthreads();
     pass2<true>(lds, tb.twM, t);
     __syncthreads();
@@ -189,35 +189,59 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, const Tables& tb, 
     for (int s = 0; s < 16; ++s) fr[q + 16 * s] = x[s];
     if (q == 0) fr[256] = x[0];              // Z[256] == Z[0]
     wave_sync();
-    // magnitudes of the 512-point real FFT, pooled over 4 bins; lane handles pooled rows b = q + 16 i
-    float pooled[4];
+    // |rFFT_512| pooled over 4 bins.  Bins come in Hermitian pairs (k, 256-k) that share P, Q and w*Q, so a lane
+    // takes the pooled rows b = q and q+16 (bins 4b..4b+3 < 128) together with their mirror bins 256-4b-e:
+    //   D[b]    = sum_e |X[4b+e]|                      -> row b
+    //   M0[b]   = |X[256-4b]|                           -> row 64-b
+    //   M123[b] = sum_{e=1..3} |X[256-4b-e]|            -> row 63-b          (+ |X[128]| = |Z[128]| for row 32)
+    float* ps = reinterpret_cast<float*>(sc);           // per frame: D[32] | M0[32] | M123[32] | X128 ; stride 100
+    float dsum[2], m0[2], m123[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const int b = q + 16 * i;
-        float acc = 0.f;
+        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fr + 4 * b);          // Z[4b .. 4b+3]
+        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fr + 252 - 4 * b);    // Z[252-4b .. 255-4b]
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(tb.tw512 + 4 * b);
+        const f32x4 k01 = zk4[0], k23 = zk4[1], p01 = zp4[0], p23 = zp4[1], w01 = w4[0], w23 = w4[1];
+        const c32 ptop = fr[256 - 4 * b];
+        const c32 zk[4] = {k01.xy, k01.zw, k23.xy, k23.zw};
+        const c32 zp[4] = {ptop, p23.zw, p23.xy, p01.zw};
+        const c32 ww[4] = {w01.xy, w01.zw, w23.xy, w23.zw};
+        float d = 0.f, m = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = 4 * b + e;
-            const c32 zk = fr[k], zp = fr[256 - k];
-            const c32 P = mk2(zk.x + zp.x, zk.y - zp.y);
-            const c32 Q = mk2(zk.x - zp.x, zk.y + zp.y);
-            const c32 wq = cmul(tb.tw512[k], Q);
-            const float re = P.x + wq.y, im = P.y - wq.x;       // P - i*w*Q = 2 X[k]
-            acc += sqrtf(re * re + im * im);
+            const c32 P = add_conj(zk[e], zp[e]), Q = sub_conj(zk[e], zp[e]);
+            const c32 wq = cmul(Q, ww[e]);
+            const c32 X = add_mi(P, wq), Y = add_pi(P, wq);                      // 2 X[k], conj(2 X[256-k])
+            d += fast_sqrt(X.x * X.x + X.y * X.y);
+            const float my = fast_sqrt(Y.x * Y.x + Y.y * Y.y);
+            if (e == 0) m0[i] = 0.5f * my; else m += my;
         }
-        pooled[i] = 0.5f * acc;
+        dsum[i] = 0.5f * d;
+        m123[i] = 0.5f * m;
     }
-    float nyq = 0.f;
-    if (q == 0) { const c32 z0 = fr[0]; nyq = fabsf(z0.x - z0.y); }   // |X[256]|
+    float x128 = 0.f;
+    if (q == 0) { const c32 z = fr[128]; x128 = fast_sqrt(z.x * z.x + z.y * z.y); }
     wave_sync();
-    float* ps = reinterpret_cast<float*>(sc);                  // [4 frames][66] floats
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ps[f * 66 + q + 16 * i] = pooled[i];
-    if (q == 0) ps[f * 66 + 64] = nyq;
+    for (int i = 0; i < 2; ++i) {
+        ps[f * 100 + q + 16 * i] = dsum[i];
+        ps[f * 100 + 32 + q + 16 * i] = m0[i];
+        ps[f * 100 + 64 + q + 16 * i] = m123[i];
+    }
+    if (q == 0) ps[f * 100 + 96] = x128;
     wave_sync();
-    for (int b = lane; b < kBins4; b += 64) {
-        const float v = (ps[b] + ps[66 + b]) + (ps[132 + b] + ps[198 + b]);
-        store(b, log1pf(v * (1.0f / 16.0f)));
+    for (int r = lane; r < kBins4; r += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* pf = ps + g * 100;
+            if (r < 32) v += pf[r];
+            else if (r == 32) v += pf[64 + 31] + pf[96];
+            else if (r < 64) v += pf[64 + 63 - r] + pf[32 + 64 - r];
+            else v += pf[32];
+        }
+        store(r, log1pf(v * (1.0f / 16.0f)));
     }
 }
 
@@ -272,9 +296,20 @@ struct ConvParams {
 };
 
 // forward FFT of RIR block i of one ear + multiply by the window spectrum `slot` -> acc (= or +=)
-template <bool ACCUMULATE>
+template <bool ACCUMULATE, bool PREFETCH>
 __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, int t, const float* h, int L, int i,
                                            int slot, c32 (&acc)[2][8]) {
+    // PREFETCH = issue the 8 window-spectrum loads before pass 1 instead of at the item stage.  Measured on
+    // MI355X (profiles/r1_notes.md): it is SLOWER (conv 21.3 vs 20.1 us at 128 units): the 128 KB of L2 reads queue
+    // ahead of the RIR's HBM loads on the in-order vmcnt path.  Kept as a switch, off everywhere.
+    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+    f32x4 sv[2][4];
+    if (PREFETCH) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
+    }
     // bank rows are zero-padded to rir_cap, so the only bound is the row capacity (L is used for block counts)
     const int lo = i * kB, es = p.rir_elem_stride, cap = p.rir_cap;
     (void)L;
@@ -289,27 +324,25 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, int t,
         });
     }
     fwd_passes(lds, p.tb, t);
-    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        f32x4 sv[4];
+        if (!PREFETCH) {
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) sv[hh] = sp[(s * 4 + hh) * 1024];
+            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
+        }
         c32 v[8];
         item_load_fwd(lds, p.tb.twItem, t + 1024 * s, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const c32 w = (e & 1) ? sv[e >> 1].zw : sv[e >> 1].xy;
+            const c32 w = (e & 1) ? sv[s][e >> 1].zw : sv[s][e >> 1].xy;
             c32 pr = cmul(v[e], w);
             if (s == 0 && e == 0 && t == 0) pr = mk2(v[0].x * w.x, v[0].y * w.y);   // (X[0], X[16384]) are real
-            if (ACCUMULATE) { acc[s][e].x += pr.x; acc[s][e].y += pr.y; }
+            if (ACCUMULATE) acc[s][e] += pr;
             else acc[s][e] = pr;
         }
     }
 }
 
-// SIMPLE: the caller guarantees one output block (gridDim.y == 1), RIR capacity <= kB and no distractor term,
-// so a unit is at most ONE forward FFT: straight-line code, no accumulator carried across passes, no scratch.
 template <bool FUSE, bool SIMPLE>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     __shared__ c32 lds[kLdsComplex];
@@ -328,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
             if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
                 const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
-                conv_block<false>(lds, p, t, h, L, 0, spec0 - m_min, acc);
+                                conv_block<false, false>(lds, p, t, h, L, 0, spec0 - m_min, acc);
                 any = true;
             }
         }
@@ -351,11 +384,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             int tl = t;
             SSK_OPAQUE1(tl);
             if (!any) {
-                conv_block<false>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
+                conv_block<false, false>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
                 any = true;
             } else {
                 __syncthreads();                   // previous block's item reads of layout B are done
-                conv_block<true>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
+                conv_block<true, false>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
             }
         }
     }
