@@ -194,6 +194,13 @@ def main():
         conv_ms = e0.elapsed_time(e1) / reps
 
     if rank == 0:
+        traffic = None                      # HBM bytes per launch from the committed PMC pass of this same command
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))["k_conv<FUSE=true>"]
+            if tj["units_per_launch"] == N and tj["sampling_rate"] == sr:
+                traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
+        except Exception:
+            pass
         b = bytes_per_unit(sr, L, t4)
         fused = sr <= P.KB
         dom_bytes = (b["fused"] if fused else b["conv"]) * N
@@ -213,7 +220,7 @@ def main():
                        "exchange": (args.exchange if world > 1 else "none"), "kernel": "k_conv<fused>" if fused else
                        "k_conv + k_spectrogram"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_conv<FUSE=true>" if fused else "k_conv<FUSE=false>+k_spectrogram",
                          "bytes_per_unit": b["fused"] if fused else b["conv"], "units_per_launch": N,
                          "avg_launch_ms": round(kernel_ms, 5)},

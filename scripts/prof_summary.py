@@ -6,11 +6,15 @@ d = sys.argv[1]
 out = []
 for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
     out.append(f"## {os.path.relpath(f, d)}")
-    for row in list(csv.DictReader(open(f)))[:12]:
+    for row in csv.DictReader(open(f)):
+        if "ssk::" not in row.get("Name", ""):
+            continue                       # torch kernels that only build the synthetic banks
         out.append("  " + " | ".join(f"{k}={v}" for k, v in row.items()))
 agg = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):
+        if "ssk::" not in row.get("Kernel_Name", ""):
+            continue
         k = row.get("Kernel_Name", "?").split("(")[0][:60]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in agg.items():
