@@ -262,17 +262,32 @@ __device__ __forceinline__ int item_gA(int q) {
 }
 
 // ---- forward passes 2,3 and inverse passes 3',2' (LDS <-> LDS) ---------------
-// All take the workgroup's LDS buffer and the twM table (global memory).
+// The per-thread base twiddle of every pass is a single table entry; all four are loaded once at kernel start
+// (ThreadTw) so that no pass begins with an exposed L2 round trip.  Each use goes through an opaque copy so the
+// cheap power chain is recomputed per pass instead of being kept alive (see SSK_OPAQUE2).
+struct ThreadTw {
+    c32 p1;      // twM[t]            passes 1 / 1'
+    c32 p2;      // twM[16*(t&63)]    passes 2 / 2'
+    c32 i0, i1;  // twItem[t], twItem[t+1024]   Hermitian stage of the two items
+};
+__device__ __forceinline__ ThreadTw load_thread_tw(const c32* __restrict__ twM, const c32* __restrict__ twItem, int t) {
+    ThreadTw w;
+    w.p1 = twM[t];
+    w.p2 = twM[16 * (t & 63)];
+    w.i0 = twItem[t];
+    w.i1 = twItem[t + 1024];
+    return w;
+}
 
 // pass 2 (forward, in place, layout A): a' = t>>6, low2 = t&63
 template <bool INV>
-__device__ __forceinline__ void pass2(c32* lds, const c32* __restrict__ twM, int t) {
+__device__ __forceinline__ void pass2(c32* lds, c32 wbase, int t) {
     // posA(a'*1024 + b*64 + low2) = a'*1040 + low2 + 65*b : one base register + immediate offsets
     c32* base = lds + (t >> 6) * 1040 + (t & 63);
     c32 x[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) x[b] = base[65 * b];
-    c32 w = twM[16 * (t & 63)];
+    c32 w = wbase;
     SSK_OPAQUE2(w);
     if (INV) twiddle16<true>(x, w);
     fft16<INV>(x);
@@ -343,8 +358,7 @@ __device__ __forceinline__ c32 mul_w8(c32 wg) {
 // 16384-point FFT, and turn the 8 bins into 2*rFFT_32768 bins:
 //   v[j]   (j<4)  = X2[gA + 4096 j]
 //   v[4+j] (j<4)  = X2[gB + 4096 j]         (item 0: v[0] = (X2[0], X2[16384]) both real)
-__device__ __forceinline__ void item_load_fwd(const c32* lds, const c32* __restrict__ twItem,
-                                              int q, c32 (&v)[8]) {
+__device__ __forceinline__ void item_load_fwd(const c32* lds, c32 wbase, int q, c32 (&v)[8]) {
     const int gA = item_gA(q);
     const int gB = (q == 0) ? 2048 : 4096 - gA;
     const c32* pa = lds + 17 * group_ab(gA) + group_c(gA);
@@ -353,7 +367,7 @@ __device__ __forceinline__ void item_load_fwd(const c32* lds, const c32* __restr
     for (int d = 0; d < 4; ++d) { v[d] = pa[4352 * d]; v[4 + d] = pb[4352 * d]; }
     bfly4<false>(v[0], v[1], v[2], v[3]);
     bfly4<false>(v[4], v[5], v[6], v[7]);
-    c32 wg = twItem[q];                 // exp(-2 pi i gA / 32768)
+    c32 wg = wbase;                     // exp(-2 pi i gA / 32768)
     SSK_OPAQUE2(wg);
     if (q != 0) {
         herm_fwd(v[0], v[7], wg);
@@ -373,13 +387,12 @@ __device__ __forceinline__ void item_load_fwd(const c32* lds, const c32* __restr
 
 // Inverse of the above: y[] holds Y2 bins in the same slot order; produce packed
 // spectrum V'2, run the inverse radix-4 and write both groups back to layout B.
-__device__ __forceinline__ void item_store_inv(c32* lds, const c32* __restrict__ twItem,
-                                               int q, c32 (&y)[8]) {
+__device__ __forceinline__ void item_store_inv(c32* lds, c32 wbase, int q, c32 (&y)[8]) {
     const int gA = item_gA(q);
     const int gB = (q == 0) ? 2048 : 4096 - gA;
     c32* pa = lds + 17 * group_ab(gA) + group_c(gA);
     c32* pb = lds + 17 * group_ab(gB) + group_c(gB);
-    c32 wg = twItem[q];
+    c32 wg = wbase;
     SSK_OPAQUE2(wg);
     if (q != 0) {
         herm_inv(y[0], y[7], wg);

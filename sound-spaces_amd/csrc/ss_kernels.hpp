@@ -36,12 +36,12 @@ struct Tables {
 // pass 1 forward (global -> LDS layout A).  LOADER(m) returns the packed sample pair (x[2m], x[2m+1]).
 // HALF: packed samples m >= 8192 are known to be zero (an RIR block has <= kB real samples).
 template <bool HALF, class LOADER>
-__device__ __forceinline__ void pass1_fwd(c32* lds, const c32* __restrict__ twM, int t, LOADER load) {
+__device__ __forceinline__ void pass1_fwd(c32* lds, c32 wbase, int t, LOADER load) {
     c32 x[16];
 #pragma unroll
     for (int a = 0; a < 16; ++a) x[a] = (HALF && a >= 8) ? mk2(0.f, 0.f) : load(t + 1024 * a);
     if (HALF) fft16_fwd_lo8(x); else fft16<false>(x);
-    c32 w = twM[t];
+    c32 w = wbase;
     SSK_OPAQUE2(w);
     twiddle16<false>(x, w);
     c32* base = lds + t + (t >> 6);             // posA(t + 1024*a) = t + (t>>6) + 1040*a
@@ -51,12 +51,12 @@ __device__ __forceinline__ void pass1_fwd(c32* lds, const c32* __restrict__ twM,
 
 // pass 1 inverse: LDS layout A -> registers; only the upper half (packed samples 8192..16383, i.e. the
 // alias-free last kB real samples of the circular convolution) is produced: y[a-8] <-> packed m = t+1024*(a-8).
-__device__ __forceinline__ void pass1_inv(const c32* lds, const c32* __restrict__ twM, int t, c32 (&y)[8]) {
+__device__ __forceinline__ void pass1_inv(const c32* lds, c32 wbase, int t, c32 (&y)[8]) {
     c32 x[16];
     const c32* base = lds + t + (t >> 6);
 #pragma unroll
     for (int a = 0; a < 16; ++a) x[a] = base[1040 * a];
-    c32 w = twM[t];
+    c32 w = wbase;
     SSK_OPAQUE2(w);
     twiddle16<true>(x, w);
     fft16<true>(x);
@@ -65,9 +65,9 @@ __device__ __forceinline__ void pass1_inv(const c32* lds, const c32* __restrict_
 }
 
 // forward chain after pass 1 up to "layout B holds the radix-4 groups" (items are then read one at a time)
-__device__ __forceinline__ void fwd_passes(c32* lds, const Tables& tb, int t) {
+__device__ __forceinline__ void fwd_passes(c32* lds, const ThreadTw& tw, int t) {
     __syncthreads();
-    pass2<false>(lds, tb.twM, t);
+    pass2<false>(lds, tw.p2, t);
     __syncthreads();
     pass3_fwd(lds, t);
     __syncthreads();
@@ -75,15 +75,15 @@ __device__ __forceinline__ void fwd_passes(c32* lds, const Tables& tb, int t) {
 
 // inverse chain from "items hold Y2 bins" to the last kB real samples in registers.
 // LDS must not be in use by other threads' pending reads (caller syncs before).
-__device__ __forceinline__ void items_to_time(c32* lds, const Tables& tb, int t, c32 (&acc)[2][8], c32 (&y)[8]) {
-    item_store_inv(lds, tb.twItem, t, acc[0]);
-    item_store_inv(lds, tb.twItem, t + 1024, acc[1]);
+__device__ __forceinline__ void items_to_time(c32* lds, const ThreadTw& tw, int t, c32 (&acc)[2][8], c32 (&y)[8]) {
+    item_store_inv(lds, tw.i0, t, acc[0]);
+    item_store_inv(lds, tw.i1, t + 1024, acc[1]);
     __syncthreads();
     pass3_inv(lds, t);
     __syncthreads();
-    pass2<true>(lds, tb.twM, t);
+    pass2<true>(lds, tw.p2, t);
     __syncthreads();
-    pass1_inv(lds, tb.twM, t, y);
+    pass1_inv(lds, tw.p1, t, y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -116,16 +116,17 @@ __global__ __launch_bounds__(1024) void k_source_windows(SrcParams p) {
     const float* x = p.src + __builtin_amdgcn_readfirstlane(d[0]);
     const int len = __builtin_amdgcn_readfirstlane(d[1]), start = __builtin_amdgcn_readfirstlane(d[2]);
     const int wrap = __builtin_amdgcn_readfirstlane(d[3]);
-    pass1_fwd<false>(lds, p.tb.twM, t, [&](int m) {
+    const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    pass1_fwd<false>(lds, tw.p1, t, [&](int m) {
         return mk2(src_sample(x, len, start + 2 * m, wrap), src_sample(x, len, start + 2 * m + 1, wrap));
     });
-    fwd_passes(lds, p.tb, t);
+    fwd_passes(lds, tw, t);
     constexpr float scale = 1.0f / (8.0f * 16384.0f);   // (2X -> X) * 1/(4M): inverse packing 2x2, 1/M of the IFFT
     f32x4* o = p.spec + (size_t)w * (kSpecComplex / 2) + t;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         c32 v[8];
-        item_load_fwd(lds, p.tb.twItem, t + 1024 * s, v);
+        item_load_fwd(lds, s ? tw.i1 : tw.i0, t + 1024 * s, v);
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             o[(s * 4 + h) * 1024] = mk4(v[2 * h] * scale, v[2 * h + 1] * scale);
@@ -136,12 +137,6 @@ __global__ __launch_bounds__(1024) void k_source_windows(SrcParams p) {
 // STFT -> |.| -> 4x4 mean-pool -> log1p for one 4-frame time block per wave.
 // y: audiogoal row (LDS or global), length len.  Frame tf covers y[160*tf-256 .. 160*tf+255]
 // (librosa centre padding: reflect (pad_mode 0) or zeros (pad_mode 1)).
-__device__ __forceinline__ float pad_sample(const float* y, int len, int i, int pad_mode) {
-    if (i < 0) { if (pad_mode) return 0.f; i = -i; }
-    else if (i >= len) { if (pad_mode) return 0.f; i = 2 * (len - 1) - i; }
-    return (i >= 0 && i < len) ? y[i] : 0.f;
-}
-
 // phase A: windowed frame samples -> registers (packed even/odd).  lane = f*16 + q.
 // Interior frames (all but the first two and last two of a row) take the branch-free path: 16 aligned
 // 8-byte loads of the row and 16 of the window table; edge frames go through the padding logic per sample.
@@ -160,24 +155,40 @@ __device__ __forceinline__ void stft_load(const float* y, int len, int tf, int n
             x[j] = mk2(w.x * s.x, w.y * s.y);
         }
     } else {
+        // edge frame: librosa's centre padding resolved by index arithmetic and unconditional (clamped) loads, so the
+        // two or three waves per row that own edge frames do not fall into divergent per-sample branches
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int n = 2 * (q + 16 * j);
+            const int n = base + 2 * (q + 16 * j);
             const c32 w = w2[16 * j];
-            x[j] = mk2(w.x * pad_sample(y, len, base + n, pad_mode), w.y * pad_sample(y, len, base + n + 1, pad_mode));
+            float sv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int i = n + u;
+                if (pad_mode == 0) {                       // reflect (wave-uniform switch)
+                    i = i < 0 ? -i : i;
+                    i = i >= len ? 2 * (len - 1) - i : i;
+                }
+                const bool ok = (i >= 0) && (i < len);
+                const float v = y[ok ? i : 0];
+                sv[u] = ok ? v : 0.f;
+            }
+            x[j] = mk2(w.x * sv[0], w.y * sv[1]);
         }
     }
 }
 
 // phase B: everything after the load, for ONE wave: sc = this wave's private scratch (kWaveScratch complex),
 // so all synchronisation is wave-scope (no workgroup barrier).  Pooled log1p values go out through STORE(b, value).
+// wq = exp(-2 pi i q / 256) (= twM[64 q], loaded once by the caller); tw512 = table exp(-2 pi i k / 512) (global or LDS).
 template <class STORE>
-__device__ __forceinline__ void stft_block(c32* sc, int lane, const Tables& tb, c32 (&x)[16], STORE store) {
+__device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32* tw512, c32 (&x)[16], STORE store) {
     const int f = lane >> 4, q = lane & 15;
     c32* fr = sc + f * kFrameStride;
     // 256-point FFT of the packed frame: pass 1 over j (stride 16), twiddle w256^(q r), transpose, pass 2 over q
     fft16<false>(x);
-    twiddle16<false>(x, tb.twM[64 * q]);
+    SSK_OPAQUE2(wq);
+    twiddle16<false>(x, wq);
 #pragma unroll
     for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
     wave_sync();
@@ -201,7 +212,7 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, const Tables& tb, 
         const int b = q + 16 * i;
         const f32x4* zk4 = reinterpret_cast<const f32x4*>(fr + 4 * b);          // Z[4b .. 4b+3]
         const f32x4* zp4 = reinterpret_cast<const f32x4*>(fr + 252 - 4 * b);    // Z[252-4b .. 255-4b]
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(tb.tw512 + 4 * b);
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(tw512 + 4 * b);
         const f32x4 k01 = zk4[0], k23 = zk4[1], p01 = zp4[0], p23 = zp4[1], w01 = w4[0], w23 = w4[1];
         const c32 ptop = fr[256 - 4 * b];
         const c32 zk[4] = {k01.xy, k01.zw, k23.xy, k23.zw};
@@ -261,12 +272,13 @@ __global__ __launch_bounds__(256) void k_spectrogram(SpecParams p) {
     const int tb4 = (blockIdx.x % blocks_per_row) * 4 + wv; // pooled time index
     const int unit = row >> 1, ch = row & 1;
     const float* y = p.x + (size_t)row * p.len;
+    const c32 wq = p.tb.twM[64 * (lane & 15)];
     c32 x[16];
     // tb4 >= t4 (tail waves): all frames invalid -> zeros, nothing stored
     stft_load(y, p.len, 4 * tb4 + (lane >> 4), tb4 < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, p.tb.win, x);
     float* o = p.out + (size_t)unit * kBins4 * p.t4 * 2;
     if (tb4 < p.t4)
-        stft_block(sc + wv * kWaveScratch, lane, p.tb, x, [&](int b, float v) { o[(b * p.t4 + tb4) * 2 + ch] = v; });
+        stft_block(sc + wv * kWaveScratch, lane, wq, p.tb.tw512, x, [&](int b, float v) { o[(b * p.t4 + tb4) * 2 + ch] = v; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,33 +309,38 @@ struct ConvParams {
 
 // forward FFT of RIR block i of one ear + multiply by the window spectrum `slot` -> acc (= or +=)
 template <bool ACCUMULATE, bool PREFETCH>
-__device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, int t, const float* h, int L, int i,
-                                           int slot, c32 (&acc)[2][8]) {
-    // PREFETCH = issue the 8 window-spectrum loads before pass 1 instead of at the item stage.  Measured on
-    // MI355X (profiles/r1_notes.md): it is SLOWER (conv 21.3 vs 20.1 us at 128 units): the 128 KB of L2 reads queue
-    // ahead of the RIR's HBM loads on the in-order vmcnt path.  Kept as a switch, off everywhere.
+__device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const float* h,
+                                           int L, int i, int slot, c32 (&acc)[2][8]) {
+    // PREFETCH = issue the 8 window-spectrum loads (L2/MALL hits) at the start of pass 3 instead of at the item
+    // stage, so their latency hides under pass 3.  (Issuing them before pass 1 was measured SLOWER, +1.2 us:
+    // 128 KB of L2 reads queue ahead of the RIR's HBM loads on the in-order vmcnt path.)  Only the loop-free
+    // kernel can afford the 32 VGPRs; the looped kernel also carries an accumulator across the passes.
     const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
     f32x4 sv[2][4];
-    if (PREFETCH) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
-    }
     // bank rows are zero-padded to rir_cap, so the only bound is the row capacity (L is used for block counts)
     const int lo = i * kB, es = p.rir_elem_stride, cap = p.rir_cap;
     (void)L;
     if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
         const c32* h2 = reinterpret_cast<const c32*>(h + lo);
         const int m_end = (cap - lo) >> 1;
-        pass1_fwd<true>(lds, p.tb.twM, t, [&](int m) { return m < m_end ? h2[m] : mk2(0.f, 0.f); });
+        pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? h2[m] : mk2(0.f, 0.f); });
     } else {
-        pass1_fwd<true>(lds, p.tb.twM, t, [&](int m) {
+        pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
             const int n = lo + 2 * m;
             return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
         });
     }
-    fwd_passes(lds, p.tb, t);
+    __syncthreads();
+    pass2<false>(lds, tw.p2, t);
+    __syncthreads();
+    if (PREFETCH) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
+    }
+    pass3_fwd(lds, t);
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if (!PREFETCH) {
@@ -331,7 +348,7 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, int t,
             for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
         }
         c32 v[8];
-        item_load_fwd(lds, p.tb.twItem, t + 1024 * s, v);
+        item_load_fwd(lds, s ? tw.i1 : tw.i0, t + 1024 * s, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const c32 w = (e & 1) ? sv[s][e >> 1].zw : sv[s][e >> 1].xy;
@@ -349,6 +366,17 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     const int t = threadIdx.x;
     const int unit = blockIdx.x >> 1, ch = blockIdx.x & 1, j = SIMPLE ? 0 : blockIdx.y;
     const int* d = p.desc + 8 * unit;
+    const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    // fused path: the STFT's window and exp(-2 pi i k/512) tables are staged in the 21 KiB of LDS the FFT buffer
+    // leaves free, and the lane's 256-point twiddle is fetched now, so the STFT phase starts no global loads
+    __shared__ float s_win[FUSE ? kNfft : 1];
+    __shared__ c32 s_tw512[FUSE ? 256 : 1];
+    c32 wq = mk2(1.f, 0.f);
+    if (FUSE) {
+        if (t < kNfft) s_win[t] = p.tb.win[t];
+        if (t < 256) s_tw512[t] = p.tb.tw512[t];
+        wq = p.tb.twM[64 * (t & 15)];
+    }
 
     c32 acc[2][8];
     bool any = false;
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
             if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
                 const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
-                                conv_block<false, false>(lds, p, t, h, L, 0, spec0 - m_min, acc);
+                                conv_block<false, true>(lds, p, tw, t, h, L, 0, spec0 - m_min, acc);
                 any = true;
             }
         }
@@ -384,11 +412,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             int tl = t;
             SSK_OPAQUE1(tl);
             if (!any) {
-                conv_block<false, false>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
+                conv_block<false, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
                 any = true;
             } else {
                 __syncthreads();                   // previous block's item reads of layout B are done
-                conv_block<true, false>(lds, p, tl, h, L, i, spec0 + (m - m_min), acc);
+                conv_block<true, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
             }
         }
     }
@@ -396,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     c32 y[8];
     if (any) {
         __syncthreads();
-        items_to_time(lds, p.tb, t, acc, y);
+        items_to_time(lds, tw, t, acc, y);
     } else {
 #pragma unroll
         for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
@@ -442,11 +470,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) { const int n = kTail0 + t + 1024 * k; tail[k] = n < kB ? yl[n] : 0.f; }
         c32 x[16];
-        stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, p.tb.win, x);
+        stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x);
         __syncthreads();
         float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
         if (wv < p.t4)
-            stft_block(lds + wv * kWaveScratch, lane, p.tb, x, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
+            stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
         if (p.t4 > 16) {
             __syncthreads();
 #pragma unroll
@@ -454,10 +482,10 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             __syncthreads();
             const bool act = wv + 16 < p.t4;
             stft_load(yl + kTailOff - kTail0, p.out_len, 4 * (wv + 16) + (lane >> 4), act ? p.n_frames : 0, lane & 15,
-                      p.pad_mode, p.tb.win, x);
+                      p.pad_mode, s_win, x);
             __syncthreads();
             if (act)
-                stft_block(lds + wv * kWaveScratch, lane, p.tb, x, [&](int b, float v) {
+                stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) {
                     o[(b * p.t4 + wv + 16) * 2 + ch] = v;
                 });
         }
