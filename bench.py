@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--bank-mib", type=int, default=512, help="RIR bank size per GPU (> 256 MiB Infinity Cache)")
     ap.add_argument("--sounds", type=int, default=102)
     ap.add_argument("--exchange", choices=["allgather", "none"], default="allgather")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
+                                                      "the multi-rank flow on a 1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
@@ -121,11 +123,15 @@ def main():
     from ss_amd.renderer import BatchedAudioRenderer, RirBank
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic, HBM-resident inputs --------------------------------------------------------------
     rng = np.random.default_rng(1000 + rank)

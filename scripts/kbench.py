@@ -15,6 +15,7 @@ ap.add_argument("--sr", type=int, default=16000)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--sizes", default="128,2048")
 ap.add_argument("--only", default="")
+ap.add_argument("--bank-mib", type=int, default=512)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sr = a.sr
@@ -22,7 +23,7 @@ rng = np.random.default_rng(0)
 r = BatchedAudioRenderer(sr, device=dev)
 for i, c in enumerate(O.synth_sources(rng, sr, k=16)):
     r.add_source(str(i), c)
-R = (512 << 20) // (2 * sr * 4)
+R = max(8, (a.bank_mib << 20) // (2 * sr * 4))
 r.set_rir_bank(RirBank(synth_rir_bank_device(torch, R, sr, sr, dev, 3), torch.full((R,), sr, dtype=torch.int32, device=dev)))
 
 def timeit(fn, reps):

@@ -252,7 +252,7 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
             else if (r < 64) v += pf[64 + 63 - r] + pf[32 + 64 - r];
             else v += pf[32];
         }
-        store(r, log1pf(v * (1.0f / 16.0f)));
+        store(r, fast_log1p(v * (1.0f / 16.0f)));
     }
 }
 
