@@ -15,6 +15,7 @@
  *                               abs -> block_reduce(4,4,mean) -> log1p -> stack(axis=-1)
  *   ss_audio_obs_f32         <- get_current_spectrogram_observation on a cache miss
  *                               (soundspaces/simulator.py:690-701), both stages fused
+ *   ss_intensity_f32         <- Intensity.get_observation (ss_baselines/av_wan/avwan_sensors.py:91-100)
  *   ss_source_windows_f32    <- the FFT of the source clip that fftconvolve recomputes on every
  *                               call (simulator.py:630) hoisted out and cached per (sound, window)
  *
@@ -79,6 +80,10 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
                      float* audiogoal, float* spectrogram, int n_units,
                      long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
                      int rir_cap, int n_valid, int out_len, int pad_mode, int flags, void* stream);
+
+/* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
+ * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
+int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,4 +167,16 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
     return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
 }
 
+int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream) {
+    if (n_units == 0) return 0;
+    if (!audiogoal || !out || n_units < 0 || len <= 0 || num_frame <= 0) return SS_EINVAL;
+    ssk::IntensityParams p;
+    p.x = audiogoal;
+    p.out = out;
+    p.len = len;
+    p.num_frame = num_frame;
+    hipLaunchKernelGGL(ssk::k_intensity, dim3(n_units), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
 }  // extern "C"

@@ -492,4 +492,48 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_intensity: av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on the audiogoal:
+//   thr = 0.1 * max(x);  onset = min over ears of the first index with x > thr (0 if none);
+//   out = mean( x[:, onset : onset+num_frame] ** 2 )      (mean over the samples that exist)
+// One 256-thread workgroup per unit; two block reductions (max, then min index) and one sum.
+struct IntensityParams {
+    const float* x;    // [N][2][len]
+    float* out;        // [N]
+    int len, num_frame;
+};
+
+__global__ __launch_bounds__(256) void k_intensity(IntensityParams p) {
+    __shared__ float red[256];
+    __shared__ int redi[256];
+    const int t = threadIdx.x;
+    const float* x = p.x + (size_t)blockIdx.x * 2 * p.len;
+    float m = -3.402823466e38f;
+    for (int i = t; i < 2 * p.len; i += 256) m = fmaxf(m, x[i]);
+    red[t] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = fmaxf(red[t], red[t + s]); __syncthreads(); }
+    const float thr = 0.1f * red[0];
+    __syncthreads();
+    int first[2] = {p.len, p.len};                       // first index above the threshold, per ear
+    for (int c = 0; c < 2; ++c)
+        for (int i = t; i < p.len; i += 256)
+            if (x[c * p.len + i] > thr) { first[c] = i; break; }
+    for (int c = 0; c < 2; ++c) {
+        redi[t] = first[c];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (t < s) redi[t] = min(redi[t], redi[t + s]); __syncthreads(); }
+        first[c] = redi[0] == p.len ? 0 : redi[0];       // np.argmax of an all-False row is 0
+        __syncthreads();
+    }
+    const int onset = min(first[0], first[1]);
+    const int n = min(p.num_frame, p.len - onset);
+    float acc = 0.f;
+    for (int i = t; i < 2 * n; i += 256) { const float v = x[(i / n) * p.len + onset + (i % n)]; acc += v * v; }
+    red[t] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    if (t == 0) p.out[blockIdx.x] = n > 0 ? red[0] / (2.f * n) : 0.f;
+}
+
 }  // namespace ssk

@@ -129,6 +129,19 @@ def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pa
     return ag, sg
 
 
+def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:
+    """av_wan Intensity (ss_baselines/av_wan/avwan_sensors.py:91-100): [N,2,T] -> [N] mean-square of the 150 samples
+    after the onset."""
+    _chk(audiogoal, torch.float32, "audiogoal")
+    N, two, n = audiogoal.shape
+    assert two == 2
+    out = torch.empty((N,), dtype=torch.float32, device=audiogoal.device)
+    with torch.cuda.device(audiogoal.device):
+        _lib.check(_lib.load().ss_intensity_f32(audiogoal.data_ptr(), out.data_ptr(), N, n, num_frame, _stream()),
+                   "ss_intensity_f32")
+    return out
+
+
 # ---- torch.ops.ss_hip.* ------------------------------------------------------------------------------
 def _register():
     lib = torch.library.Library("ss_hip", "DEF")
@@ -138,6 +151,9 @@ def _register():
     lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
     lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
                "int pad_mode=0, bool interleaved=False) -> (Tensor, Tensor)")
+    lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
+    lib.impl("intensity", intensity, "CUDA")
+    lib.impl("intensity", lambda a, num_frame=150: a.new_empty((a.shape[0],)), "Meta")
     lib.impl("source_windows", source_windows, "CUDA")
     lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
     lib.impl("spectrogram", lambda x, pad_mode=0: spectrogram(x, pad_mode), "CUDA")

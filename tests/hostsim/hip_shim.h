@@ -23,3 +23,4 @@ void hostsim_syncthreads();
 void hostsim_wave_sync();
 #define __syncthreads() hostsim_syncthreads()
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int min(int a, int b) { return a < b ? a : b; }

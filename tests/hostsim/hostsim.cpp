@@ -149,4 +149,16 @@ int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mod
     return 0;
 }
 
+int hs_intensity(const float* x, float* out, int n_units, int len, int num_frame) {
+    ssk::IntensityParams p;
+    p.x = x; p.out = out; p.len = len; p.num_frame = num_frame;
+    gridDim = dim3{(unsigned)n_units, 1, 1};
+    for (int b = 0; b < n_units; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(256, [&] { ssk::k_intensity(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

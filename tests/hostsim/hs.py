@@ -99,3 +99,12 @@ def spectrogram(x, pad_mode=0):
     rc = L.hs_spectrogram(_p(x, ctypes.c_float), _p(sg, ctypes.c_float), N, n, pad_mode)
     assert rc == 0, rc
     return sg
+
+
+def intensity(x, num_frame=150):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.full((x.shape[0],), np.nan, np.float32)
+    rc = L.hs_intensity(_p(x, ctypes.c_float), _p(out, ctypes.c_float), x.shape[0], x.shape[2], num_frame)
+    assert rc == 0, rc
+    return out

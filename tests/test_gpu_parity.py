@@ -215,3 +215,57 @@ def test_linearity_and_shift_properties_full_size():
     assert np.abs(ag[3] - shifted[None]).max() <= 1e-5
     for k in range(4, 128):
         np.testing.assert_array_equal(ag[k], ag[k % 4])        # deterministic across workgroups
+
+
+def test_intensity_sensor():
+    from ss_amd import ops
+    z = golden()[0]
+    a = z["clip1s/audiogoal"]
+    x = np.stack([a, np.zeros_like(a), a[::-1].copy()])
+    got = torch.ops.ss_hip.intensity(torch.from_numpy(x).to(DEV), 150).cpu().numpy()
+    np.testing.assert_allclose(got[0], z["clip1s/intensity"][0], rtol=2e-6)     # vs the reference's own function
+    for n in range(3):
+        np.testing.assert_allclose(got[n], O.intensity(x[n])[0], rtol=2e-6, atol=1e-12)
+
+
+def test_audiogoal_batcher_savi_semantics():
+    from ss_amd.datasets import AudioGoalBatcher
+    d0, d2 = case_inputs("savi_i0"), case_inputs("savi_i2")
+    sr = d0["sr"]
+    r = make_renderer(sr, [d0["source"]], [d0["rir"]])
+    b = AudioGoalBatcher(r)
+    ag, sg = b.spectrograms([0, 0], [0, 0], [d0["rir"].shape[0]] * 2, [0, 2], want_audiogoal=True)
+    for n, name in enumerate(("savi_i0", "savi_i2")):
+        ref_a, ref_s, stride = case_outputs(name)
+        check(ag[n].cpu().numpy()[:, ::stride], ref_a)
+        check(sg[n].cpu().numpy(), ref_s)
+    idx = b.draw_indices(np.random.default_rng(0), [0] * 50)
+    assert idx.min() >= 0 and idx.max() <= len(d0["source"]) // sr - 2          # random.randint(0, n - 2), inclusive
+
+
+def test_plugin_boundary_end_to_end_on_gpu():
+    """The reference-shaped call chain sensor -> sim.get_current_spectrogram_observation -> HIP engine, with the real
+    AudioEngine (RIR store + renderer) behind a stand-in simulator object."""
+    from fakes import FakeSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    d = case_inputs("clip1s")
+    sr = d["sr"]
+    ref_a, ref_s, _ = case_outputs("clip1s")
+    sim = FakeSim(sr, {"telephone.wav": d["source"]}, {"rirs/replica/apartment_0/90/3_7.wav": d["rir"]})
+    eng = AudioEngine(sr, device=DEV, rir_slots=16)
+    sim_audio.attach(sim, eng, rir_reader=sim.reader)
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    s = sg_sensor.get_observation(observations=None, episode=None)
+    a = ag_sensor.get_observation(observations=None, episode=None)
+    assert s.dtype == np.float32 and s.shape == sg_sensor.observation_space.shape
+    check(a, ref_a)
+    check(s, ref_s)
+    assert sg_sensor.get_observation(observations=None, episode=None) is s       # memo cache hit
+    assert eng.store.misses == 1
+    check(sensors.SpectrogramSensor.compute_spectrogram(ref_a), ref_s)           # static method = HIP kernel
+    sim._rotation_angle = 0                                                        # azimuth 0: file missing -> zeros
+    assert not sg_sensor.get_observation(observations=None, episode=None).any()
+    obs = sim_audio.VectorAudioObserver(eng, [sim._ss_hip_audio] * 3, want_audiogoal=True).observe()
+    assert tuple(obs["spectrogram"].shape) == (3, 65, 26, 2) and obs["spectrogram"].is_cuda

@@ -156,3 +156,16 @@ def test_window_planning():
     assert P.plan_window_set(16000, 5 * P.KB, 1, 1).count == 0
     row = P.unit_desc_row()
     assert row[0] == -1 and row[4] == -1
+
+
+def test_intensity_kernel_vs_reference_run():
+    z = golden()[0]
+    a = z["clip1s/audiogoal"]
+    rng = np.random.default_rng(2)
+    late = np.zeros((2, 16000), np.float32)
+    late[:, 15950:] = rng.standard_normal((2, 50)).astype(np.float32)            # onset near the end: < 150 samples
+    x = np.stack([a, np.zeros_like(a), -np.abs(a) - 1.0, late])
+    got = hs.intensity(x)
+    np.testing.assert_allclose(got[0], z["clip1s/intensity"][0], rtol=2e-6)
+    for n in range(4):
+        np.testing.assert_allclose(got[n], O.intensity(x[n])[0], rtol=2e-6, atol=1e-12)
