@@ -54,6 +54,19 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() carries a workgroup-scope release fence, which on
+// gfx9 lowers to s_waitcnt vmcnt(0): every barrier would drain all outstanding global loads and stores, i.e. no
+// prefetch issued before a barrier could overlap the compute behind it (measured: the software-pipelined kernel was
+// SLOWER with __syncthreads()).  All barriers in these kernels only hand LDS data between waves, so waiting for the
+// wave's own LDS operations (lgkmcnt) before s_barrier is sufficient; global loads / stores stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 constexpr int kM = 16384;            // complex points of one block FFT
 constexpr int kB = 16384;            // real samples of one partition block (FFT covers 2*kB)
 constexpr int kT = 1024;             // threads per workgroup
@@ -318,7 +331,7 @@ __device__ __forceinline__ void pass3_fwd(c32* lds, int t) {
     for (int c = 0; c < 16; ++c) x[c] = src[4 * c];
     fft16<false>(x);
     twiddle16_d<false>(x, __builtin_amdgcn_readfirstlane(d));
-    __syncthreads();                       // every layout-A read done before layout-B writes
+    lds_barrier();                       // every layout-A read done before layout-B writes
 #pragma unroll
     for (int c = 0; c < 16; ++c) dst[c] = x[c];
 }
@@ -333,7 +346,7 @@ __device__ __forceinline__ void pass3_inv(c32* lds, int t) {
     for (int c = 0; c < 16; ++c) x[c] = src[c];
     twiddle16_d<true>(x, __builtin_amdgcn_readfirstlane(d));
     fft16<true>(x);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int c = 0; c < 16; ++c) dst[4 * c] = x[c];
 }

@@ -66,11 +66,11 @@ __device__ __forceinline__ void pass1_inv(const c32* lds, c32 wbase, int t, c32 
 
 // forward chain after pass 1 up to "layout B holds the radix-4 groups" (items are then read one at a time)
 __device__ __forceinline__ void fwd_passes(c32* lds, const ThreadTw& tw, int t) {
-    __syncthreads();
+    lds_barrier();
     pass2<false>(lds, tw.p2, t);
-    __syncthreads();
+    lds_barrier();
     pass3_fwd(lds, t);
-    __syncthreads();
+    lds_barrier();
 }
 
 // inverse chain from "items hold Y2 bins" to the last kB real samples in registers.
@@ -78,11 +78,11 @@ __device__ __forceinline__ void fwd_passes(c32* lds, const ThreadTw& tw, int t) 
 __device__ __forceinline__ void items_to_time(c32* lds, const ThreadTw& tw, int t, c32 (&acc)[2][8], c32 (&y)[8]) {
     item_store_inv(lds, tw.i0, t, acc[0]);
     item_store_inv(lds, tw.i1, t + 1024, acc[1]);
-    __syncthreads();
+    lds_barrier();
     pass3_inv(lds, t);
-    __syncthreads();
+    lds_barrier();
     pass2<true>(lds, tw.p2, t);
-    __syncthreads();
+    lds_barrier();
     pass1_inv(lds, tw.p1, t, y);
 }
 
@@ -330,9 +330,9 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const 
             return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
         });
     }
-    __syncthreads();
+    lds_barrier();
     pass2<false>(lds, tw.p2, t);
-    __syncthreads();
+    lds_barrier();
     if (PREFETCH) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -340,7 +340,7 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const 
             for (int hh = 0; hh < 4; ++hh) sv[s][hh] = sp[(s * 4 + hh) * 1024];
     }
     pass3_fwd(lds, t);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if (!PREFETCH) {
@@ -360,6 +360,115 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const 
     }
 }
 
+// One (unit, ear) row of the SIMPLE case after pass 1 has filled the LDS buffer: passes 2-3, the item stage, passes
+// 3'-2'-1'.  The item stage is IN PLACE per thread (a thread writes back exactly the layout-B slots it read), so each
+// item is carried through load -> Hermitian split -> multiply by the window spectrum -> merge -> inverse radix-4 ->
+// store before the next one starts: no accumulator array, no barrier between the two halves, ~35 fewer live VGPRs.
+// Item 0's spectrum values are fetched before pass 3 and item 1's while item 0 is being processed, so neither L2
+// round trip is exposed.
+__device__ __forceinline__ void multiply_item(c32* lds, c32 wg, int t, int s, const f32x4 (&sv)[4]) {
+    c32 v[8];
+    item_load_fwd(lds, wg, t + 1024 * s, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const c32 w = (e & 1) ? sv[e >> 1].zw : sv[e >> 1].xy;
+        c32 pr = cmul(v[e], w);
+        if (s == 0 && e == 0 && t == 0) pr = mk2(v[0].x * w.x, v[0].y * w.y);   // (X[0], X[16384]) are real
+        v[e] = pr;
+    }
+    item_store_inv(lds, wg, t + 1024 * s, v);
+}
+
+__device__ __forceinline__ void simple_row_after_pass1(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, int slot,
+                                                       c32 (&y)[8]) {
+    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+    lds_barrier();
+    pass2<false>(lds, tw.p2, t);
+    lds_barrier();
+    f32x4 sv0[4], sv1[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) sv0[hh] = sp[hh * 1024];
+    pass3_fwd(lds, t);
+    lds_barrier();
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) sv1[hh] = sp[(4 + hh) * 1024];
+    multiply_item(lds, tw.i0, t, 0, sv0);
+    multiply_item(lds, tw.i1, t, 1, sv1);
+    lds_barrier();
+    pass3_inv(lds, t);
+    lds_barrier();
+    pass2<true>(lds, tw.p2, t);
+    lds_barrier();
+    pass1_inv(lds, tw.p1, t, y);
+}
+
+// write one output block (kB samples starting at j*kB) of row `row`; block 0 also zero-fills [n_valid, out_len)
+__device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size_t row, int j, const c32 (&y)[8]) {
+    if (!p.out) return;
+    float* orow = p.out + row * p.out_len + j * kB;
+    const int nv = p.n_valid - j * kB;                     // valid samples of this block
+    if (!(nv & 1) && !(reinterpret_cast<size_t>(orow) & 7)) {
+        c32* o2 = reinterpret_cast<c32*>(orow) + t;
+        const int m_end = nv >> 1;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) if (t + 1024 * a < m_end) o2[1024 * a] = y[a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int n = 2 * (t + 1024 * a);
+            if (n < nv) orow[n] = y[a].x;
+            if (n + 1 < nv) orow[n + 1] = y[a].y;
+        }
+    }
+    if (j == 0) for (int n = p.n_valid + t; n < p.out_len; n += kT) p.out[row * p.out_len + n] = 0.f;
+}
+
+// Fused STFT phase (out_len <= kB, t4 <= 26): the 1-s row goes from registers into LDS and feeds the STFT directly.
+__device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
+                                                 const float* s_win, const c32* s_tw512, c32 wq) {
+    float* yl = reinterpret_cast<float*>(lds);
+    lds_barrier();   // all pass-1' reads of layout A are done
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int n = 2 * (t + 1024 * a);
+        yl[n] = n < p.n_valid ? y[a].x : 0.f;
+        yl[n + 1] = n + 1 < p.n_valid ? y[a].y : 0.f;
+    }
+    lds_barrier();
+    const int lane = t & 63, wv = t >> 6;
+    // The row (<= 16384 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch
+    // overlays the whole buffer.  Round 1 = time blocks 0..15 (frames pulled into registers first);
+    // round 2 = blocks 16..25, which only read y[9984..]: that tail is parked in 7 registers per thread
+    // across round 1 and put back above the scratch of the <= 10 waves that are active in round 2.
+    constexpr int kTail0 = kHop * 64 - kNfft / 2;          // 9984: first sample frame 64 touches
+    constexpr int kTailOff = 10 * kWaveScratch * 2;        // float offset just above 10 waves of scratch
+    float tail[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { const int n = kTail0 + t + 1024 * k; tail[k] = n < kB ? yl[n] : 0.f; }
+    c32 x[16];
+    stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x);
+    lds_barrier();
+    float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
+    if (wv < p.t4)
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
+    if (p.t4 > 16) {
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { const int n = t + 1024 * k; if (kTail0 + n < kB) yl[kTailOff + n] = tail[k]; }
+        lds_barrier();
+        const bool act = wv + 16 < p.t4;
+        stft_load(yl + kTailOff - kTail0, p.out_len, 4 * (wv + 16) + (lane >> 4), act ? p.n_frames : 0, lane & 15,
+                  p.pad_mode, s_win, x);
+        lds_barrier();
+        if (act)
+            stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) {
+                o[(b * p.t4 + wv + 16) * 2 + ch] = v;
+            });
+    }
+}
+
+// SIMPLE: the caller guarantees one output block (gridDim.y == 1), RIR capacity <= kB and no distractor term,
+// so a unit is at most ONE forward FFT: straight-line code, no accumulator carried across passes, no scratch.
 template <bool FUSE, bool SIMPLE>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     __shared__ c32 lds[kLdsComplex];
@@ -379,9 +488,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     }
 
     c32 acc[2][8];
+    c32 y[8];
     bool any = false;
     if (SIMPLE) {
         const int ridx = __builtin_amdgcn_readfirstlane(d[0]);
+        bool active = false;
         if (ridx >= 0) {
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
@@ -389,9 +500,24 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
             if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
                 const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
-                                conv_block<false, true>(lds, p, tw, t, h, L, 0, spec0 - m_min, acc);
-                any = true;
+                const int es = p.rir_elem_stride, cap = p.rir_cap;
+                if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
+                    const c32* h2 = reinterpret_cast<const c32*>(h);
+                    const int m_end = cap >> 1;
+                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? h2[m] : mk2(0.f, 0.f); });
+                } else {
+                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
+                        const int n = 2 * m;
+                        return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
+                    });
+                }
+                simple_row_after_pass1(lds, p, tw, t, spec0 - m_min, y);
+                active = true;
             }
+        }
+        if (!active) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
         }
     } else
     for (int term = 0; term < 2; ++term) {
@@ -415,81 +541,23 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                 conv_block<false, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
                 any = true;
             } else {
-                __syncthreads();                   // previous block's item reads of layout B are done
+                lds_barrier();                   // previous block's item reads of layout B are done
                 conv_block<true, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
             }
         }
     }
 
-    c32 y[8];
-    if (any) {
-        __syncthreads();
-        items_to_time(lds, tw, t, acc, y);
-    } else {
-#pragma unroll
-        for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
-    }
-    const size_t row = (size_t)unit * 2 + ch;
-    if (p.out) {
-        float* orow = p.out + row * p.out_len + j * kB;
-        const int nv = p.n_valid - j * kB;                     // valid samples of this block
-        if (!(nv & 1) && !(reinterpret_cast<size_t>(orow) & 7)) {
-            c32* o2 = reinterpret_cast<c32*>(orow) + t;
-            const int m_end = nv >> 1;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) if (t + 1024 * a < m_end) o2[1024 * a] = y[a];
+    if (!SIMPLE) {
+        if (any) {
+            lds_barrier();
+            items_to_time(lds, tw, t, acc, y);
         } else {
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const int n = 2 * (t + 1024 * a);
-                if (n < nv) orow[n] = y[a].x;
-                if (n + 1 < nv) orow[n + 1] = y[a].y;
-            }
-        }
-        if (j == 0) for (int n = p.n_valid + t; n < p.out_len; n += kT) p.out[row * p.out_len + n] = 0.f;
-    }
-
-    if (FUSE) {     // gridDim.y == 1, out_len <= kB, t4 <= 26: the row stays in LDS and feeds the STFT directly
-        float* yl = reinterpret_cast<float*>(lds);
-        __syncthreads();   // all pass-1' reads of layout A are done
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int n = 2 * (t + 1024 * a);
-            yl[n] = n < p.n_valid ? y[a].x : 0.f;
-            yl[n + 1] = n + 1 < p.n_valid ? y[a].y : 0.f;
-        }
-        __syncthreads();
-        const int lane = t & 63, wv = t >> 6;
-        // The row (<= 16384 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch
-        // overlays the whole buffer.  Round 1 = time blocks 0..15 (frames pulled into registers first);
-        // round 2 = blocks 16..25, which only read y[9984..]: that tail is parked in 7 registers per thread
-        // across round 1 and put back above the scratch of the <= 10 waves that are active in round 2.
-        constexpr int kTail0 = kHop * 64 - kNfft / 2;          // 9984: first sample frame 64 touches
-        constexpr int kTailOff = 10 * kWaveScratch * 2;        // float offset just above 10 waves of scratch
-        float tail[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) { const int n = kTail0 + t + 1024 * k; tail[k] = n < kB ? yl[n] : 0.f; }
-        c32 x[16];
-        stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x);
-        __syncthreads();
-        float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
-        if (wv < p.t4)
-            stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
-        if (p.t4 > 16) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 7; ++k) { const int n = t + 1024 * k; if (kTail0 + n < kB) yl[kTailOff + n] = tail[k]; }
-            __syncthreads();
-            const bool act = wv + 16 < p.t4;
-            stft_load(yl + kTailOff - kTail0, p.out_len, 4 * (wv + 16) + (lane >> 4), act ? p.n_frames : 0, lane & 15,
-                      p.pad_mode, s_win, x);
-            __syncthreads();
-            if (act)
-                stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) {
-                    o[(b * p.t4 + wv + 16) * 2 + ch] = v;
-                });
+            for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
         }
     }
+    store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    if (FUSE) fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
 }
 
 // ---------------------------------------------------------------------------------------------

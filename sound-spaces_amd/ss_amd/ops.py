@@ -17,6 +17,7 @@ from .planning import KB, SPEC_FLOATS, ceil_div, spectrogram_shape
 
 PAD_REFLECT, PAD_CONSTANT = 0, 1
 FLAG_NO_DISTRACTOR = 1      # SS_FLAG_NO_DISTRACTOR: every unit descriptor has term 1 absent
+
 _PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
 
 
