@@ -199,8 +199,28 @@ class BatchedAudioRenderer:
         return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), flags)
 
     def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> Plan:
-        """Vector form of plan() for the common no-distractor case (rir < 0 = silent)."""
-        return self.plan([UnitRequest(int(s), int(t), int(r)) for s, t, r in zip(sound, t0, rir)])
+        """Vectorised plan() for the common no-distractor case (rir < 0 = silent): the per-step host cost is a handful
+        of numpy operations on the N-vectors plus one dict lookup per *distinct* (sound, t0) pair."""
+        assert self.rirs is not None, "set_rir_bank() first"
+        sound = np.asarray(sound, np.int64)
+        t0 = np.asarray(t0, np.int64)
+        rir = np.asarray(rir, np.int64)
+        active = rir >= 0
+        desc = np.zeros((sound.shape[0], 8), np.int32)
+        desc[:, 0] = -1
+        desc[:, 4] = -1
+        if active.any():
+            keys, inv = np.unique(np.stack([sound[active], t0[active]], axis=1), axis=0, return_inverse=True)
+            self._ensure_windows([(int(s), int(t), self.wrap) for s, t in keys])
+            tab = np.array([(self._windows[(int(s), int(t), self.wrap)][0],) +
+                            (lambda ws: (ws.m_min, ws.count))(self._windows[(int(s), int(t), self.wrap)][1])
+                            for s, t in keys], np.int32).reshape(-1, 3)
+            rows = tab[inv.reshape(-1)]
+            ok = rows[:, 2] > 0                                  # windows with nothing to convolve -> silent
+            idx = np.flatnonzero(active)[ok]
+            desc[idx, 0] = rir[active][ok]
+            desc[idx, 1:4] = rows[ok]
+        return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), ops.FLAG_NO_DISTRACTOR)
 
     # ---- rendering ---------------------------------------------------------------------------------------
     def render(self, plan: Plan, want_audiogoal: bool = False,
@@ -288,6 +308,27 @@ class RirStore:
         self._slot_of[key] = slot
         self._upload(slot, loader())
         return slot
+
+
+def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 90, 180, 270), limit: Optional[int] = None):
+    """Bulk pre-load of one scene's binaural RIRs, `<scene_rir_dir>/<azimuth>/<receiver>_<source>.wav`
+    (soundspaces/README.md:38-42, simulator.py:615-616), into the HBM store so that no step of an episode in this scene
+    touches the disk.  Keys are the file paths the simulator adapter asks for.  Returns the number of files loaded."""
+    import os
+    n = 0
+    for az in azimuths:
+        d = os.path.join(scene_rir_dir, str(az))
+        if not os.path.isdir(d):
+            continue
+        for name in sorted(os.listdir(d)):
+            if not name.endswith(".wav"):
+                continue
+            path = os.path.join(d, name)
+            store.slot(path, lambda path=path: reader(path))
+            n += 1
+            if limit is not None and n >= limit:
+                return n
+    return n
 
 
 class AudioEngine:

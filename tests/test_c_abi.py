@@ -1,0 +1,57 @@
+"""The C-ABI library (include/ss_hip.h): it loads without a GPU, exports every declared symbol, and rejects bad
+arguments with SS_EINVAL before touching the device.  No compute calls here (CPU container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from ss_amd import _lib, planning
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ss_hip.h")).read()
+    return sorted(set(re.findall(r"\bint\s+(ss_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert set(names) == set(_lib.EXPORTS)
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_geometry_constants_match_python_planning():
+    lib = _lib.load()
+    assert lib.ss_block_len() == planning.KB
+    assert lib.ss_spec_floats() == planning.SPEC_FLOATS
+    assert lib.ss_version() >= 1
+
+
+def test_argument_checks_return_einval_without_a_gpu():
+    lib = _lib.load()
+    null = None
+    one = ctypes.c_void_p(16)          # non-null dummy pointer: never dereferenced on these paths
+    assert lib.ss_source_windows_f32(null, one, one, 4, null) == -1
+    assert lib.ss_source_windows_f32(one, one, one, 0, null) == 0                        # empty batch is a no-op
+    assert lib.ss_fftconv_binaural_f32(one, one, one, one, null, 2, 32000, 16000, 1, 16000, 16000, 16000, 0, null) == -1
+    assert lib.ss_fftconv_binaural_f32(one, one, one, one, one, 2, 32000, 16000, 1, 16000, 16001, 16000, 0, null) == -1   # n_valid > out_len
+    assert lib.ss_fftconv_binaural_f32(one, one, one, one, one, 2, 32000, 16000, 0, 16000, 16000, 16000, 0, null) == -1   # elem stride 0
+    assert lib.ss_fftconv_binaural_f32(one, one, one, one, one, 0, 32000, 16000, 1, 16000, 16000, 16000, 0, null) == 0
+    assert lib.ss_spectrogram_f32(one, one, 1, 100, 0, null) == -1                       # shorter than the reflect pad
+    assert lib.ss_spectrogram_f32(one, one, 1, 16000, 7, null) == -1                     # unknown pad mode
+    assert lib.ss_audio_obs_f32(one, one, one, one, null, null, 1, 32000, 16000, 1, 16000, 16000, 16000, 0, 0, null) == -1
+    assert lib.ss_intensity_f32(one, one, 1, 16000, 0, null) == -1
+    assert lib.ss_intensity_f32(null, one, 1, 16000, 150, null) == -1
+
+
+def test_python_layer_refuses_cpu_tensors():
+    import torch
+    from ss_amd import ops
+    with pytest.raises(_lib.SsHipError):
+        ops.spectrogram(torch.zeros((1, 2, 16000)))
+    with pytest.raises(_lib.SsHipError):
+        ops.intensity(torch.zeros((1, 2, 16000)))

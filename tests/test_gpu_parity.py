@@ -269,3 +269,21 @@ def test_plugin_boundary_end_to_end_on_gpu():
     assert not sg_sensor.get_observation(observations=None, episode=None).any()
     obs = sim_audio.VectorAudioObserver(eng, [sim._ss_hip_audio] * 3, want_audiogoal=True).observe()
     assert tuple(obs["spectrogram"].shape) == (3, 65, 26, 2) and obs["spectrogram"].is_cuda
+
+
+def test_vectorised_planner_equals_per_unit_planner():
+    from ss_amd.renderer import UnitRequest
+    sr = 16000
+    rng = np.random.default_rng(4)
+    src = [O.synth_sources(rng, sr, k=1, seconds=s)[0] for s in (1, 1, 4)]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=6)]
+    r = make_renderer(sr, src, rirs)
+    n = 64
+    sound = rng.integers(0, 3, n)
+    t0 = np.where(sound == 2, rng.integers(0, 6, n) * sr, 0)          # includes windows past the end of the 4-s clip
+    rir = rng.integers(-1, 6, n)                                        # -1 = silent
+    a = r.plan_arrays(sound, t0, rir)
+    b = r.plan([UnitRequest(int(s), int(t), int(h)) for s, t, h in zip(sound, t0, rir)])
+    assert torch.equal(a.desc, b.desc) and a.flags == b.flags
+    sg = r.render(a)[1].cpu().numpy()
+    assert not sg[rir < 0].any()

@@ -146,3 +146,21 @@ def test_rir_store_lru_and_refresh():
 def test_unit_request_defaults():
     u = UnitRequest()
     assert u.rir == -1 and not u.silent and u.dis_rir == -1
+
+
+def test_bulk_scene_loader(tmp_path):
+    from scipy.io import wavfile
+    from ss_amd.renderer import load_scene_rirs
+    from ss_amd.sim_audio import wav_rir_reader
+    rng = np.random.default_rng(0)
+    for az in (0, 90):
+        (tmp_path / str(az)).mkdir()
+        for name in ("3_7", "5_7"):
+            wavfile.write(str(tmp_path / str(az) / f"{name}.wav"), SR, rng.standard_normal((1200, 2)).astype(np.float32))
+    (tmp_path / "90" / "bad_1.wav").write_bytes(b"not a wav")                     # unreadable -> zero RIR, length 0
+    st = RirStore(slots=16, cap=2000, device="cpu")
+    assert load_scene_rirs(st, str(tmp_path), wav_rir_reader) == 5
+    slot = st.slot(str(tmp_path / "90" / "3_7.wav"), lambda: (_ for _ in ()).throw(AssertionError("must be a hit")))
+    assert int(st.bank.lengths[slot]) == 1200 and st.hits == 1
+    bad = st.slot(str(tmp_path / "90" / "bad_1.wav"), lambda: None)
+    assert int(st.bank.lengths[bad]) == 0 and not st.bank.data[bad].any()
