@@ -169,3 +169,32 @@ def test_intensity_kernel_vs_reference_run():
     np.testing.assert_allclose(got[0], z["clip1s/intensity"][0], rtol=2e-6)
     for n in range(4):
         np.testing.assert_allclose(got[n], O.intensity(x[n])[0], rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_randomised_edge_cases(seed):
+    """Ragged / odd RIR lengths (down to 1 tap), odd n_valid, windows that run past the end of the clip, multi-second
+    t0, both bank layouts, fused and unfused, SIMPLE and loop kernels — against the direct O(L*T) formula."""
+    rng = np.random.default_rng(100 + seed)
+    sr = 16000
+    seconds = int(rng.integers(1, 4))
+    src = O.synth_sources(rng, sr, k=1, seconds=seconds)[0]
+    L = int(rng.choice([1, 2, 3, 777, 4001, 15999, 16000]))
+    h = (O.synth_rir(rng, sr, length=L, n=1)[0] if L > 1000 else
+         (0.3 * rng.standard_normal((2, L))).astype(np.float32))                # planar [2, L]
+    cap = int(rng.choice([L + (L & 1), 16000, 16384]))
+    cap = max(cap, L + (L & 1), 2)
+    bank = np.zeros((1, 2, cap), np.float32)
+    bank[0, :, :L] = h
+    n_valid = int(rng.choice([sr, 4000, 4001, 1, 15999]))
+    t0 = int(rng.choice([0, 5, sr, len(src) - 100, len(src) + 7]))
+    kw = dict(fuse=bool(seed & 1), interleaved=bool(seed & 2) and not (seed & 1), simple=bool(rng.integers(0, 2)))
+    out, sg = hs.run([src], bank, [L], [dict(sound=0, t0=t0, rir=0)], n_valid, sr, want_spectrogram=True, **kw)
+    ref = np.zeros((2, sr))
+    ref[:, :n_valid] = O.conv_window_direct(src, np.ascontiguousarray(h.T), t0, n_valid) if n_valid <= 512 else \
+        O.conv_window_fft(src.astype(np.float64), np.ascontiguousarray(h.T).astype(np.float64), t0, n_valid)
+    bound = np.abs(src).max() * np.abs(h).sum(axis=1).max()          # |out| <= max|x| * sum|h|: FFT rounding scales with it
+    assert np.abs(out[0] - ref).max() <= 2e-6 * bound
+    assert not out[0][:, n_valid:].any()
+    if np.abs(ref).max() > 1e-3 * bound:
+        check(sg[0], O.compute_spectrogram(ref.astype(np.float32)), tol=1e-4)
