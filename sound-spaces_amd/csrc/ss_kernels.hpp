@@ -436,34 +436,22 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     }
     lds_barrier();
     const int lane = t & 63, wv = t >> 6;
-    // The row (<= 16384 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch
-    // overlays the whole buffer.  Round 1 = time blocks 0..15 (frames pulled into registers first);
-    // round 2 = blocks 16..25, which only read y[9984..]: that tail is parked in 7 registers per thread
-    // across round 1 and put back above the scratch of the <= 10 waves that are active in round 2.
-    constexpr int kTail0 = kHop * 64 - kNfft / 2;          // 9984: first sample frame 64 touches
-    constexpr int kTailOff = 10 * kWaveScratch * 2;        // float offset just above 10 waves of scratch
-    float tail[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) { const int n = kTail0 + t + 1024 * k; tail[k] = n < kB ? yl[n] : 0.f; }
-    c32 x[16];
-    stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x);
+    // The row (<= 16384 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch overlays the whole
+    // buffer, so every wave first pulls the frames of BOTH its time blocks (wv and wv+16; t4 <= 26) into registers;
+    // after one barrier the row is dead and each wave runs its two blocks back to back in its private scratch with
+    // wave-scope synchronisation only (no workgroup barrier, waves free-running).
+    c32 x0[16], x1[16];
+    const bool two = wv + 16 < p.t4;
+    stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x0);
+    stft_load(yl, p.out_len, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x1);
     lds_barrier();
     float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
     if (wv < p.t4)
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
-    if (p.t4 > 16) {
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < 7; ++k) { const int n = t + 1024 * k; if (kTail0 + n < kB) yl[kTailOff + n] = tail[k]; }
-        lds_barrier();
-        const bool act = wv + 16 < p.t4;
-        stft_load(yl + kTailOff - kTail0, p.out_len, 4 * (wv + 16) + (lane >> 4), act ? p.n_frames : 0, lane & 15,
-                  p.pad_mode, s_win, x);
-        lds_barrier();
-        if (act)
-            stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) {
-                o[(b * p.t4 + wv + 16) * 2 + ch] = v;
-            });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
+    if (two) {
+        wave_sync();
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1,
+                   [&](int b, float v) { o[(b * p.t4 + wv + 16) * 2 + ch] = v; });
     }
 }
 
