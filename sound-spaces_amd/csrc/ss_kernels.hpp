@@ -428,11 +428,11 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
                                                  const float* s_win, const c32* s_tw512, c32 wq) {
     float* yl = reinterpret_cast<float*>(lds);
     lds_barrier();   // all pass-1' reads of layout A are done
+    c32* yl2 = lds + t;                                   // the row as packed pairs: one ds_write_b64 per pair
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         const int n = 2 * (t + 1024 * a);
-        yl[n] = n < p.n_valid ? y[a].x : 0.f;
-        yl[n + 1] = n + 1 < p.n_valid ? y[a].y : 0.f;
+        yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);
     }
     lds_barrier();
     const int lane = t & 63, wv = t >> 6;
