@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--bank-mib", type=int, default=512, help="RIR bank size per GPU (> 256 MiB Infinity Cache)")
     ap.add_argument("--sounds", type=int, default=102)
     ap.add_argument("--exchange", choices=["allgather", "none"], default="allgather")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="steps per all-gather: the learner consumes rollouts, so per-rank slabs are exchanged in chunks of "
+                         "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); 1 = every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank flow on a 1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -146,14 +149,22 @@ def main():
     descs = [r.plan_arrays(rng.integers(0, args.sounds, N), np.zeros(N, np.int64), rng.integers(0, R, N))
              for _ in range(total)]
     t4 = r.spectrogram_shape[1]
-    ex = SlabExchange((N,) + r.spectrogram_shape, device=dev) if (world > 1 and args.exchange == "allgather") else None
+    G = max(1, args.gather_every)
+    ex = SlabExchange((G * N,) + r.spectrogram_shape, device=dev) if (world > 1 and args.exchange == "allgather") else None
+    chunk = {"buf": None, "n": 0}
     sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(2)]
     ag_buf = torch.empty((N, 2, sr), dtype=torch.float32, device=dev) if (args.with_audiogoal or sr > P.KB) else None
 
     def step(k):
         if ex is not None:
-            r.render(descs[k], spectrogram_out=ex.next_local(), audiogoal_out=ag_buf)
-            ex.gather()
+            if chunk["n"] == 0:
+                chunk["buf"] = ex.next_local()                 # [G*N, 65, T4, 2]: G consecutive steps of this rank
+            i = chunk["n"]
+            r.render(descs[k], spectrogram_out=chunk["buf"][i * N:(i + 1) * N], audiogoal_out=ag_buf)
+            chunk["n"] += 1
+            if chunk["n"] == G:
+                ex.gather()
+                chunk["n"] = 0
         else:
             r.render(descs[k], spectrogram_out=sg_buf[k & 1], audiogoal_out=ag_buf)
 
@@ -162,10 +173,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def flush():
+        if ex is not None:
+            if chunk["n"]:                                     # partial last chunk
+                ex.gather()
+                chunk["n"] = 0
+            ex.wait()
+
     for k in range(args.warmup):
         step(k)
-    if ex is not None:
-        ex.wait()
+    flush()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
@@ -173,8 +190,7 @@ def main():
     for k in range(args.warmup, total):
         step(k)
     ev1.record()
-    if ex is not None:
-        ex.wait()
+    flush()
     fence()
     elapsed = time.perf_counter() - t_start
     kernel_ms = ev0.elapsed_time(ev1) / args.steps           # avg launch duration on the launch stream
@@ -223,7 +239,7 @@ def main():
                                    f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident), "
                                    "cache-miss path, spectrogram [65,%d,2] f32 out" % t4,
                        "envs_per_gpu": N, "sampling_rate": sr, "rir_len": L,
-                       "exchange": (args.exchange if world > 1 else "none"), "kernel": "k_conv<fused>" if fused else
+                       "exchange": ((args.exchange + f" every {G} steps") if (world > 1 and args.exchange == "allgather") else "none"), "kernel": "k_conv<fused>" if fused else
                        "k_conv + k_spectrogram"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
