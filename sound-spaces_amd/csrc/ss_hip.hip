@@ -136,8 +136,13 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
     p.n_frames = n_frames_of(len);
     p.t4 = t4_of(len);
     p.pad_mode = pad_mode;
-    const int blocks_per_row = (p.t4 + 3) / 4;
-    hipLaunchKernelGGL(ssk::k_spectrogram, dim3(2 * n_units * blocks_per_row), dim3(256), 0,
+    const int groups = (p.t4 + 3) / 4;                      // 4 pooled time blocks x 2 ears per round of a workgroup
+    // large batches: one workgroup walks several groups (tables staged once, next segment prefetched under the math);
+    // small batches keep one group per workgroup so that the launch still fills 256 CUs x 2 workgroups
+    long long gpw = (long long)n_units * groups / 2048;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    hipLaunchKernelGGL(ssk::k_spectrogram, dim3(n_units * chunks), dim3(512), 0,
                        static_cast<hipStream_t>(stream), p);
     return hip_err(hipGetLastError());
 }

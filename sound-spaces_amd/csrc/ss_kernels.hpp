@@ -261,24 +261,96 @@ struct SpecParams {
     float* out;           // [N][65][T4][2]
     Tables tb;
     int len, n_frames, t4, pad_mode;
+    int gpw;              // groups (of 4 pooled time blocks) handled per workgroup
 };
 
-// stand-alone spectrogram: 256 threads = 4 waves, each wave one (unit, channel, time-block).
-__global__ __launch_bounds__(256) void k_spectrogram(SpecParams p) {
-    __shared__ c32 sc[4 * kWaveScratch];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int blocks_per_row = (p.t4 + 3) >> 2;
-    const int row = blockIdx.x / blocks_per_row;            // unit*2 + channel
-    const int tb4 = (blockIdx.x % blocks_per_row) * 4 + wv; // pooled time index
-    const int unit = row >> 1, ch = row & 1;
-    const float* y = p.x + (size_t)row * p.len;
+// stand-alone spectrogram: 512 threads = 8 waves = {ear 0, ear 1} x 4 consecutive pooled time blocks of one unit.
+// (Ablation of the previous one-wave-per-block layout, profiles/r1/NOTES.md: 58 of 200 us were the per-lane frame
+// loads from global with their padding logic, 29 us the scattered 4-byte stores, 17 us all of the math.)
+//   1. the 16 frames of the group span 2912 samples per ear: both segments are staged in LDS by coalesced loads, with
+//      librosa's centre padding (reflect / zeros) resolved once per sample instead of once per frame lane;
+//   2. every wave pulls its 4 frames from LDS into registers (always the branch-free path), then the staging area is
+//      dead and is overlaid by the per-wave STFT scratch;
+//   3. the 65 x (4 blocks x 2 ears) results are collected in LDS and written as contiguous 32-byte runs of the
+//      channel-last output instead of 4-byte scatters.
+constexpr int kSegFrames = 16, kSegLen = kHop * (kSegFrames - 1) + kNfft;     // 2912 samples
+constexpr int kSegQuads = kSegLen / 4;                                         // 728 float4 per ear
+
+// the (up to) 3 float4 of the two-ear segment of group g that thread t stages: quad e4 = t + 512 k
+__device__ __forceinline__ void spec_seg_load(const SpecParams& p, const float* row0, int g, int t, f32x4 (&r)[3]) {
+    const int s0 = kHop * kSegFrames * g - kNfft / 2;
+    const bool vec_ok = !(p.len & 3) && !(reinterpret_cast<size_t>(row0) & 15);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e4 = t + 512 * k;
+        const int c = e4 >= kSegQuads, n = s0 + 4 * (e4 - c * kSegQuads);
+        const float* row = row0 + (size_t)c * p.len;
+        if (e4 >= 2 * kSegQuads) {
+            r[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (vec_ok && n >= 0 && n + 4 <= p.len) {
+            r[k] = *reinterpret_cast<const f32x4*>(row + n);
+        } else {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                   // librosa centre padding, resolved once per sample
+                int i = n + u;
+                if (p.pad_mode == 0) { i = i < 0 ? -i : i; i = i >= p.len ? 2 * (p.len - 1) - i : i; }
+                const bool ok = i >= 0 && i < p.len;
+                const float q = row[ok ? i : 0];
+                v[u] = ok ? q : 0.f;
+            }
+            r[k] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
+    __shared__ c32 sc[8 * kWaveScratch];                    // 69632 B: staging (2 x 2912 floats), then 8 wave scratches
+    __shared__ float res[kBins4 * 8];                       // [65][4 blocks][2 ears]
+    __shared__ float s_win[kNfft];
+    __shared__ c32 s_tw512[256];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int groups = (p.t4 + 3) >> 2, chunks = (groups + p.gpw - 1) / p.gpw;
+    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
+    const int ch = wv >> 2, tbl = wv & 3;                   // this wave: ear, local pooled block
+    const float* row0 = p.x + (size_t)unit * 2 * p.len;
+    f32x4* seg4 = reinterpret_cast<f32x4*>(sc);             // seg[c][i] = padded y_c[160*16*g - 256 + i]
+    const float* seg = reinterpret_cast<const float*>(sc);
+    f32x4 r[3];
+    spec_seg_load(p, row0, g0, t, r);
+    s_win[t] = p.tb.win[t];
+    if (t < 256) s_tw512[t] = p.tb.tw512[t];
     const c32 wq = p.tb.twM[64 * (lane & 15)];
-    c32 x[16];
-    // tb4 >= t4 (tail waves): all frames invalid -> zeros, nothing stored
-    stft_load(y, p.len, 4 * tb4 + (lane >> 4), tb4 < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, p.tb.win, x);
-    float* o = p.out + (size_t)unit * kBins4 * p.t4 * 2;
-    if (tb4 < p.t4)
-        stft_block(sc + wv * kWaveScratch, lane, wq, p.tb.tw512, x, [&](int b, float v) { o[(b * p.t4 + tb4) * 2 + ch] = v; });
+    for (int g = g0; g < g1; ++g) {
+        // the barrier at the end of the previous round made the scratch (and res) dead
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (t + 512 * k < 2 * kSegQuads) seg4[t + 512 * k] = r[k];
+        lds_barrier();
+        const int tb4 = 4 * g + tbl, fl = 4 * tbl + (lane >> 4);
+        const bool live = tb4 < p.t4 && kSegFrames * g + fl < p.n_frames;
+        c32 x[16];
+        {   // frame fl of the segment starts at seg[160*fl], padding already resolved: always the aligned path
+            const c32* y2 = reinterpret_cast<const c32*>(seg + ch * kSegLen + kHop * fl) + (lane & 15);
+            const c32* w2 = reinterpret_cast<const c32*>(s_win) + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const c32 s = y2[16 * j], w = w2[16 * j];
+                x[j] = live ? mk2(w.x * s.x, w.y * s.y) : mk2(0.f, 0.f);
+            }
+        }
+        lds_barrier();                                      // staging area dead: scratch may overlay it
+        if (g + 1 < g1) spec_seg_load(p, row0, g + 1, t, r);   // next segment in flight under this round's math
+        if (tb4 < p.t4)
+            stft_block(sc + wv * kWaveScratch, lane, wq, s_tw512, x, [&](int b, float v) { res[b * 8 + tbl * 2 + ch] = v; });
+        lds_barrier();
+        if (t < kBins4 * 4) {                               // 65 rows x 4 (block, ear-pair) float2 = 32-byte runs
+            const int b = t >> 2, c2 = t & 3;
+            if (4 * g + c2 < p.t4)
+                *reinterpret_cast<c32*>(p.out + ((size_t)unit * kBins4 + b) * p.t4 * 2 + 8 * g + 2 * c2) =
+                    *reinterpret_cast<const c32*>(res + 8 * b + 2 * c2);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

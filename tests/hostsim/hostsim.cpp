@@ -135,15 +135,17 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     return 0;
 }
 
-int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mode) {
+int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mode, int gpw) {
     ssk::SpecParams p;
     p.x = x; p.out = out; p.tb = host_tables();
     p.len = len; p.n_frames = 1 + len / ssk::kHop; p.t4 = (p.n_frames + 3) / 4; p.pad_mode = pad_mode;
-    const int bpr = (p.t4 + 3) / 4;
-    gridDim = dim3{(unsigned)(2 * n_units * bpr), 1, 1};
-    for (int b = 0; b < 2 * n_units * bpr; ++b) {
+    const int groups = (p.t4 + 3) / 4;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    gridDim = dim3{(unsigned)(n_units * chunks), 1, 1};
+    for (int b = 0; b < n_units * chunks; ++b) {
         blockIdx = dim3{(unsigned)b, 0, 0};
-        int rc = run_block(256, [&] { ssk::k_spectrogram(p); });
+        int rc = run_block(512, [&] { ssk::k_spectrogram(p); });
         if (rc) return rc;
     }
     return 0;

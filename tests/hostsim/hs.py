@@ -86,17 +86,17 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
                    N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode)
     assert rc == 0, rc
     if want_spectrogram and not fuse:
-        rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode)
+        rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
         assert rc == 0, rc
     return out, (sg if (fuse or want_spectrogram) else None)
 
 
-def spectrogram(x, pad_mode=0):
+def spectrogram(x, pad_mode=0, gpw=1):
     L = lib()
     x = np.ascontiguousarray(x, np.float32)
     N, _, n = x.shape
     sg = np.full((N, 65, P.spectrogram_shape(n)[1], 2), np.nan, np.float32)
-    rc = L.hs_spectrogram(_p(x, ctypes.c_float), _p(sg, ctypes.c_float), N, n, pad_mode)
+    rc = L.hs_spectrogram(_p(x, ctypes.c_float), _p(sg, ctypes.c_float), N, n, pad_mode, gpw)
     assert rc == 0, rc
     return sg
 

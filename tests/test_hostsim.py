@@ -145,6 +145,19 @@ def test_spectrogram_kernel_pad_modes_and_edges():
     assert hs.spectrogram(np.ones((1, 2, 16000), np.float32)).shape == (1, 65, 26, 2)   # nav.py:77 KAT
 
 
+@pytest.mark.parametrize("n,gpw", [(16000, 3), (16000, 7), (44100, 4), (15999, 2), (4801, 1), (257, 1), (7919, 9)])
+def test_spectrogram_kernel_chunked_rounds_and_odd_lengths(n, gpw):
+    # one workgroup walks `gpw` groups of 4 pooled blocks (prefetching the next segment); odd lengths take the
+    # scalar staging path, short rows have reflect padding on both sides inside one segment
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((2, 2, n)).astype(np.float32)
+    for pm, name in ((0, "reflect"), (1, "constant")):
+        got = hs.spectrogram(x, pad_mode=pm, gpw=gpw)
+        assert got.shape[1:] == (65,) + (P.spectrogram_shape(n)[1], 2)
+        for k in range(2):
+            check(got[k], O.compute_spectrogram(x[k], pad_mode=name))
+
+
 def test_window_planning():
     # 1-s clip at 16 kHz: only m = 0 is non-zero
     ws = P.plan_window_set(16000, 0, 1, 1)
