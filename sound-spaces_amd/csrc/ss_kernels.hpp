@@ -21,8 +21,18 @@ __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b
 
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
 constexpr int kNfft = 512, kHop = 160, kPool = 4, kBins4 = 65;   // 257 bins -> 65 pooled rows
-constexpr int kWaveScratch = 1088;        // complex per wave: 4 frames x 272
-constexpr int kFrameStride = 272;         // 16 x 17 (transpose tile) and >= 257 (natural-order spectrum)
+constexpr int kFrameStride = 272;         // transpose tiles (16 x 17 complex per frame); = 16 mod 32 so that the four
+                                          // frames of a wave start 32 banks apart (ds_read/write_b64 rules)
+constexpr int kNatStride = 288;           // natural-order spectra per frame; = 0 mod 32 (ds_read_b128 lane groups)
+constexpr int kWaveScratch = 4 * kNatStride;     // complex per wave: 4 frames
+constexpr int kPsStride = 112;            // floats per frame of pooled partial sums (>= 97, = 16 mod 64: bank-disjoint)
+// Natural-order spectrum / tw512 table index: 2 complex (16 B) of padding after every 32.  The magnitude stage reads
+// Z[4b..4b+1], lane = b, as ds_read_b128 at a 32-byte lane stride; unpadded, the 16 lanes of a b128 lane group
+// ({0-3,12-15,20-27}, ... : MI355X_MICROARCH LDS table) hit 8 four-bank groups twice (measured SQ_LDS_BANK_CONFLICT
+// = 16 % of the STFT phase's LDS cycles).  With this padding and kNatStride every b128 group covers all 64 banks once
+// (tests/test_lds_banks.py enumerates it).
+__host__ __device__ constexpr int posN(int k) { return k + 2 * (k >> 5); }
+constexpr int kTw512Lds = posN(255) + 1;  // 270 complex
 
 // Device-resident constant tables (built once per device by the host library, in double precision).
 struct Tables {
@@ -55,7 +65,7 @@ __device__ __forceinline__ void pass1_inv(const c32* lds, c32 wbase, int t, c32 
     c32 x[16];
     const c32* base = lds + t + (t >> 6);
 #pragma unroll
-    for (int a = 0; a < 16; ++a) x[a] = base[1040 * a];
+    for (int a = 0; a < 16; ++a) x[a] = lds_ld(base + 1040 * a);
     c32 w = wbase;
     SSK_OPAQUE2(w);
     twiddle16<true>(x, w);
@@ -151,7 +161,7 @@ __device__ __forceinline__ void stft_load(const float* y, int len, int tf, int n
         const c32* y2 = reinterpret_cast<const c32*>(y + base) + q;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const c32 s = y2[16 * j], w = w2[16 * j];
+            const c32 s = lds_ld(y2 + 16 * j), w = lds_ld(w2 + 16 * j);
             x[j] = mk2(w.x * s.x, w.y * s.y);
         }
     } else {
@@ -160,7 +170,7 @@ __device__ __forceinline__ void stft_load(const float* y, int len, int tf, int n
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int n = base + 2 * (q + 16 * j);
-            const c32 w = w2[16 * j];
+            const c32 w = lds_ld(w2 + 16 * j);
             float sv[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -180,11 +190,12 @@ __device__ __forceinline__ void stft_load(const float* y, int len, int tf, int n
 
 // phase B: everything after the load, for ONE wave: sc = this wave's private scratch (kWaveScratch complex),
 // so all synchronisation is wave-scope (no workgroup barrier).  Pooled log1p values go out through STORE(b, value).
-// wq = exp(-2 pi i q / 256) (= twM[64 q], loaded once by the caller); tw512 = table exp(-2 pi i k / 512) (global or LDS).
+// wq = exp(-2 pi i q / 256) (= twM[64 q], loaded once by the caller); tw512 = LDS copy of the table exp(-2 pi i k / 512), entry k at posN(k).
 template <class STORE>
 __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32* tw512, c32 (&x)[16], STORE store) {
     const int f = lane >> 4, q = lane & 15;
-    c32* fr = sc + f * kFrameStride;
+    c32* fr = sc + f * kFrameStride;        // transpose tile of this frame
+    c32* fn = sc + f * kNatStride;          // natural-order spectrum of this frame (after the second pass)
     // 256-point FFT of the packed frame: pass 1 over j (stride 16), twiddle w256^(q r), transpose, pass 2 over q
     fft16<false>(x);
     SSK_OPAQUE2(wq);
@@ -193,31 +204,39 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
     for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = fr[q * 17 + r];
+    for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
     fft16<false>(x);                         // x[s] = Z[q + 16 s]
     wave_sync();
 #pragma unroll
-    for (int s = 0; s < 16; ++s) fr[q + 16 * s] = x[s];
-    if (q == 0) fr[256] = x[0];              // Z[256] == Z[0]
+    for (int s = 0; s < 16; ++s) fn[q + posN(16 * s)] = x[s];   // posN(q + 16 s) = q + posN(16 s)
     wave_sync();
     // |rFFT_512| pooled over 4 bins.  Bins come in Hermitian pairs (k, 256-k) that share P, Q and w*Q, so a lane
     // takes the pooled rows b = q and q+16 (bins 4b..4b+3 < 128) together with their mirror bins 256-4b-e:
     //   D[b]    = sum_e |X[4b+e]|                      -> row b
     //   M0[b]   = |X[256-4b]|                           -> row 64-b
     //   M123[b] = sum_{e=1..3} |X[256-4b-e]|            -> row 63-b          (+ |X[128]| = |Z[128]| for row 32)
-    float* ps = reinterpret_cast<float*>(sc);           // per frame: D[32] | M0[32] | M123[32] | X128 ; stride 100
+    float* ps = reinterpret_cast<float*>(sc);           // per frame: D[32] | M0[32] | M123[32] | X128 ; stride kPsStride
     float dsum[2], m0[2], m123[2];
+    // Z[256-4b], the mirror of Z[4b], sits just above this lane's aligned mirror quad: it is the previous lane's
+    // Z[252-4(b-1)], fetched by DPP (a direct LDS read at this lane stride would be 4-way bank conflicted)
+    f32x4 k01[2], k23[2], p01[2], p23[2], w01[2], w23[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int b = q + 16 * i;
-        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fr + 4 * b);          // Z[4b .. 4b+3]
-        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fr + 252 - 4 * b);    // Z[252-4b .. 255-4b]
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(tw512 + 4 * b);
-        const f32x4 k01 = zk4[0], k23 = zk4[1], p01 = zp4[0], p23 = zp4[1], w01 = w4[0], w23 = w4[1];
-        const c32 ptop = fr[256 - 4 * b];
-        const c32 zk[4] = {k01.xy, k01.zw, k23.xy, k23.zw};
-        const c32 zp[4] = {ptop, p23.zw, p23.xy, p01.zw};
-        const c32 ww[4] = {w01.xy, w01.zw, w23.xy, w23.zw};
+        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fn + posN(4 * b));          // Z[4b .. 4b+3]
+        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fn + posN(252 - 4 * b));    // Z[252-4b .. 255-4b]
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(tw512 + posN(4 * b));
+        k01[i] = zk4[0]; k23[i] = zk4[1]; p01[i] = zp4[0]; p23[i] = zp4[1]; w01[i] = w4[0]; w23[i] = w4[1];
+    }
+    const c32 prev0 = mk2(row_ror1(p01[0].x, lane), row_ror1(p01[0].y, lane));         // lane q-1 (15 for q = 0), i = 0
+    const c32 prev1 = mk2(row_ror1(p01[1].x, lane), row_ror1(p01[1].y, lane));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // b = 0: Z[256] = Z[0];  b = 16 (q = 0, i = 1): Z[192] is lane 15's i = 0 quad start
+        const c32 ptop = i == 0 ? (q == 0 ? k01[0].xy : prev0) : (q == 0 ? prev0 : prev1);
+        const c32 zk[4] = {k01[i].xy, k01[i].zw, k23[i].xy, k23[i].zw};
+        const c32 zp[4] = {ptop, p23[i].zw, p23[i].xy, p01[i].zw};
+        const c32 ww[4] = {w01[i].xy, w01[i].zw, w23[i].xy, w23[i].zw};
         float d = 0.f, m = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -232,21 +251,21 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
         m123[i] = 0.5f * m;
     }
     float x128 = 0.f;
-    if (q == 0) { const c32 z = fr[128]; x128 = fast_sqrt(z.x * z.x + z.y * z.y); }
+    if (q == 0) { const c32 z = fn[posN(128)]; x128 = fast_sqrt(z.x * z.x + z.y * z.y); }
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        ps[f * 100 + q + 16 * i] = dsum[i];
-        ps[f * 100 + 32 + q + 16 * i] = m0[i];
-        ps[f * 100 + 64 + q + 16 * i] = m123[i];
+        ps[f * kPsStride + q + 16 * i] = dsum[i];
+        ps[f * kPsStride + 32 + q + 16 * i] = m0[i];
+        ps[f * kPsStride + 64 + q + 16 * i] = m123[i];
     }
-    if (q == 0) ps[f * 100 + 96] = x128;
+    if (q == 0) ps[f * kPsStride + 96] = x128;
     wave_sync();
     for (int r = lane; r < kBins4; r += 64) {
         float v = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float* pf = ps + g * 100;
+            const float* pf = ps + g * kPsStride;
             if (r < 32) v += pf[r];
             else if (r == 32) v += pf[64 + 31] + pf[96];
             else if (r < 64) v += pf[64 + 63 - r] + pf[32 + 64 - r];
@@ -305,10 +324,10 @@ __device__ __forceinline__ void spec_seg_load(const SpecParams& p, const float* 
 }
 
 __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
-    __shared__ c32 sc[8 * kWaveScratch];                    // 69632 B: staging (2 x 2912 floats), then 8 wave scratches
+    __shared__ c32 sc[8 * kWaveScratch];                    // 73728 B: staging (2 x 2912 floats), then 8 wave scratches
     __shared__ float res[kBins4 * 8];                       // [65][4 blocks][2 ears]
     __shared__ float s_win[kNfft];
-    __shared__ c32 s_tw512[256];
+    __shared__ c32 s_tw512[kTw512Lds];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int groups = (p.t4 + 3) >> 2, chunks = (groups + p.gpw - 1) / p.gpw;
     const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
@@ -319,7 +338,7 @@ __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
     f32x4 r[3];
     spec_seg_load(p, row0, g0, t, r);
     s_win[t] = p.tb.win[t];
-    if (t < 256) s_tw512[t] = p.tb.tw512[t];
+    if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
     const c32 wq = p.tb.twM[64 * (lane & 15)];
     for (int g = g0; g < g1; ++g) {
         // the barrier at the end of the previous round made the scratch (and res) dead
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
             const c32* w2 = reinterpret_cast<const c32*>(s_win) + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const c32 s = y2[16 * j], w = w2[16 * j];
+                const c32 s = lds_ld(y2 + 16 * j), w = lds_ld(w2 + 16 * j);
                 x[j] = live ? mk2(w.x * s.x, w.y * s.y) : mk2(0.f, 0.f);
             }
         }
@@ -531,7 +550,7 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
 // so a unit is at most ONE forward FFT: straight-line code, no accumulator carried across passes, no scratch.
 template <bool FUSE, bool SIMPLE>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
-    __shared__ c32 lds[kLdsComplex];
+    __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
     const int unit = blockIdx.x >> 1, ch = blockIdx.x & 1, j = SIMPLE ? 0 : blockIdx.y;
     const int* d = p.desc + 8 * unit;
@@ -539,11 +558,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     // fused path: the STFT's window and exp(-2 pi i k/512) tables are staged in the 21 KiB of LDS the FFT buffer
     // leaves free, and the lane's 256-point twiddle is fetched now, so the STFT phase starts no global loads
     __shared__ float s_win[FUSE ? kNfft : 1];
-    __shared__ c32 s_tw512[FUSE ? 256 : 1];
+    __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
     c32 wq = mk2(1.f, 0.f);
     if (FUSE) {
         if (t < kNfft) s_win[t] = p.tb.win[t];
-        if (t < 256) s_tw512[t] = p.tb.tw512[t];
+        if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
         wq = p.tb.twM[64 * (t & 15)];
     }
 

@@ -21,6 +21,7 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 void hostsim_syncthreads();
 void hostsim_wave_sync();
+float hostsim_lane_read(float v, int src_lane);   // value of `v` held by lane src_lane of the caller's wave
 #define __syncthreads() hostsim_syncthreads()
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline int min(int a, int b) { return a < b ? a : b; }

@@ -95,6 +95,15 @@ ssk::Tables host_tables() {
 
 void hostsim_syncthreads() { barrier_wait(g_block_barrier, g_nthreads); }
 void hostsim_wave_sync() { barrier_wait(g_wave_barrier[g_cur / 64], 64); }
+static float g_xch[16][64];
+float hostsim_lane_read(float v, int src_lane) {
+    const int w = g_cur / 64;
+    g_xch[w][g_cur % 64] = v;
+    hostsim_wave_sync();
+    const float r = g_xch[w][src_lane];
+    hostsim_wave_sync();
+    return r;
+}
 
 extern "C" {
 
