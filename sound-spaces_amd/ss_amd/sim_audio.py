@@ -154,3 +154,14 @@ class VectorAudioObserver:
         units = [b.unit_request() for b in self.backends]
         return self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
                                    want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+
+    def observe_into(self, rollouts):
+        """Render this vector step straight into the rollout rows the next `rollouts.insert()` fills
+        (`observations[sensor][step + 1]`, ss_baselines/common/rollout_storage.py:89-92): no per-env arrays, no
+        `batch_obs` stack, no H2D copy.  `rollouts` is an `ss_amd.rollout.RolloutStorage`; returns the slots
+        (a `DeviceObservations`) to be merged with the other sensors' batch and passed to `insert()`, which
+        recognises them and skips the copy."""
+        names = [s for s in ("spectrogram", "audiogoal") if s in rollouts.observations]
+        slots = rollouts.next_observation_slots(names)
+        self.observe(spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
+        return slots

@@ -87,8 +87,15 @@ class OracleEngine:
             ag.append(a.astype(np.float32))
             sg.append(O.compute_spectrogram(a.astype(np.float32)).astype(np.float32))
         out = {}
-        if want_audiogoal or not want_spectrogram:
-            out["audiogoal"] = torch.from_numpy(np.stack(ag))
+
+        def place(dst, arr):                     # like the real engine: fill the caller's tensor when one is given
+            t = torch.from_numpy(np.stack(arr))
+            if dst is None:
+                return t
+            dst.copy_(t)
+            return dst
+        if want_audiogoal or audiogoal_out is not None or not want_spectrogram:
+            out["audiogoal"] = place(audiogoal_out, ag)
         if want_spectrogram:
-            out["spectrogram"] = torch.from_numpy(np.stack(sg))
+            out["spectrogram"] = place(spectrogram_out, sg)
         return out

@@ -120,6 +120,21 @@ def test_vector_observer_batches_all_envs_in_one_launch():
     assert tuple(obs["spectrogram"].shape) == (5, 65, 26, 2) and tuple(obs["audiogoal"].shape) == (5, 2, SR)
     assert not obs["spectrogram"][2].any() and obs["spectrogram"][0].any()
     assert torch.equal(obs["spectrogram"][0], obs["spectrogram"][1])
+    # the same step rendered straight into a rollout: insert() sees its own rows and does not copy
+    from ss_amd.rollout import RolloutStorage
+    import types
+    space = types.SimpleNamespace(spaces={"spectrogram": types.SimpleNamespace(shape=(65, 26, 2)),
+                                          "audiogoal": types.SimpleNamespace(shape=(2, SR))})
+
+    class ActionSpace:
+        pass
+    rs = RolloutStorage(2, 5, space, ActionSpace(), 3)
+    slots = sim_audio.VectorAudioObserver(eng, backends).observe_into(rs)
+    assert slots["spectrogram"].data_ptr() == rs.observations["spectrogram"][1].data_ptr()
+    z = torch.zeros(5, 1)
+    rs.insert(slots, torch.zeros(1, 5, 3), z.long(), z, z, z, torch.ones(5, 1))
+    assert torch.equal(rs.observations["spectrogram"][1], obs["spectrogram"])
+    assert torch.equal(rs.observations["audiogoal"][1], obs["audiogoal"]) and rs.step == 1
 
 
 def test_rir_store_lru_and_refresh():
