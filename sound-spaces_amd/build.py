@@ -28,8 +28,32 @@ def build(force=False, verbose=True):
     cmd = [hipcc] + FLAGS + ["ss_hip.hip", "-o", SO]
     if verbose:
         print("[ss_amd] " + " ".join(cmd), flush=True)
-    subprocess.check_call(cmd, cwd=CSRC)
+    tmp_so = SO + ".tmp"
+    subprocess.check_call(cmd[:-1] + [tmp_so], cwd=CSRC)
+    guard_isa(hipcc, verbose)
+    os.replace(tmp_so, SO)
     return SO
+
+
+def guard_isa(hipcc, verbose=True):
+    """k_conv_rows issues its RIR prefetch with inline-asm loads the compiler cannot see as asynchronous; check in the
+    generated ISA that nothing reads or writes their destination registers before the wait that retires them
+    (scripts/check_prefetch_regs.py), and that no kernel spills VGPRs.  A violation fails the build."""
+    import re
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "scripts"))
+    import check_prefetch_regs
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "ss_hip.s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-Wno-unused-command-line-argument", "ss_hip.hip", "-o", asm], cwd=CSRC)
+        if check_prefetch_regs.check(asm, verbose=verbose):
+            raise RuntimeError("k_conv_rows: prefetch destination registers are touched while the loads are in flight")
+        text = open(asm).read()
+        spills = [(n, int(v)) for n, v in re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)]
+        bad = [(n, v) for n, v in spills if v]
+        if bad:
+            raise RuntimeError(f"VGPR spills: {bad}")
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 // ss_hip.hip — host side of libss_hip.so: table construction and kernel launches (gfx950 only).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -14,13 +15,14 @@ constexpr int kMaxDevices = 64;
 struct DeviceTables {
     bool ready = false;
     ssk::Tables tb{};
+    int n_cus = 0;
 };
 DeviceTables g_tables[kMaxDevices];
 std::mutex g_mu;
 
 inline int hip_err(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
 
-int get_tables(ssk::Tables* out) {
+int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_err(e);
@@ -38,9 +40,14 @@ int get_tables(ssk::Tables* out) {
         d.tb.twItem = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwItemOff);
         d.tb.tw512 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTw512Off);
         d.tb.win = dev_buf + ssk_host::kWinOff;
+        int cus = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);   // slow call: once per device
+        if (e != hipSuccess) { (void)hipFree(dev_buf); return hip_err(e); }
+        d.n_cus = cus > 0 ? cus : 1;
         d.ready = true;
     }
     *out = d.tb;
+    if (n_cus) *n_cus = d.n_cus;
     return 0;
 }
 
@@ -48,10 +55,20 @@ inline int n_frames_of(int len) { return 1 + len / ssk::kHop; }
 inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kPool; }
 
 template <bool FUSE>
-int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, hipStream_t st) {
+int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.rir_cap <= ssk::kB;
     const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
+    // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
+    const bool planar = p.rir_elem_stride == 1 && !(p.rir_cap & 1) && !(reinterpret_cast<size_t>(p.rir) & 7) &&
+                        !(p.rir_unit_stride & 1) && !(p.rir_chan_stride & 1) && p.rir_cap >= 2;
+    static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
+    if constexpr (!FUSE) {              // the fused kernel gains nothing from it (measured), see k_conv_rows
+        if (simple && planar && !no_rows && 2 * n_units > n_cus) {
+            hipLaunchKernelGGL(ssk::k_conv_rows, dim3(n_cus), block, 0, st, p, 2 * n_units);
+            return hip_err(hipGetLastError());
+        }
+    }
     if (simple) hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
@@ -84,12 +101,12 @@ int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out
     return hip_err(hipGetLastError());
 }
 
-static int fill_conv(ssk::ConvParams& p, const float* spec, const float* rir, const int* rir_len,
+static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const float* rir, const int* rir_len,
                      const int* unit_desc, long long us, int cs, int es, int cap, int n_valid, int out_len) {
     if (!spec || !rir || !rir_len || !unit_desc) return SS_EINVAL;
     if (n_valid < 0 || out_len <= 0 || n_valid > out_len || n_valid > 3 * ssk::kB) return SS_EINVAL;
     if (es < 1 || cs < 0 || us < 0 || cap < 0) return SS_EINVAL;
-    int rc = get_tables(&p.tb);
+    int rc = get_tables(&p.tb, n_cus);
     if (rc) return rc;
     p.spec = reinterpret_cast<const ssk::f32x4*>(spec);
     p.rir = rir;
@@ -115,12 +132,13 @@ int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_
     if (n_units == 0) return 0;
     if (!out || n_units < 0) return SS_EINVAL;
     ssk::ConvParams p;
-    int rc = fill_conv(p, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
+    int n_cus = 1;
+    int rc = fill_conv(p, &n_cus, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
                        rir_cap, n_valid, out_len);
     if (rc) return rc;
     p.out = out;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
-    return launch_conv<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream));
+    return launch_conv<false>(p, n_units, nb_y, flags, n_cus, static_cast<hipStream_t>(stream));
 }
 
 int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream) {
@@ -156,14 +174,15 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
     if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
     if (out_len < ssk::kNfft / 2 + 1) return SS_EINVAL;
     ssk::ConvParams p;
-    int rc = fill_conv(p, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
+    int n_cus = 1;
+    int rc = fill_conv(p, &n_cus, spec, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
                        rir_cap, n_valid, out_len);
     if (rc) return rc;
     p.pad_mode = pad_mode;
     if (out_len <= ssk::kB && p.t4 <= 26) {             // fused: waveform stays in LDS
         p.out = audiogoal;
         p.sgram = spectrogram;
-        return launch_conv<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
+        return launch_conv<true>(p, n_units, 1, flags, n_cus, static_cast<hipStream_t>(stream));
     }
     if (!audiogoal) return SS_EINVAL;                   // long rows hand over through HBM/L2
     rc = ss_fftconv_binaural_f32(spec, rir, rir_len, unit_desc, audiogoal, n_units, rir_unit_stride,

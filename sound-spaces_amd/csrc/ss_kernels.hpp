@@ -470,8 +470,8 @@ __device__ __forceinline__ void multiply_item(c32* lds, c32 wg, int t, int s, co
     item_store_inv(lds, wg, t + 1024 * s, v);
 }
 
-__device__ __forceinline__ void simple_row_after_pass1(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, int slot,
-                                                       c32 (&y)[8]) {
+// forward half: passes 2-3 and the in-place item stage (LDS ends up holding the product spectrum in layout B)
+__device__ __forceinline__ void simple_row_fwd(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, int slot) {
     const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
     lds_barrier();
     pass2<false>(lds, tw.p2, t);
@@ -485,12 +485,22 @@ __device__ __forceinline__ void simple_row_after_pass1(c32* lds, const ConvParam
     for (int hh = 0; hh < 4; ++hh) sv1[hh] = sp[(4 + hh) * 1024];
     multiply_item(lds, tw.i0, t, 0, sv0);
     multiply_item(lds, tw.i1, t, 1, sv1);
+}
+
+// inverse half: passes 3'-2'-1' -> the row's last kB samples in registers
+__device__ __forceinline__ void simple_row_inv(c32* lds, const ThreadTw& tw, int t, c32 (&y)[8]) {
     lds_barrier();
     pass3_inv(lds, t);
     lds_barrier();
     pass2<true>(lds, tw.p2, t);
     lds_barrier();
     pass1_inv(lds, tw.p1, t, y);
+}
+
+__device__ __forceinline__ void simple_row_after_pass1(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, int slot,
+                                                       c32 (&y)[8]) {
+    simple_row_fwd(lds, p, tw, t, slot);
+    simple_row_inv(lds, tw, t, y);
 }
 
 // write one output block (kB samples starting at j*kB) of row `row`; block 0 also zero-fills [n_valid, out_len)
@@ -637,6 +647,128 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     }
     store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
     if (FUSE) fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_rows: the SIMPLE case as a PERSISTENT kernel for launches with more (unit, ear) rows than CUs.
+// One workgroup owns a CU (139 KB of LDS) and walks rows blockIdx.x, + gridDim.x, ...  With one workgroup per row
+// (k_conv) a CU's time line is load RIR (HBM latency, nothing to compute) -> 7 FFT passes (no memory traffic) ->
+// store, strictly serial because a second workgroup does not fit beside the first (ablation, profiles/r1/NOTES.md:
+// 303 us = 203 compute + ~100 exposed IO at 2048 units).  Here the NEXT row's RIR is loaded into 16 registers as
+// soon as pass 1 has consumed the current one, so its HBM latency runs under passes 2-3 and the item stage, and the
+// current row's stores drain under the next row's pass 1.
+// gfx9 has ONE in-order counter (vmcnt) for loads AND stores, so the order of issue is part of the design:
+//   * the row descriptors come through the scalar cache (s_load, lgkmcnt): a vector load here would have to wait
+//     for the previous row's freshly issued stores;
+//   * prefetch loads are issued before the window-spectrum loads; the wait for the latter (vmcnt(0) at the second
+//     item, long after) therefore retires them too and nothing is pending on the RIR registers at the back edge;
+//   * the prologue load is waited for explicitly before the loop (otherwise the merged loop-header state would make
+//     the compiler wait at the top of EVERY iteration, i.e. for the stores just issued).
+// Preconditions checked by the launcher: planar bank rows (elem stride 1), even capacity <= kB, 8-byte aligned rows.
+struct RowInfo { int active, slot; const c32* h2; };
+
+__device__ __forceinline__ int uniform_load(const int* ptr) {      // wave-uniform address -> scalar cache
+#if defined(__HIP_DEVICE_COMPILE__)
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+#else
+    return *ptr;
+#endif
+}
+
+__device__ __forceinline__ RowInfo row_info(const ConvParams& p, int row) {
+    const int* d = p.desc + 8 * (row >> 1);
+    RowInfo r{0, 0, reinterpret_cast<const c32*>(p.rir)};      // inactive: a valid address for the dummy prefetch
+    const int ridx = uniform_load(d);
+    if (ridx < 0) return r;
+    const int L = uniform_load(p.rir_len + ridx);
+    const int spec0 = uniform_load(d + 1), m_min = uniform_load(d + 2), m_cnt = uniform_load(d + 3);
+    if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
+        r.active = 1;
+        r.slot = spec0 - m_min;
+        r.h2 = reinterpret_cast<const c32*>(p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)(row & 1) * p.rir_chan_stride);
+    }
+    return r;
+}
+
+// Issue the loads of the row's packed sample pairs t + 1024 a, a < 8, WITHOUT waiting for them.  Inline asm on
+// purpose: (1) the compiler turns the clamped-address form back into eight predicated branches, and (2) it guards the
+// destination registers with s_waitcnt vmcnt(0), which on gfx9 also waits for the previous row's freshly issued
+// stores.  The registers must not be touched until row_rir_wait(); out-of-row lanes load pair 0 and are zeroed there.
+__device__ __forceinline__ void row_rir_issue(const ConvParams& p, const RowInfo& r, int t, c32 (&h)[8]) {
+    const int m_end = p.rir_cap >> 1;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int m = t + 1024 * a;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned off = m < m_end ? 8u * (unsigned)m : 0u;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(h[a]) : "v"(off), "s"(r.h2) : "memory");
+#else
+        h[a] = r.h2[m < m_end ? m : 0];
+#endif
+    }
+}
+
+__device__ __forceinline__ void row_rir_wait(const ConvParams& p, int active, int t, c32 (&h)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // every VMEM operation of this wave retired.  The wait carries no register operands: tied operands may be
+    // realised as copies placed BEFORE the statement, i.e. reads of registers whose loads are still in flight.  The
+    // second statement makes the compiler treat the registers as produced here (no use can move above it).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]));
+#endif
+    const int m_end = active ? p.rir_cap >> 1 : 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) h[a] = (t + 1024 * a < m_end) ? h[a] : mk2(0.f, 0.f);
+}
+
+// Conv-only: for the fused kernel the same scheme was measured and rejected (profiles/r1/NOTES.md) - its STFT phase
+// has no 16 registers to spare (20 spills, +7 %), and an L2-only prefetch (dummy loads, real loads at the top of the
+// next row) gained nothing (-1 % at 2048 units, +3 % at 512).
+__global__ __launch_bounds__(1024) void k_conv_rows(ConvParams p, int n_rows) {
+    __shared__ c32 lds[kLdsComplex];
+    const int t = threadIdx.x;
+    ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    int row = blockIdx.x;
+    RowInfo cur = row_info(p, row);
+    c32 h[8];
+    row_rir_issue(p, cur, t, h);                            // unconditional, like the one in the loop
+    row_rir_wait(p, cur.active, t, h);
+    // nothing the compiler tracks may still be pending when the loop starts: its merged loop-header state would
+    // otherwise put a partial s_waitcnt vmcnt(n) for these table loads inside the body, where it would (the count
+    // being in-order) also wait for the prefetch loads the compiler does not know about
+    SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1);
+    for (;;) {
+        int tl = t;
+        SSK_OPAQUE1(tl);                                    // see k_conv: keeps LICM from hoisting the body's addresses
+        const int nxt = row + (int)gridDim.x;
+        if (cur.active) pass1_fwd<true>(lds, tw.p1, tl, [&](int m) { return h[(m - tl) >> 10]; });
+        RowInfo nx{0, 0, reinterpret_cast<const c32*>(p.rir)};
+        if (nxt < n_rows) nx = row_info(p, nxt);
+        if (cur.active) simple_row_fwd(lds, p, tw, tl, cur.slot);
+        // The prefetch goes out AFTER the last window-spectrum load of this row has been waited for: the counter is
+        // in-order, so HBM loads issued earlier would sit in front of those L2 hits and every partial
+        // s_waitcnt vmcnt(n) the compiler emits for them (n computed without these loads) would wait for the prefetch
+        // (measured: issued right after pass 1, -3 %; here, -8 %).  From here it has the three inverse passes
+        // (~4 us) to arrive.  ONE issue site, executed unconditionally (an inactive next row reads pair 0 of the bank
+        // and is zeroed at the wait): two sites would meet in a register merge, i.e. copies of registers whose loads
+        // are still in flight.
+        row_rir_issue(p, nx, tl, h);
+        c32 y[8];
+        if (cur.active) simple_row_inv(lds, tw, tl, y);
+        else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+        }
+        // retire the prefetch BEFORE this row's stores are issued: one in-order counter serves loads and stores
+        row_rir_wait(p, nx.active, tl, h);
+        store_row_block(p, tl, (size_t)row, 0, y);
+        if (nxt >= n_rows) break;
+        row = nxt;
+        cur = nx;
+        lds_barrier();                                      // every wave is done with the LDS buffer of this row
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

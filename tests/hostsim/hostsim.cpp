@@ -120,7 +120,8 @@ int hs_source_windows(const float* src, const int* desc, float* spec, int n_wind
 }
 
 int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
-            float* sgram, int n_units, long long us, int cs, int es, int cap, int n_valid, int out_len, int pad_mode) {
+            float* sgram, int n_units, long long us, int cs, int es, int cap, int n_valid, int out_len, int pad_mode,
+            int persist) {
     ssk::ConvParams p;
     p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
     p.out = out; p.sgram = sgram; p.tb = host_tables();
@@ -131,6 +132,18 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.pad_mode = pad_mode;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
+    if (persist > 0) {                                  // k_conv_rows: `persist` workgroups walk the 2*n_units rows
+        if (fuse || !simple || nb_y != 1 || es != 1 || (cap & 1) || cap > ssk::kB) return -2;
+        gridDim = dim3{(unsigned)persist, 1, 1};
+        for (int b = 0; b < persist && b < 2 * n_units; ++b) {
+            blockIdx = dim3{(unsigned)b, 0, 0};
+            int rc = run_block(ssk::kT, [&] {
+                ssk::k_conv_rows(p, 2 * n_units);
+            });
+            if (rc) return rc;
+        }
+        return 0;
+    }
     gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
     for (int j = 0; j < nb_y; ++j)
         for (int b = 0; b < 2 * n_units; ++b) {

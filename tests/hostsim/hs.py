@@ -33,7 +33,7 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True):
+        interleaved=False, simple=True, persist=0):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent).
     Returns (audiogoal [N,2,out_len], spectrogram [N,65,T4,2] or None)."""
@@ -83,7 +83,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     simple = int(simple and not any(u.get("dis_rir", -1) >= 0 for u in units) and cap <= P.KB and nby == 1)
     rc = L.hs_conv(int(fuse), simple, _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
                    _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
-                   N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode)
+                   N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode, persist)
     assert rc == 0, rc
     if want_spectrogram and not fuse:
         rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)

@@ -194,6 +194,44 @@ def test_baseline_configs_vs_oracle(sr, n_units, ragged):
         check(sg[n], cache[key][1])
 
 
+def test_persistent_row_kernel_large_batches():
+    """More (unit, ear) rows than CUs: the AudioGoal-only path switches to the persistent k_conv_rows (next row's RIR
+    prefetched under the inverse passes).  300 units with ragged RIRs, silent units and an empty RIR in the walk;
+    every unit against the oracle, and the whole batch against the fused kernel (one workgroup per row)."""
+    from ss_amd.renderer import UnitRequest
+    sr, n_units = 16000, 300
+    src, rirs, sel_s, sel_r = _random_batch(sr, n_units, 5, 16, seed=3, ragged=True)
+    rirs = list(rirs) + [None]                                     # unreadable file -> zero RIR (simulator.py:619-624)
+    r = make_renderer(sr, list(src), rirs)
+    units = []
+    for n, (s_, h_) in enumerate(zip(sel_s, sel_r)):
+        if n % 37 == 5:
+            units.append(UnitRequest(int(s_), 0, int(h_), silent=True))
+        elif n % 41 == 7:
+            units.append(UnitRequest(int(s_), 0, len(rirs) - 1))
+        else:
+            units.append(UnitRequest(int(s_), 0, int(h_)))
+    plan = r.plan(units)
+    ag = r.render_audiogoal(plan).cpu().numpy()
+    ag_f, _ = r.render(plan, want_audiogoal=True)
+    scale = float(ag_f.abs().max())
+    assert np.abs(ag - ag_f.cpu().numpy()).max() <= 2e-6 * scale
+    cache = {}
+    for n, u in enumerate(units):
+        if u.silent or u.rir == len(rirs) - 1:
+            assert not ag[n].any()
+            continue
+        key = (u.sound, u.rir)
+        if key not in cache:
+            cache[key] = O.compute_audiogoal(src[u.sound], rirs[u.rir], sr)
+        check(ag[n], cache[key])
+    # a 0.25-s SS2.0 step (n_valid = 4000 < out_len) through the same kernel: identical head, tail zero-filled
+    r2 = make_renderer(sr, list(src), rirs, step_time=0.25)
+    ag2 = r2.render_audiogoal(r2.plan(units)).cpu().numpy()
+    assert not ag2[:, :, 4000:].any()
+    np.testing.assert_allclose(ag2[:, :, :4000], ag[:, :, :4000], atol=2e-6 * scale)
+
+
 def test_linearity_and_shift_properties_full_size():
     """Size-independent properties at the 128-env headline size: the path is linear in the RIR and a delayed
     unit impulse RIR returns the delayed source."""

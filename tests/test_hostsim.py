@@ -60,6 +60,28 @@ def test_unfused_equals_fused_and_interleaved_layout():
     np.testing.assert_array_equal(s1, s4)
 
 
+@pytest.mark.parametrize("wgs", [1, 3, 64])
+def test_persistent_row_kernel_equals_one_workgroup_per_row(wgs, fuse=False):
+    # k_conv_rows: `wgs` workgroups walk the rows (prefetching the next row's RIR); silent units and empty RIRs in the
+    # middle of a walk, ragged RIR lengths, a 0.25-s step (n_valid < out_len)
+    rng = np.random.default_rng(7)
+    sr = 16000
+    srcs = O.synth_sources(rng, sr, k=2)
+    bank = np.zeros((4, 2, sr), np.float32)
+    lens = [sr, 5000, 0, 12345]
+    for i, L in enumerate(lens):
+        if L:
+            bank[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
+    units = [dict(sound=0, t0=0, rir=0), dict(rir=-1), dict(sound=1, t0=0, rir=1), dict(sound=0, t0=0, rir=2),
+             dict(sound=1, t0=0, rir=3)]
+    for n_valid in (sr, 4000):
+        a_ref, s_ref = hs.run(srcs, bank, lens, units, n_valid, sr, fuse=fuse, want_spectrogram=True)
+        a, sg = hs.run(srcs, bank, lens, units, n_valid, sr, fuse=fuse, want_spectrogram=True, persist=wgs)
+        np.testing.assert_array_equal(a, a_ref)
+        np.testing.assert_array_equal(sg, s_ref)
+        assert not a[1].any() and not a[3].any() and a[4].any()
+
+
 def test_distractor_silent_and_zero_rir_in_one_batch():
     d = case_inputs("distractor")
     sr = d["sr"]
