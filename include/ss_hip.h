@@ -16,6 +16,7 @@
  *   ss_audio_obs_f32         <- get_current_spectrogram_observation on a cache miss
  *                               (soundspaces/simulator.py:690-701), both stages fused
  *   ss_intensity_f32         <- Intensity.get_observation (ss_baselines/av_wan/avwan_sensors.py:91-100)
+ *   ss_logmel_f32            <- extension, not in the reference (log-mel front end named by the north star)
  *   ss_source_windows_f32    <- the FFT of the source clip that fftconvolve recomputes on every
  *                               call (simulator.py:630) hoisted out and cached per (sound, window)
  *
@@ -84,6 +85,15 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
 /* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
  * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream);
+
+/* EXTENSION (no counterpart in the reference; BASELINE.json north_star "log-mel"): log-mel spectrogram of
+ * x [n_units, 2, len] -> out [n_units, n_mels, 1 + len/160, 2] (channel-last, no pooling):
+ *   out = log( sum_k W[j][k] * |STFT(x)[k]|^2 + eps ), STFT framing exactly as ss_spectrogram_f32.
+ * The filter bank is band-sparse: band j covers bins mel_start[j] .. mel_start[j] + max_len - 1 with weights
+ * mel_w[j*max_len + i] (zero padded).  n_mels <= 128, max_len <= 63, n_mels*max_len <= 4096,
+ * 0 <= mel_start[j] <= 256 (checked by the caller; the kernel reads zeros beyond bin 256). */
+int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode, const int* mel_start,
+                  const float* mel_w, int n_mels, int max_len, float eps, void* stream);
 
 #ifdef __cplusplus
 }

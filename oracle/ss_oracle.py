@@ -358,3 +358,56 @@ def relerr(got, ref):
     den = np.abs(ref).max()
     num = np.abs(np.asarray(got, dtype=np.float64) - ref).max()
     return num / den if den > 0 else num
+
+
+# --------------------------------------------------------------------------
+# EXTENSION (BASELINE.json north_star "log-mel"): NOT in the
+# reference.  There is no reference implementation to pin against ("parity unpinned");
+# this restates the textbook definition with librosa's documented defaults
+# (librosa.filters.mel: Slaney mel scale, htk=False, norm='slaney') on top of the same
+# STFT framing as compute_spectrogram, and is cross-checked in tests against an
+# independent dense construction.
+# --------------------------------------------------------------------------
+
+def hz_to_mel(f):
+    """Slaney (auditory toolbox) mel scale: linear below 1 kHz, logarithmic above."""
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mel = f / f_sp
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mel)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr, n_mels=64, n_fft=N_FFT, fmin=0.0, fmax=None):
+    """Triangular filters [n_mels, 1 + n_fft//2], area-normalised ('slaney')."""
+    fmax = sr / 2.0 if fmax is None else fmax
+    fft_f = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    w = np.zeros((n_mels, fft_f.size))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0.0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w
+
+
+def compute_logmel(audio_data, sr, n_mels=64, eps=1e-6, pad_mode="reflect"):
+    """[2, T] -> log(mel(|STFT|^2) + eps), [n_mels, 1 + T//160, 2] channel-last (no pooling)."""
+    fb = mel_filterbank(sr, n_mels)
+    chans = []
+    for c in range(2):
+        p = np.abs(stft(audio_data[c], pad_mode=pad_mode).astype(np.complex128)) ** 2
+        chans.append(np.log(fb @ p + eps))
+    return np.stack(chans, axis=-1)

@@ -165,6 +165,35 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
     return hip_err(hipGetLastError());
 }
 
+int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode, const int* mel_start,
+                  const float* mel_w, int n_mels, int max_len, float eps, void* stream) {
+    if (n_units == 0) return 0;
+    if (!x || !out || !mel_start || !mel_w || n_units < 0 || len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (n_mels < 1 || n_mels > ssk::kMelMaxBands || max_len < 1 || max_len > ssk::kMelMaxLen ||
+        n_mels * max_len > ssk::kMelTableFloats || !(eps > 0.f))
+        return SS_EINVAL;
+    ssk::MelParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.x = x;
+    p.out = out;
+    p.start = mel_start;
+    p.w = mel_w;
+    p.len = len;
+    p.n_frames = n_frames_of(len);
+    p.pad_mode = pad_mode;
+    p.n_mels = n_mels;
+    p.max_len = max_len;
+    p.eps = eps;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    long long gpw = (long long)n_units * groups / 1024;     // one 111 KB workgroup per CU: ~4 rounds of 256
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    hipLaunchKernelGGL(ssk::k_logmel, dim3(n_units * chunks), dim3(512), 0, static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
                      int rir_chan_stride, int rir_elem_stride, int rir_cap, int n_valid, int out_len,

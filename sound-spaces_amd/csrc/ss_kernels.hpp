@@ -373,6 +373,155 @@ __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_logmel (EXTENSION, not in the reference: SURVEY 8(f) rank 4 / BASELINE north_star "log-mel"):
+//   out[n][j][tf][c] = log( sum_k W[j][k] |STFT_c[k][tf]|^2 + eps ),  same framing / window / padding as k_spectrogram,
+// no pooling.  W comes as a band-sparse table: band j covers bins start[j] .. start[j]+max_len-1 with weights
+// w[j][0..max_len) (zero padded; triangular mel filters are contiguous in k).
+// Same workgroup shape and staging as k_spectrogram (8 waves = 2 ears x 4 blocks of 4 frames, padded segments staged in
+// LDS, next group prefetched).  After the two radix-16 passes the power spectrum of a wave's 4 frames goes to LDS
+// (kPowStride floats per frame, zero tail so that every band can run the same max_len-step loop), lane (f, q)
+// accumulates bands q, q+16, ... of frame f, and the [n_mels][16 frames][2 ears] results of a group leave as 128-byte
+// rows.  The filter bank is a sparse GEMV of ~2 non-zeros per bin: plain VALU FMAs fed from LDS (an MFMA tile would be
+// >90 % zeros).
+struct MelParams {
+    const float* x;        // [N][2][len]
+    float* out;            // [N][n_mels][n_frames][2]
+    Tables tb;
+    const int* start;      // [n_mels]
+    const float* w;        // [n_mels][max_len]
+    int len, n_frames, pad_mode, gpw;
+    int n_mels, max_len;
+    float eps;
+};
+constexpr int kPowStride = 320, kMelMaxLen = kPowStride - 257, kMelMaxBands = 128;
+constexpr int kMelTableFloats = 4096;   // LDS copy of w (n_mels * max_len <= 4096)
+
+// first half of stft_block: 256-point FFT of the packed frame, then the power spectrum |X[k]|^2, k = 0..256, of this
+// lane's bins into pw[] (LDS, frame-private) -- see stft_block for the pairing of bins
+__device__ __forceinline__ void stft_power(c32* sc, int lane, c32 wq, const c32* tw512, c32 (&x)[16]) {
+    const int f = lane >> 4, q = lane & 15;
+    c32* fr = sc + f * kFrameStride;
+    c32* fn = sc + f * kNatStride;
+    fft16<false>(x);
+    SSK_OPAQUE2(wq);
+    twiddle16<false>(x, wq);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
+    fft16<false>(x);
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) fn[q + posN(16 * s)] = x[s];
+    wave_sync();
+    f32x4 k01[2], k23[2], p01[2], p23[2], w01[2], w23[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = q + 16 * i;
+        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fn + posN(4 * b));
+        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fn + posN(252 - 4 * b));
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(tw512 + posN(4 * b));
+        k01[i] = zk4[0]; k23[i] = zk4[1]; p01[i] = zp4[0]; p23[i] = zp4[1]; w01[i] = w4[0]; w23[i] = w4[1];
+    }
+    const c32 prev0 = mk2(row_ror1(p01[0].x, lane), row_ror1(p01[0].y, lane));
+    const c32 prev1 = mk2(row_ror1(p01[1].x, lane), row_ror1(p01[1].y, lane));
+    float z128 = 0.f;
+    if (q == 0) { const c32 z = fn[posN(128)]; z128 = z.x * z.x + z.y * z.y; }
+    wave_sync();                                         // every lane holds its Z values: the scratch may be overwritten
+    float* pw = reinterpret_cast<float*>(sc) + f * kPowStride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = q + 16 * i;
+        const c32 ptop = i == 0 ? (q == 0 ? k01[0].xy : prev0) : (q == 0 ? prev0 : prev1);
+        const c32 zk[4] = {k01[i].xy, k01[i].zw, k23[i].xy, k23[i].zw};
+        const c32 zp[4] = {ptop, p23[i].zw, p23[i].xy, p01[i].zw};
+        const c32 ww[4] = {w01[i].xy, w01[i].zw, w23[i].xy, w23[i].zw};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const c32 P = add_conj(zk[e], zp[e]), Q = sub_conj(zk[e], zp[e]);
+            const c32 wQ = cmul(Q, ww[e]);
+            const c32 X = add_mi(P, wQ), Y = add_pi(P, wQ);          // 2 X[k], conj(2 X[256-k])
+            pw[4 * b + e] = 0.25f * (X.x * X.x + X.y * X.y);
+            pw[256 - 4 * b - e] = 0.25f * (Y.x * Y.x + Y.y * Y.y);   // (k = 0: X[256], written by lane 0 only)
+        }
+    }
+    if (q == 0) pw[128] = z128;                            // X[128] = conj(Z[128]); after the loop: b = 32 is nobody's
+    for (int k = 257 + q; k < kPowStride; k += 16) pw[k] = 0.f;
+    wave_sync();
+}
+
+__global__ __launch_bounds__(512) void k_logmel(MelParams p) {
+    __shared__ c32 sc[8 * kWaveScratch];
+    __shared__ float res[kMelMaxBands * 32];                // [n_mels][16 frames][2 ears]
+    __shared__ float s_win[kNfft];
+    __shared__ c32 s_tw512[kTw512Lds];
+    __shared__ float s_w[kMelTableFloats];
+    __shared__ int s_start[kMelMaxBands];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int groups = (p.n_frames + kSegFrames - 1) / kSegFrames, chunks = (groups + p.gpw - 1) / p.gpw;
+    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
+    const int ch = wv >> 2, tbl = wv & 3;
+    const float* row0 = p.x + (size_t)unit * 2 * p.len;
+    f32x4* seg4 = reinterpret_cast<f32x4*>(sc);
+    const float* seg = reinterpret_cast<const float*>(sc);
+    SpecParams sp;                                          // the staging helper only needs these fields
+    sp.x = p.x; sp.len = p.len; sp.pad_mode = p.pad_mode;
+    f32x4 r[3];
+    spec_seg_load(sp, row0, g0, t, r);
+    s_win[t] = p.tb.win[t];
+    if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
+    for (int e = t; e < p.n_mels * p.max_len; e += 512) s_w[e] = p.w[e];
+    if (t < p.n_mels) s_start[t] = p.start[t];
+    const c32 wq = p.tb.twM[64 * (lane & 15)];
+    for (int g = g0; g < g1; ++g) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (t + 512 * k < 2 * kSegQuads) seg4[t + 512 * k] = r[k];
+        lds_barrier();
+        const int fl = 4 * tbl + (lane >> 4);               // frame of this lane within the group
+        const bool live = kSegFrames * g + fl < p.n_frames;
+        c32 x[16];
+        {
+            const c32* y2 = reinterpret_cast<const c32*>(seg + ch * kSegLen + kHop * fl) + (lane & 15);
+            const c32* w2 = reinterpret_cast<const c32*>(s_win) + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const c32 s = lds_ld(y2 + 16 * j), w = lds_ld(w2 + 16 * j);
+                x[j] = live ? mk2(w.x * s.x, w.y * s.y) : mk2(0.f, 0.f);
+            }
+        }
+        lds_barrier();
+        if (g + 1 < g1) spec_seg_load(sp, row0, g + 1, t, r);
+        if (kSegFrames * g + 4 * tbl < p.n_frames) {        // wave-uniform: at least one live frame in this block
+            c32* wsc = sc + wv * kWaveScratch;
+            stft_power(wsc, lane, wq, s_tw512, x);
+            const float* pw = reinterpret_cast<const float*>(wsc) + (lane >> 4) * kPowStride;
+            for (int j = lane & 15; j < p.n_mels; j += 16) {
+                const float* pj = pw + s_start[j];
+                const float* wj = s_w + j * p.max_len;
+                float acc = 0.f;
+                for (int i = 0; i < p.max_len; ++i) acc = fmaf(wj[i], pj[i], acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const float v = __builtin_amdgcn_logf(acc + p.eps) * 0.69314718055994531f;
+#else
+                const float v = logf(acc + p.eps);
+#endif
+                res[(j * kSegFrames + fl) * 2 + ch] = v;
+            }
+        }
+        lds_barrier();
+        // rows of 16 frames x 2 ears = 128 contiguous bytes of out[unit][j][16 g ..][.]
+        const int nf = min(kSegFrames, p.n_frames - kSegFrames * g);
+        float* o = p.out + ((size_t)unit * p.n_mels * p.n_frames + kSegFrames * g) * 2;
+        for (int e = t; e < p.n_mels * 32; e += 512) {
+            const int j = e >> 5, c = e & 31;
+            if (c < 2 * nf) o[(size_t)j * p.n_frames * 2 + c] = res[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv: one workgroup per (unit, ear, output block j = blockIdx.y).
 // unit descriptor desc[n][8], two terms (source, distractor):
 //   desc[4k+0] = RIR bank index (-1: term absent)      desc[4k+1] = spectrum slot of window m = m_min

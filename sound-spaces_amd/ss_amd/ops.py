@@ -100,6 +100,26 @@ def spectrogram(x: torch.Tensor, pad_mode="reflect") -> torch.Tensor:
     return out
 
 
+def logmel_into(x: torch.Tensor, out: torch.Tensor, mel_start: torch.Tensor, mel_w: torch.Tensor, eps: float = 1e-6,
+                pad_mode="reflect") -> None:
+    """EXTENSION (not in the reference): out[n, j, t, c] = log(sum_i mel_w[j, i] |STFT(x[n, c])[mel_start[j]+i, t]|^2 + eps).
+    mel_start int32 [n_mels], mel_w float32 [n_mels, max_len] on the device (planning.mel_filterbank_sparse)."""
+    _chk(x, torch.float32, "x"); _chk(out, torch.float32, "out"); _chk(mel_start, torch.int32, "mel_start")
+    _chk(mel_w, torch.float32, "mel_w")
+    N, two, n = x.shape
+    n_mels, max_len = mel_w.shape
+    assert two == 2 and mel_start.shape == (n_mels,) and tuple(out.shape) == (N, n_mels, 1 + n // 160, 2)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ss_logmel_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], mel_start.data_ptr(),
+                                             mel_w.data_ptr(), n_mels, max_len, float(eps), _stream()), "ss_logmel_f32")
+
+
+def logmel(x: torch.Tensor, mel_start: torch.Tensor, mel_w: torch.Tensor, eps: float = 1e-6, pad_mode="reflect"):
+    out = torch.empty((x.shape[0], mel_w.shape[0], 1 + x.shape[2] // 160, 2), dtype=torch.float32, device=x.device)
+    logmel_into(x, out, mel_start, mel_w, eps, pad_mode)
+    return out
+
+
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
                    pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
     """Fused observation.  ``audiogoal`` may be None when out_len <= KB (waveform never leaves the CU)."""
@@ -153,6 +173,10 @@ def _register():
     lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
                "int pad_mode=0, bool interleaved=False) -> (Tensor, Tensor)")
     lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
+    lib.define("logmel(Tensor x, Tensor mel_start, Tensor mel_w, float eps=1e-6, int pad_mode=0) -> Tensor")
+    lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0: logmel(x, ms, mw, eps, pad_mode), "CUDA")
+    lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0:
+             x.new_empty((x.shape[0], mw.shape[0], 1 + x.shape[2] // 160, 2)), "Meta")
     lib.impl("intensity", intensity, "CUDA")
     lib.impl("intensity", lambda a, num_frame=150: a.new_empty((a.shape[0],)), "Meta")
     lib.impl("source_windows", source_windows, "CUDA")

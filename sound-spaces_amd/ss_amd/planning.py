@@ -106,3 +106,46 @@ def spectrogram_shape(length: int) -> tuple:
     (65, 69, 2) @44.1 kHz."""
     n_frames = 1 + length // 160
     return (65, ceil_div(n_frames, 4), 2)
+
+
+# ---- log-mel extension (not in the reference; ss_logmel_f32) -------------------------------------------------------
+def _slaney_mel(f):
+    """Hz -> mel on the Slaney / auditory-toolbox scale (linear to 1 kHz, log above): librosa's default."""
+    f = np.asarray(f, dtype=np.float64)
+    lin = 3.0 * f / 200.0
+    return np.where(f >= 1000.0, 15.0 + 27.0 * np.log(np.maximum(f, 1e-30) / 1000.0) / np.log(6.4), lin)
+
+
+def _slaney_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((m - 15.0) * np.log(6.4) / 27.0), 200.0 * m / 3.0)
+
+
+def mel_filterbank_sparse(sr: int, n_mels: int = 64, n_fft: int = 512, fmin: float = 0.0, fmax=None):
+    """Area-normalised triangular mel filters in the band-sparse form ss_logmel_f32 takes:
+    (start int32 [n_mels], weights float32 [n_mels, max_len], max_len); band j weighs bins start[j] + i.
+    Triangles are evaluated per bin from the band edges (each filter is non-zero on one contiguous run of bins)."""
+    fmax = sr / 2.0 if fmax is None else float(fmax)
+    n_bins = 1 + n_fft // 2
+    edges = _slaney_hz(np.linspace(_slaney_mel(fmin), _slaney_mel(fmax), n_mels + 2))
+    bin_hz = np.arange(n_bins, dtype=np.float64) * (sr / float(n_fft))
+    rows, starts = [], []
+    for j in range(n_mels):
+        lo, ce, hi = edges[j], edges[j + 1], edges[j + 2]
+        rise = (bin_hz - lo) / (ce - lo)
+        fall = (hi - bin_hz) / (hi - ce)
+        tri = np.clip(np.minimum(rise, fall), 0.0, None) * (2.0 / (hi - lo))
+        nz = np.nonzero(tri)[0]
+        if nz.size == 0:                    # band narrower than one bin (librosa warns: "empty filters")
+            starts.append(0); rows.append(np.zeros(1))
+        else:
+            starts.append(int(nz[0])); rows.append(tri[nz[0]:nz[-1] + 1])
+    max_len = max(len(r) for r in rows)
+    w = np.zeros((n_mels, max_len), np.float32)
+    for j, r in enumerate(rows):
+        w[j, :len(r)] = r
+    return np.asarray(starts, np.int32), w, max_len
+
+
+def logmel_shape(n_samples: int, n_mels: int):
+    return (n_mels, 1 + n_samples // 160, 2)

@@ -173,6 +173,25 @@ int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mod
     return 0;
 }
 
+int hs_logmel(const float* x, float* out, int n_units, int len, int pad_mode, const int* start, const float* w,
+              int n_mels, int max_len, float eps, int gpw) {
+    ssk::MelParams p;
+    p.x = x; p.out = out; p.tb = host_tables(); p.start = start; p.w = w;
+    p.len = len; p.n_frames = 1 + len / ssk::kHop; p.pad_mode = pad_mode;
+    p.n_mels = n_mels; p.max_len = max_len; p.eps = eps;
+    if (n_mels > ssk::kMelMaxBands || max_len > ssk::kMelMaxLen || n_mels * max_len > ssk::kMelTableFloats) return -2;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    gridDim = dim3{(unsigned)(n_units * chunks), 1, 1};
+    for (int b = 0; b < n_units * chunks; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(512, [&] { ssk::k_logmel(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int hs_intensity(const float* x, float* out, int n_units, int len, int num_frame) {
     ssk::IntensityParams p;
     p.x = x; p.out = out; p.len = len; p.num_frame = num_frame;

@@ -108,3 +108,16 @@ def intensity(x, num_frame=150):
     rc = L.hs_intensity(_p(x, ctypes.c_float), _p(out, ctypes.c_float), x.shape[0], x.shape[2], num_frame)
     assert rc == 0, rc
     return out
+
+
+def logmel(x, sr, n_mels=64, eps=1e-6, pad_mode=0, gpw=1):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    N, _, n = x.shape
+    start, w, max_len = P.mel_filterbank_sparse(sr, n_mels)
+    start = np.ascontiguousarray(start, np.int32); w = np.ascontiguousarray(w, np.float32)
+    out = np.full((N,) + P.logmel_shape(n, n_mels), np.nan, np.float32)
+    rc = L.hs_logmel(_p(x, ctypes.c_float), _p(out, ctypes.c_float), N, n, pad_mode, _p(start, ctypes.c_int),
+                     _p(w, ctypes.c_float), n_mels, max_len, ctypes.c_float(eps), gpw)
+    assert rc == 0, rc
+    return out
