@@ -180,6 +180,12 @@ def main():
                 chunk["n"] = 0
             ex.wait()
 
+    if ex is not None:                                         # RCCL communicator / channel set-up (seconds, lazy on
+        for _ in range(2):                                     # the first collective) must not land in the timed region
+            ex.next_local()                                    # whatever --warmup is; both buffers, full-size gathers
+            ex.gather()
+        ex.wait()
+        torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
     flush()
