@@ -170,8 +170,8 @@ int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode
     if (n_units == 0) return 0;
     if (!x || !out || !mel_start || !mel_w || n_units < 0 || len < ssk::kNfft / 2 + 1) return SS_EINVAL;
     if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
-    if (n_mels < 1 || n_mels > ssk::kMelMaxBands || max_len < 1 || max_len > ssk::kMelMaxLen ||
-        n_mels * max_len > ssk::kMelTableFloats || !(eps > 0.f))
+    if (n_mels < 1 || n_mels > ssk::kMelMaxBands || max_len < 4 || max_len > ssk::kMelMaxLen || (max_len & 3) ||
+        n_mels * max_len > ssk::kMelTableFloats || !(eps > 0.f) || (reinterpret_cast<size_t>(mel_w) & 15))
         return SS_EINVAL;
     ssk::MelParams p;
     int rc = get_tables(&p.tb);

@@ -324,7 +324,7 @@ __device__ __forceinline__ void spec_seg_load(const SpecParams& p, const float* 
 }
 
 __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
-    __shared__ c32 sc[8 * kWaveScratch];                    // 73728 B: staging (2 x 2912 floats), then 8 wave scratches
+    alignas(16) __shared__ c32 sc[8 * kWaveScratch];        // 73728 B: staging (2 x 2912 floats), then 8 wave scratches
     __shared__ float res[kBins4 * 8];                       // [65][4 blocks][2 ears]
     __shared__ float s_win[kNfft];
     __shared__ c32 s_tw512[kTw512Lds];
@@ -393,7 +393,7 @@ struct MelParams {
     int n_mels, max_len;
     float eps;
 };
-constexpr int kPowStride = 320, kMelMaxLen = kPowStride - 257, kMelMaxBands = 128;
+constexpr int kPowStride = 320, kMelMaxLen = 60, kMelMaxBands = 128;   // start <= 256, start + max_len <= 316 < 320
 constexpr int kMelTableFloats = 4096;   // LDS copy of w (n_mels * max_len <= 4096)
 
 // first half of stft_block: 256-point FFT of the packed frame, then the power spectrum |X[k]|^2, k = 0..256, of this
@@ -452,11 +452,11 @@ __device__ __forceinline__ void stft_power(c32* sc, int lane, c32 wq, const c32*
 }
 
 __global__ __launch_bounds__(512) void k_logmel(MelParams p) {
-    __shared__ c32 sc[8 * kWaveScratch];
+    alignas(16) __shared__ c32 sc[8 * kWaveScratch];
     __shared__ float res[kMelMaxBands * 32];                // [n_mels][16 frames][2 ears]
     __shared__ float s_win[kNfft];
     __shared__ c32 s_tw512[kTw512Lds];
-    __shared__ float s_w[kMelTableFloats];
+    alignas(16) __shared__ float s_w[kMelTableFloats];
     __shared__ int s_start[kMelMaxBands];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int groups = (p.n_frames + kSegFrames - 1) / kSegFrames, chunks = (groups + p.gpw - 1) / p.gpw;
@@ -498,10 +498,15 @@ __global__ __launch_bounds__(512) void k_logmel(MelParams p) {
             stft_power(wsc, lane, wq, s_tw512, x);
             const float* pw = reinterpret_cast<const float*>(wsc) + (lane >> 4) * kPowStride;
             for (int j = lane & 15; j < p.n_mels; j += 16) {
-                const float* pj = pw + s_start[j];
-                const float* wj = s_w + j * p.max_len;
+                // band starts and max_len are multiples of 4 (ABI contract): two aligned 16-byte LDS reads per 4 bins
+                const f32x4* pj = reinterpret_cast<const f32x4*>(pw + s_start[j]);
+                const f32x4* wj = reinterpret_cast<const f32x4*>(s_w + j * p.max_len);
                 float acc = 0.f;
-                for (int i = 0; i < p.max_len; ++i) acc = fmaf(wj[i], pj[i], acc);
+                for (int i = 0; i < (p.max_len >> 2); ++i) {
+                    const f32x4 a = wj[i], b = pj[i];
+                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+                    acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                }
 #if defined(__HIP_DEVICE_COMPILE__)
                 const float v = __builtin_amdgcn_logf(acc + p.eps) * 0.69314718055994531f;
 #else

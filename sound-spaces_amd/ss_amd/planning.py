@@ -137,10 +137,11 @@ def mel_filterbank_sparse(sr: int, n_mels: int = 64, n_fft: int = 512, fmin: flo
         tri = np.clip(np.minimum(rise, fall), 0.0, None) * (2.0 / (hi - lo))
         nz = np.nonzero(tri)[0]
         if nz.size == 0:                    # band narrower than one bin (librosa warns: "empty filters")
-            starts.append(0); rows.append(np.zeros(1))
+            starts.append(0); rows.append(np.zeros(4))
         else:
-            starts.append(int(nz[0])); rows.append(tri[nz[0]:nz[-1] + 1])
-    max_len = max(len(r) for r in rows)
+            s0 = int(nz[0]) & ~3            # ABI: starts are multiples of 4 (16-byte LDS reads), leading weights zero
+            starts.append(s0); rows.append(tri[s0:nz[-1] + 1])
+    max_len = (max(len(r) for r in rows) + 3) & ~3
     w = np.zeros((n_mels, max_len), np.float32)
     for j, r in enumerate(rows):
         w[j, :len(r)] = r

@@ -179,7 +179,7 @@ int hs_logmel(const float* x, float* out, int n_units, int len, int pad_mode, co
     p.x = x; p.out = out; p.tb = host_tables(); p.start = start; p.w = w;
     p.len = len; p.n_frames = 1 + len / ssk::kHop; p.pad_mode = pad_mode;
     p.n_mels = n_mels; p.max_len = max_len; p.eps = eps;
-    if (n_mels > ssk::kMelMaxBands || max_len > ssk::kMelMaxLen || n_mels * max_len > ssk::kMelTableFloats) return -2;
+    if (n_mels > ssk::kMelMaxBands || max_len > ssk::kMelMaxLen || (max_len & 3) || n_mels * max_len > ssk::kMelTableFloats) return -2;
     const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
     p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
     const int chunks = (groups + p.gpw - 1) / p.gpw;
