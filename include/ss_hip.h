@@ -16,6 +16,7 @@
  *   ss_audio_obs_f32         <- get_current_spectrogram_observation on a cache miss
  *                               (soundspaces/simulator.py:690-701), both stages fused
  *   ss_intensity_f32         <- Intensity.get_observation (ss_baselines/av_wan/avwan_sensors.py:91-100)
+ *   ss_gccphat_f32           <- extension, not in the reference (GCC-PHAT inter-aural feature of configs[4])
  *   ss_logmel_f32            <- extension, not in the reference (log-mel front end named by the north star)
  *   ss_source_windows_f32    <- the FFT of the source clip that fftconvolve recomputes on every
  *                               call (simulator.py:630) hoisted out and cached per (sound, window)
@@ -95,6 +96,13 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
  * time and sees zeros beyond bin 256); mel_w 16-byte aligned.  mel_start's range is the caller's responsibility. */
 int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode, const int* mel_start,
                   const float* mel_w, int n_mels, int max_len, float eps, void* stream);
+
+/* EXTENSION (no counterpart in the reference; BASELINE.json configs[4] "GCC-PHAT"): generalised cross-correlation
+ * with phase transform between the two ears, per STFT frame (framing exactly as ss_spectrogram_f32):
+ *   G[k] = X_left[k] conj(X_right[k]);  g = irfft(G / (|G| + eps), 512);  out[n][i][t] = g[(i - max_lag) mod 512]
+ * x [n_units, 2, len] -> out [n_units, 2*max_lag + 1, 1 + len/160].  1 <= max_lag <= 32, eps > 0. */
+int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mode, int max_lag, float eps,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -411,3 +411,16 @@ def compute_logmel(audio_data, sr, n_mels=64, eps=1e-6, pad_mode="reflect"):
         p = np.abs(stft(audio_data[c], pad_mode=pad_mode).astype(np.complex128)) ** 2
         chans.append(np.log(fb @ p + eps))
     return np.stack(chans, axis=-1)
+
+
+def compute_gcc_phat(audio_data, max_lag=32, eps=1e-8, pad_mode="reflect"):
+    """EXTENSION (not in the reference; see the note above compute_logmel).  Generalised cross-correlation with
+    phase transform between the two ears, per STFT frame:
+        G[k] = X_l[k] conj(X_r[k]);  g = irfft(G / (|G| + eps), 512);  out[i] = g[(i - max_lag) mod 512]
+    [2, T] -> [2*max_lag + 1, 1 + T//160] (lag -max_lag .. +max_lag; positive lag = left ear delayed)."""
+    xl = stft(audio_data[0], pad_mode=pad_mode).astype(np.complex128)
+    xr = stft(audio_data[1], pad_mode=pad_mode).astype(np.complex128)
+    g = xl * np.conj(xr)
+    g = g / (np.abs(g) + eps)
+    cc = np.fft.irfft(g, n=N_FFT, axis=0)
+    return np.concatenate([cc[N_FFT - max_lag:], cc[:max_lag + 1]], axis=0)

@@ -194,6 +194,30 @@ int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode
     return hip_err(hipGetLastError());
 }
 
+int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mode, int max_lag, float eps,
+                   void* stream) {
+    if (n_units == 0) return 0;
+    if (!x || !out || n_units < 0 || len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (max_lag < 1 || max_lag > ssk::kGccMaxLag || !(eps > 0.f)) return SS_EINVAL;
+    ssk::GccParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.x = x;
+    p.out = out;
+    p.len = len;
+    p.n_frames = n_frames_of(len);
+    p.pad_mode = pad_mode;
+    p.max_lag = max_lag;
+    p.eps = eps;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    long long gpw = (long long)n_units * groups / 2048;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    hipLaunchKernelGGL(ssk::k_gccphat, dim3(n_units * chunks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
                      int rir_chan_stride, int rir_elem_stride, int rir_cap, int n_valid, int out_len,

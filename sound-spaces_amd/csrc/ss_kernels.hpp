@@ -527,6 +527,203 @@ __global__ __launch_bounds__(512) void k_logmel(MelParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_gccphat (EXTENSION, not in the reference: BASELINE configs[4] "GCC-PHAT"): per STFT frame
+//   G[k] = X_l[k] conj(X_r[k]),  g = irfft(G / (|G| + eps), 512),  out[n][i][tf] = g[(i - max_lag) mod 512].
+// 256 threads = 4 waves; a workgroup owns 16 frames of one unit and BOTH ears (the cross-spectrum needs them in one
+// place), a wave its 4 frames: two forward 256-point FFTs (the packed real FFTs of the two ears), Hermitian split of
+// both, normalised cross-spectrum, Hermitian merge, one inverse 256-point FFT = the 512 lags as packed pairs.  All
+// stages reuse the STFT building blocks (radix-16 passes, padded natural-order layout, DPP for the mirror top bin);
+// everything between the staged input segment and the result rows stays in registers / the wave's LDS scratch.
+struct GccParams {
+    const float* x;        // [N][2][len]
+    float* out;            // [N][2*max_lag+1][n_frames]
+    Tables tb;
+    int len, n_frames, pad_mode, gpw, max_lag;
+    float eps;
+};
+constexpr int kGccMaxLag = 32;
+constexpr int kGccWaveScratch = 4 * kNatStride + 4 * kFrameStride;   // region A (natural order) + region B (tiles)
+
+// 256-point forward FFT of 4 packed frames held as x[j] = frame[q + 16 j]; natural-order result to fn[] (padded layout);
+// tile = transpose scratch
+__device__ __forceinline__ void frame_fft_fwd(c32* tile, c32* nat, int lane, c32 wq, c32 (&x)[16]) {
+    const int f = lane >> 4, q = lane & 15;
+    c32* fr = tile + f * kFrameStride;
+    c32* fn = nat + f * kNatStride;
+    fft16<false>(x);
+    SSK_OPAQUE2(wq);
+    twiddle16<false>(x, wq);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
+    fft16<false>(x);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) fn[q + posN(16 * s)] = x[s];
+    wave_sync();
+}
+
+// this lane's 8 Hermitian bin pairs (k = 4b+e, 256-k), b = q + 16 i, of one ear: X2[k] and conj(X2[256-k])
+struct EarQuads { f32x4 k01[2], k23[2], p01[2], p23[2]; };
+__device__ __forceinline__ void ear_load(const c32* nat, int lane, EarQuads& z) {
+    const int f = lane >> 4, q = lane & 15;
+    const c32* fn = nat + f * kNatStride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int b = q + 16 * i;
+        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fn + posN(4 * b));
+        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fn + posN(252 - 4 * b));
+        z.k01[i] = zk4[0]; z.k23[i] = zk4[1]; z.p01[i] = zp4[0]; z.p23[i] = zp4[1];
+    }
+}
+__device__ __forceinline__ void ear_pairs(const EarQuads& z, int i, int lane, c32 (&zk)[4], c32 (&zp)[4]) {
+    const int q = lane & 15;
+    const c32 prev0 = mk2(row_ror1(z.p01[0].x, lane), row_ror1(z.p01[0].y, lane));
+    const c32 prev1 = mk2(row_ror1(z.p01[1].x, lane), row_ror1(z.p01[1].y, lane));
+    const c32 ptop = i == 0 ? (q == 0 ? z.k01[0].xy : prev0) : (q == 0 ? prev0 : prev1);
+    zk[0] = z.k01[i].xy; zk[1] = z.k01[i].zw; zk[2] = z.k23[i].xy; zk[3] = z.k23[i].zw;
+    zp[0] = ptop; zp[1] = z.p23[i].zw; zp[2] = z.p23[i].xy; zp[3] = z.p01[i].zw;
+}
+
+// a / (|a| + eps): the PHAT weighting
+__device__ __forceinline__ c32 phat(c32 a, float eps) {
+    const float m = fast_sqrt(a.x * a.x + a.y * a.y) + eps;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(m);
+#else
+    const float r = 1.0f / m;
+#endif
+    return mk2(a.x * r, a.y * r);
+}
+
+__global__ __launch_bounds__(256) void k_gccphat(GccParams p) {
+    alignas(16) __shared__ c32 sc[4 * kGccWaveScratch];     // staging (2 x 2912 floats), then 4 wave scratches
+    __shared__ float res[(2 * kGccMaxLag + 1) * kSegFrames];
+    __shared__ float s_win[kNfft];
+    __shared__ c32 s_tw512[kTw512Lds];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, q = lane & 15;
+    const int groups = (p.n_frames + kSegFrames - 1) / kSegFrames, chunks = (groups + p.gpw - 1) / p.gpw;
+    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
+    const int n_lags = 2 * p.max_lag + 1;
+    const float* row0 = p.x + (size_t)unit * 2 * p.len;
+    f32x4* seg4 = reinterpret_cast<f32x4*>(sc);
+    const float* seg = reinterpret_cast<const float*>(sc);
+    SpecParams sp;
+    sp.x = p.x; sp.len = p.len; sp.pad_mode = p.pad_mode;
+    for (int e = t; e < kNfft; e += 256) s_win[e] = p.tb.win[e];
+    s_tw512[posN(t)] = p.tb.tw512[t];
+    const c32 wq = p.tb.twM[64 * q];
+    const float eps4 = 4.f * p.eps;                         // the split yields 2X, so the products carry a factor 4
+    for (int g = g0; g < g1; ++g) {
+        // stage the two padded segments (same helper as k_spectrogram, written for 512 threads: two half rounds)
+        f32x4 r[3];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            spec_seg_load(sp, row0, g, 2 * t + half, r);    // quads 2t+half + 512 k  (a permutation of 0..1535)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (2 * t + half + 512 * k < 2 * kSegQuads) seg4[2 * t + half + 512 * k] = r[k];
+        }
+        lds_barrier();
+        const int fl = 4 * wv + (lane >> 4);
+        const bool live = kSegFrames * g + fl < p.n_frames;
+        c32 xl[16], xr[16];
+        {
+            const c32* w2 = reinterpret_cast<const c32*>(s_win) + q;
+            const c32* yl = reinterpret_cast<const c32*>(seg + kHop * fl) + q;
+            const c32* yr = reinterpret_cast<const c32*>(seg + kSegLen + kHop * fl) + q;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const c32 w = lds_ld(w2 + 16 * j), a = lds_ld(yl + 16 * j), b = lds_ld(yr + 16 * j);
+                xl[j] = live ? mk2(w.x * a.x, w.y * a.y) : mk2(0.f, 0.f);
+                xr[j] = live ? mk2(w.x * b.x, w.y * b.y) : mk2(0.f, 0.f);
+            }
+        }
+        lds_barrier();                                      // staging area dead
+        if (kSegFrames * g + 4 * wv < p.n_frames) {         // wave-uniform
+            c32* regA = sc + wv * kGccWaveScratch;          // natural-order spectra / V
+            c32* regB = regA + 4 * kNatStride;              // transpose tiles
+            EarQuads zl, zr;
+            frame_fft_fwd(regB, regA, lane, wq, xl);
+            ear_load(regA, lane, zl);
+            c32 z128l = regA[(lane >> 4) * kNatStride + posN(128)];
+            wave_sync();                                    // left spectrum is in registers: region A is free again
+            frame_fft_fwd(regB, regA, lane, wq, xr);
+            ear_load(regA, lane, zr);
+            const c32 z128r = regA[(lane >> 4) * kNatStride + posN(128)];
+            f32x4 w01[2], w23[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(s_tw512 + posN(4 * (q + 16 * i)));
+                w01[i] = w4[0]; w23[i] = w4[1];
+            }
+            wave_sync();                                    // every lane holds its bins: V may overwrite region A
+            c32* vn = regA + (lane >> 4) * kNatStride;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int b = q + 16 * i;
+                c32 lk[4], lp[4], rk[4], rp[4];
+                ear_pairs(zl, i, lane, lk, lp);
+                ear_pairs(zr, i, lane, rk, rp);
+                const c32 ww[4] = {w01[i].xy, w01[i].zw, w23[i].xy, w23[i].zw};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // Hermitian split of both ears: X = 2 X[k], Y = conj(2 X[256-k])
+                    const c32 Pl = add_conj(lk[e], lp[e]), Ql = sub_conj(lk[e], lp[e]), wl = cmul(Ql, ww[e]);
+                    const c32 Pr = add_conj(rk[e], rp[e]), Qr = sub_conj(rk[e], rp[e]), wr = cmul(Qr, ww[e]);
+                    const c32 Xl = add_mi(Pl, wl), Yl = add_pi(Pl, wl), Xr = add_mi(Pr, wr), Yr = add_pi(Pr, wr);
+                    c32 gk = phat(cmulc(Xl, Xr), eps4);                       // G[k]
+                    const c32 gpc = phat(cmulc(Yl, Yr), eps4);                // conj(G[256-k])
+                    c32 gp = mk2(gpc.x, -gpc.y);
+                    herm_inv(gk, gp, ww[e]);                                  // -> 2 V[k], 2 V[256-k]
+                    vn[posN(4 * b + e)] = gk;
+                    if (4 * b + e != 0) vn[posN(256 - 4 * b - e)] = gp;       // V[256] does not exist
+                }
+            }
+            if (q == 0) {                                   // k = 128 pairs with itself: X[128] = conj(Z[128])
+                const c32 g128 = phat(cmulc(mk2(z128l.x, -z128l.y), mk2(z128r.x, -z128r.y)), p.eps);
+                vn[posN(128)] = mk2(2.f * g128.x, -2.f * g128.y);             // 2 V[128] = 2 conj(G[128])
+            }
+            wave_sync();
+            // inverse 256-point FFT of V: lane q holds V[q + 16 j]; result x[s] = 512 * (g[2n], g[2n+1]), n = q + 16 s
+            c32 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = lds_ld(vn + q + posN(16 * j));
+            fft16<true>(x);
+            c32 wqi = wq;
+            SSK_OPAQUE2(wqi);
+            twiddle16<true>(x, wqi);
+            c32* fr = regB + (lane >> 4) * kFrameStride;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) fr[r2 * 17 + q] = x[r2];
+            wave_sync();
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) x[r2] = lds_ld(fr + q * 17 + r2);
+            fft16<true>(x);
+            constexpr float inv = 1.0f / 512.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int tau = 2 * (q + 16 * s2) + u;                    // lag 0..511; >= 256 means tau - 512
+                    const int i = tau <= p.max_lag ? tau + p.max_lag : tau >= kNfft - p.max_lag ? tau - kNfft + p.max_lag : -1;
+                    if (i >= 0) res[i * kSegFrames + fl] = inv * (u ? x[s2].y : x[s2].x);
+                }
+            }
+        }
+        lds_barrier();
+        const int nf = min(kSegFrames, p.n_frames - kSegFrames * g);
+        float* o = p.out + (size_t)unit * n_lags * p.n_frames + kSegFrames * g;
+        for (int e = t; e < n_lags * kSegFrames; e += 256) {
+            const int i = e >> 4, c = e & 15;
+            if (c < nf) o[(size_t)i * p.n_frames + c] = res[e];
+        }
+        lds_barrier();                                      // res and the scratch are reused by the next group
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_conv: one workgroup per (unit, ear, output block j = blockIdx.y).
 // unit descriptor desc[n][8], two terms (source, distractor):
 //   desc[4k+0] = RIR bank index (-1: term absent)      desc[4k+1] = spectrum slot of window m = m_min

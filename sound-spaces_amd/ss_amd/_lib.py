@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libss_hip.so"))
 
 EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source_windows_f32",
-           "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32")
+           "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32", "ss_gccphat_f32")
 
 _lib = None
 
@@ -36,6 +36,7 @@ def load() -> ctypes.CDLL:
     lib.ss_spectrogram_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp]
     lib.ss_audio_obs_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]
     lib.ss_intensity_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp]
+    lib.ss_gccphat_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, ctypes.c_float, vp]
     lib.ss_logmel_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, c_int, c_int, ctypes.c_float, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int

@@ -120,6 +120,23 @@ def logmel(x: torch.Tensor, mel_start: torch.Tensor, mel_w: torch.Tensor, eps: f
     return out
 
 
+def gccphat_into(x: torch.Tensor, out: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="reflect") -> None:
+    """EXTENSION (not in the reference): per-frame GCC-PHAT between the two ears,
+    out[n, i, t] = irfft(G / (|G| + eps))[(i - max_lag) mod 512], G = STFT(x[n, 0]) conj(STFT(x[n, 1]))."""
+    _chk(x, torch.float32, "x"); _chk(out, torch.float32, "out")
+    N, two, n = x.shape
+    assert two == 2 and tuple(out.shape) == (N, 2 * max_lag + 1, 1 + n // 160)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ss_gccphat_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], int(max_lag),
+                                              float(eps), _stream()), "ss_gccphat_f32")
+
+
+def gccphat(x: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="reflect") -> torch.Tensor:
+    out = torch.empty((x.shape[0], 2 * max_lag + 1, 1 + x.shape[2] // 160), dtype=torch.float32, device=x.device)
+    gccphat_into(x, out, max_lag, eps, pad_mode)
+    return out
+
+
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
                    pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
     """Fused observation.  ``audiogoal`` may be None when out_len <= KB (waveform never leaves the CU)."""
@@ -173,6 +190,10 @@ def _register():
     lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
                "int pad_mode=0, bool interleaved=False) -> (Tensor, Tensor)")
     lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
+    lib.define("gccphat(Tensor x, int max_lag=32, float eps=1e-8, int pad_mode=0) -> Tensor")
+    lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0: gccphat(x, max_lag, eps, pad_mode), "CUDA")
+    lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0:
+             x.new_empty((x.shape[0], 2 * max_lag + 1, 1 + x.shape[2] // 160)), "Meta")
     lib.define("logmel(Tensor x, Tensor mel_start, Tensor mel_w, float eps=1e-6, int pad_mode=0) -> Tensor")
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0: logmel(x, ms, mw, eps, pad_mode), "CUDA")
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0:

@@ -192,6 +192,23 @@ int hs_logmel(const float* x, float* out, int n_units, int len, int pad_mode, co
     return 0;
 }
 
+int hs_gccphat(const float* x, float* out, int n_units, int len, int pad_mode, int max_lag, float eps, int gpw) {
+    ssk::GccParams p;
+    p.x = x; p.out = out; p.tb = host_tables();
+    p.len = len; p.n_frames = 1 + len / ssk::kHop; p.pad_mode = pad_mode; p.max_lag = max_lag; p.eps = eps;
+    if (max_lag < 1 || max_lag > ssk::kGccMaxLag) return -2;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    gridDim = dim3{(unsigned)(n_units * chunks), 1, 1};
+    for (int b = 0; b < n_units * chunks; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(256, [&] { ssk::k_gccphat(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int hs_intensity(const float* x, float* out, int n_units, int len, int num_frame) {
     ssk::IntensityParams p;
     p.x = x; p.out = out; p.len = len; p.num_frame = num_frame;

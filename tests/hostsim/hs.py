@@ -121,3 +121,13 @@ def logmel(x, sr, n_mels=64, eps=1e-6, pad_mode=0, gpw=1):
                      _p(w, ctypes.c_float), n_mels, max_len, ctypes.c_float(eps), gpw)
     assert rc == 0, rc
     return out
+
+
+def gccphat(x, max_lag=32, eps=1e-8, pad_mode=0, gpw=1):
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    N, _, n = x.shape
+    out = np.full((N, 2 * max_lag + 1, 1 + n // 160), np.nan, np.float32)
+    rc = L.hs_gccphat(_p(x, ctypes.c_float), _p(out, ctypes.c_float), N, n, pad_mode, max_lag, ctypes.c_float(eps), gpw)
+    assert rc == 0, rc
+    return out
