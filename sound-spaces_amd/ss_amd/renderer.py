@@ -310,25 +310,87 @@ class RirStore:
         return slot
 
 
-def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 90, 180, 270), limit: Optional[int] = None):
+    def _pack(self, rir: Optional[np.ndarray], row: np.ndarray) -> int:
+        row[:] = 0.0
+        if rir is None or not np.size(rir):
+            return 0
+        r = np.asarray(rir, dtype=np.float32)
+        r = r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
+        n = min(r.shape[1], self.cap)
+        row[:, :n] = r[:, :n]
+        return n
+
+    def slot_many(self, keys: Sequence, loaders: Sequence, workers: int = 8) -> List[int]:
+        """Slots of many keys at once (scene load, `AudioGoalBatcher`): the misses' loaders run on a thread pool
+        (file reads overlap), their rows are packed into ONE pinned staging block and reach the bank with one H2D copy
+        plus one row scatter, instead of one 128 KB copy per file.  Same LRU semantics as `slot()`; a batch must fit the
+        store (its slots are returned together, so none of them may evict another)."""
+        from concurrent.futures import ThreadPoolExecutor
+        out: List[int] = [-1] * len(keys)
+        todo = []
+        for i, key in enumerate(keys):
+            if key in self._slot_of:
+                out[i] = self.slot(key, loaders[i])
+            else:
+                todo.append(i)
+        # duplicates inside the batch load once
+        first = {}
+        for i in todo:
+            first.setdefault(keys[i], i)
+        uniq = list(first.values())
+        if len(set(keys)) > self.slots:
+            raise ValueError(f"slot_many: {len(set(keys))} distinct keys do not fit a store of {self.slots} slots")
+        # keys of this batch that are already resident must survive the evictions below: make them most recent
+        for lo in range(0, len(uniq), self.slots):
+            part = uniq[lo:lo + self.slots]
+            if workers > 1 and len(part) > 1:
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    rirs = list(pool.map(lambda i: loaders[i](), part))
+            else:
+                rirs = [loaders[i]() for i in part]
+            stage = torch.zeros((len(part), 2, self.cap), dtype=torch.float32,
+                                pin_memory=self.bank.data.device.type == "cuda")
+            stage_np = stage.numpy()
+            lens = np.zeros((len(part),), np.int32)
+            slots = []
+            for j, i in enumerate(part):
+                lens[j] = self._pack(rirs[j], stage_np[j])
+                self.misses += 1
+                if self._free:
+                    sl = self._free.pop()
+                else:
+                    victim = next(iter(self._slot_of))
+                    sl = self._slot_of.pop(victim)
+                self._slot_of[keys[i]] = sl
+                slots.append(sl)
+            dev = self.bank.data.device
+            idx = torch.as_tensor(slots, dtype=torch.long, device=dev)
+            self.bank.data.index_copy_(0, idx, stage.to(dev, non_blocking=True))
+            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(dev))
+        for i in todo:
+            out[i] = self._slot_of[keys[i]]
+        return out
+
+
+def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 90, 180, 270), limit: Optional[int] = None,
+                    batch: int = 256, workers: int = 8):
     """Bulk pre-load of one scene's binaural RIRs, `<scene_rir_dir>/<azimuth>/<receiver>_<source>.wav`
     (soundspaces/README.md:38-42, simulator.py:615-616), into the HBM store so that no step of an episode in this scene
     touches the disk.  Keys are the file paths the simulator adapter asks for.  Returns the number of files loaded."""
     import os
-    n = 0
+    paths = []
     for az in azimuths:
         d = os.path.join(scene_rir_dir, str(az))
         if not os.path.isdir(d):
             continue
-        for name in sorted(os.listdir(d)):
-            if not name.endswith(".wav"):
-                continue
-            path = os.path.join(d, name)
-            store.slot(path, lambda path=path: reader(path))
-            n += 1
-            if limit is not None and n >= limit:
-                return n
-    return n
+        paths += [os.path.join(d, name) for name in sorted(os.listdir(d)) if name.endswith(".wav")]
+    if limit is not None:
+        paths = paths[:limit]
+    batch = max(1, min(batch, store.slots))
+    for lo in range(0, len(paths), batch):                      # threaded reads, one H2D copy per batch
+        part = paths[lo:lo + batch]
+        store.slot_many(part, [(lambda path=path: reader(path)) for path in part], workers=workers)
+    return len(paths)
 
 
 class AudioEngine:

@@ -179,3 +179,43 @@ def test_bulk_scene_loader(tmp_path):
     assert int(st.bank.lengths[slot]) == 1200 and st.hits == 1
     bad = st.slot(str(tmp_path / "90" / "bad_1.wav"), lambda: None)
     assert int(st.bank.lengths[bad]) == 0 and not st.bank.data[bad].any()
+
+
+def test_rir_store_slot_many_matches_one_by_one():
+    """batched loading (thread-pooled loaders, one staging block) == the per-key path: same slots contents, LRU order,
+    duplicates loaded once, hits not reloaded, oversized batches keep the most recent keys"""
+    rng = np.random.default_rng(1)
+    rirs = {k: rng.standard_normal((rng.integers(5, 120), 2)).astype(np.float32) for k in "abcdefgh"}
+    rirs["empty"] = None
+    loads = []
+
+    def loader(k):
+        def f():
+            loads.append(k)
+            return rirs[k]
+        return f
+    a = RirStore(slots=16, cap=100, device="cpu")
+    b = RirStore(slots=16, cap=100, device="cpu")
+    keys = list("abcab") + ["empty", "d"]
+    sa = a.slot_many(keys, [loader(k) for k in keys], workers=4)
+    assert sorted(loads) == sorted(set(keys))                                     # duplicates load once
+    sb = [b.slot(k, loader(k)) for k in keys]
+    assert sa[0] == sa[3] and sa[1] == sa[4] and len(set(sa)) == 5
+    for x, y in zip(sa, sb):
+        assert torch.equal(a.bank.data[x], b.bank.data[y]) and int(a.bank.lengths[x]) == int(b.bank.lengths[y])
+    assert int(a.bank.lengths[sa[5]]) == 0 and not a.bank.data[sa[5]].any()
+    loads.clear()
+    again = a.slot_many(["a", "e"], [loader("a"), loader("e")])
+    assert again[0] == sa[0] and loads == ["e"] and a.hits >= 1                   # hit not reloaded
+    # a batch must fit the store; resident keys of the batch are not evicted by its own misses
+    small = RirStore(slots=3, cap=100, device="cpu")
+    with pytest.raises(ValueError):
+        small.slot_many(list("abcd"), [loader(k) for k in "abcd"])
+    small.slot_many(list("ab"), [loader(k) for k in "ab"])
+    out = small.slot_many(list("cab"), [loader(k) for k in "cab"], workers=1)
+    assert len(set(out)) == 3
+    out = small.slot_many(list("adb"), [loader(k) for k in "adb"], workers=1)    # d evicts c, never a or b
+    assert set(small._slot_of) == {"a", "b", "d"} and len(set(out)) == 3
+    for k, sl in small._slot_of.items():
+        n = min(len(rirs[k]), 100)
+        np.testing.assert_array_equal(small.bank.data[sl, :, :n].numpy(), rirs[k][:n].T)
