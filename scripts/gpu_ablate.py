@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Ablation builds of the conv kernel (timing only, results are wrong by construction):
+"""Ablation builds of the conv kernel k_conv<false,true> (timing only, results are wrong by construction; run with
+SS_HIP_NO_ROW_KERNEL=1 semantics: the script sets it, so the 2048-unit launch uses one workgroup per row):
 NOVALU = butterflies/twiddles/Hermitian stage skipped (LDS + global traffic + barriers remain)
 NOLDS  = LDS reads/writes of the passes removed (VALU + global + barriers remain)
 Patches a temporary copy of csrc/, builds it over libss_hip.so, times, restores."""
@@ -10,6 +11,7 @@ TMP = "/tmp/abl/sound-spaces_amd/csrc"
 SO = os.path.join(CSRC, "libss_hip.so")
 DRY = "--dry" in sys.argv
 shutil.copy(SO, "/tmp/base.so")
+os.environ["SS_HIP_NO_ROW_KERNEL"] = "1"
 
 def patched(kind):
     shutil.rmtree("/tmp/abl", ignore_errors=True); shutil.copytree(CSRC, TMP)
@@ -45,12 +47,12 @@ def patched(kind):
             core = core.replace(fn, fn + " return;")
     if "NOLDS" in kinds:
         # reads -> synthetic values, writes -> keep-alive
-        core = re.sub(r"x\[(\w)\] = (base|src)\[([^\]]+)\];", r"x[\1] = mk2((float)t, (float)\1);", core)
+        core = re.sub(r"x\[(\w)\] = lds_ld\((base|src) \+ ([^;]+)\);", r"x[\1] = mk2((float)t, (float)\1);", core)
         core = re.sub(r"(base|dst)\[([^\]]+)\] = x\[(\w)\];", r'asm volatile("" :: "v"(x[\3]));', core)
-        core = re.sub(r"\{ v\[d\] = pa\[4352 \* d\]; v\[4 \+ d\] = pb\[4352 \* d\]; \}", r"{ v[d] = mk2((float)q, (float)d); v[4 + d] = mk2((float)d, (float)q); }", core)
+        core = re.sub(r"\{ v\[d\] = lds_ld\(pa \+ 4352 \* d\); v\[4 \+ d\] = lds_ld\(pb \+ 4352 \* d\); \}", r"{ v[d] = mk2((float)q, (float)d); v[4 + d] = mk2((float)d, (float)q); }", core)
         core = re.sub(r"\{ pa\[4352 \* d\] = y\[d\]; pb\[4352 \* d\] = y\[4 \+ d\]; \}", r'{ asm volatile("" :: "v"(y[d]), "v"(y[4 + d])); }', core)
         kern = re.sub(r"for \(int a = 0; a < 16; \+\+a\) base\[1040 \* a\] = x\[a\];", r'for (int a = 0; a < 16; ++a) asm volatile("" :: "v"(x[a]));', kern)
-        kern = re.sub(r"for \(int a = 0; a < 16; \+\+a\) x\[a\] = base\[1040 \* a\];", r"for (int a = 0; a < 16; ++a) x[a] = mk2((float)t, (float)a);", kern)
+        kern = re.sub(r"for \(int a = 0; a < 16; \+\+a\) x\[a\] = lds_ld\(base \+ 1040 \* a\);", r"for (int a = 0; a < 16; ++a) x[a] = mk2((float)t, (float)a);", kern)
     open(os.path.join(TMP, "ss_fft_core.hpp"), "w").write(core)
     open(os.path.join(TMP, "ss_kernels.hpp"), "w").write(kern)
 
