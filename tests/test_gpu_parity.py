@@ -232,6 +232,40 @@ def test_persistent_row_kernel_large_batches():
     np.testing.assert_allclose(ag2[:, :, :4000], ag[:, :, :4000], atol=2e-6 * scale)
 
 
+def test_four_second_rir_four_partition_blocks():
+    """64000-tap RIRs (SS2.0 irTime up to 4 s) = 4 partition blocks: SS2.0 steady + wrap and SS1.0 multi-second steady,
+    a batch of 20 units with ragged long RIRs, every unit against the oracle."""
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(12)
+    sr = 16000
+    src = O.synth_sources(rng, sr, k=2, seconds=5)
+    rirs = []
+    for L in (64000, 40001, 16385, 64000):
+        h = O.synth_rir(rng, sr, length=L, n=1)[0] * np.exp(-np.arange(L) / 30000.0)[None, :].astype(np.float32)
+        rirs.append(np.ascontiguousarray(h.T))
+    # SS1.0 semantics
+    r = make_renderer(sr, list(src), rirs)
+    units, refs = [], []
+    for n in range(20):
+        s_, h_, idx = n % 2, n % 4, n % 5
+        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_))
+        refs.append(O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx))
+    ag, sg = r.render(r.plan(units), want_audiogoal=True)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    for n in range(20):
+        check(ag[n], refs[n])
+        check(sg[n], O.compute_spectrogram(refs[n].astype(np.float32)))
+    # SS2.0 semantics (0.25-s steps, wrapping sample index)
+    r2 = make_renderer(sr, list(src), rirs, step_time=0.25, wrap=True)
+    units, refs = [], []
+    for n, si in enumerate((100, 30000, 70000, 79000, 12345)):
+        units.append(UnitRequest(n % 2, P.window_start_continuous(si), n % 4))
+        refs.append(O.convolve_with_rir(src[n % 2], rirs[n % 4], sr, si, 0.25))
+    ag2 = r2.render_audiogoal(r2.plan(units)).cpu().numpy()
+    for n in range(5):
+        check(ag2[n], refs[n])
+
+
 def test_linearity_and_shift_properties_full_size():
     """Size-independent properties at the 128-env headline size: the path is linear in the RIR and a delayed
     unit impulse RIR returns the delayed source."""

@@ -156,6 +156,30 @@ def test_long_rir_two_blocks_multisecond_steady():
     assert (ws.m_min, ws.count) == (-1, 2)
 
 
+def test_four_second_rir_four_partition_blocks():
+    """SS2.0 ray-traced RIRs run up to 4 s (irTime): 64000 taps = 4 partition blocks at 16 kHz, reaching back over
+    four source windows; SS2.0 steady branch with wrap-around and the SS1.0 multi-second steady branch."""
+    rng = np.random.default_rng(11)
+    sr, L = 16000, 64000
+    src = O.synth_sources(rng, sr, k=1, seconds=5)[0]
+    h = O.synth_rir(rng, sr, length=L, n=1)[0]
+    h *= np.exp(-np.arange(L) / 30000.0)[None, :].astype(np.float32)            # keep the tail audible but decaying
+    bank = h[None].astype(np.float32)
+    rir_wav = np.ascontiguousarray(h.T)
+    # SS2.0: 0.25-s step at sample 70000 of the (wrapping) clip
+    ns = 4000
+    out, _ = hs.run([src], bank, [L], [dict(sound=0, t0=P.window_start_continuous(70000), rir=0, wrap=True)], ns, sr,
+                    simple=False)
+    ref = O.convolve_with_rir(src, rir_wav, sr, 70000, 0.25)
+    check(out[0], ref)
+    # SS1.0 multi-second, audio_index = 4 (steady: index*sr - L >= 0)
+    t0 = P.window_start_sim(len(src), sr, 4)
+    out, sg = hs.run([src], bank, [L], [dict(sound=0, t0=t0, rir=0)], sr, sr, fuse=True, simple=False)
+    ref = O.compute_audiogoal(src, rir_wav, sr, audio_index=4)
+    check(out[0], ref)
+    check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
+
+
 def test_spectrogram_kernel_pad_modes_and_edges():
     rng = np.random.default_rng(5)
     x = rng.standard_normal((2, 2, 16000)).astype(np.float32)
