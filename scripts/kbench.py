@@ -16,12 +16,13 @@ ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--sizes", default="128,2048")
 ap.add_argument("--only", default="")
 ap.add_argument("--bank-mib", type=int, default=512)
+ap.add_argument("--sounds", type=int, default=102, help="source clips (102 = bench.py: 13 MB of window spectra, more than one XCD's L2)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 sr = a.sr
 rng = np.random.default_rng(0)
 r = BatchedAudioRenderer(sr, device=dev)
-for i, c in enumerate(O.synth_sources(rng, sr, k=16)):
+for i, c in enumerate(O.synth_sources(rng, sr, k=a.sounds)):
     r.add_source(str(i), c)
 R = max(8, (a.bank_mib << 20) // (2 * sr * 4))
 r.set_rir_bank(RirBank(synth_rir_bank_device(torch, R, sr, sr, dev, 3), torch.full((R,), sr, dtype=torch.int32, device=dev)))
@@ -36,7 +37,7 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e3
 
 for N in [int(x) for x in a.sizes.split(",")]:
-    descs = [r.plan_arrays(rng.integers(0, 16, N), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(8)]
+    descs = [r.plan_arrays(rng.integers(0, a.sounds, N), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(8)]
     ag = torch.empty((N, 2, sr), device=dev); sg = torch.empty((N,) + r.spectrogram_shape, device=dev)
     res = {}
     if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % 8], spectrogram_out=sg, audiogoal_out=(ag if sr > 16384 else None)), a.reps)
