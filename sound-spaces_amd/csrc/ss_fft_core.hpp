@@ -153,6 +153,21 @@ SSK_PK2(conj_add_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_l
         mk2(a.x - b.y, -a.y - b.x))
 SSK_PK2(conj_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]", mk2(a.x + b.y, -a.y + b.x))
 
+// X = a - i*b and Y = a + i*b gathered by component: (X.x, Y.x) and (X.y, Y.y), so that |X|^2 and |Y|^2 come out of
+// ONE packed multiply + ONE packed fma (mag2) instead of two scalar pairs
+SSK_PK2(xy_re, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]", mk2(a.x + b.y, a.x - b.y))
+SSK_PK2(xy_im, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]", mk2(a.y - b.x, a.y + b.x))
+__device__ __forceinline__ c32 mag2(c32 u, c32 v) {          // (u.x^2 + v.x^2, u.y^2 + v.y^2)
+#if defined(__HIP_DEVICE_COMPILE__)
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %1" : "=v"(t) : "v"(v));
+    asm("v_pk_fma_f32 %0, %1, %1, %2" : "=v"(r) : "v"(u), "v"(t));
+    return r;
+#else
+    return mk2(fmaf(u.x, u.x, v.x * v.x), fmaf(u.y, u.y, v.y * v.y));
+#endif
+}
+
 // a * w and a * conj(w): (a.x*w.x, a.x*w.y) then fused (-+a.y*w.y, +-a.y*w.x)
 __device__ __forceinline__ c32 cmul(c32 a, c32 w) {
 #if defined(__HIP_DEVICE_COMPILE__)

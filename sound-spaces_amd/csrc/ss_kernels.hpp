@@ -242,9 +242,10 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
         for (int e = 0; e < 4; ++e) {
             const c32 P = add_conj(zk[e], zp[e]), Q = sub_conj(zk[e], zp[e]);
             const c32 wq = cmul(Q, ww[e]);
-            const c32 X = add_mi(P, wq), Y = add_pi(P, wq);                      // 2 X[k], conj(2 X[256-k])
-            d += fast_sqrt(X.x * X.x + X.y * X.y);
-            const float my = fast_sqrt(Y.x * Y.x + Y.y * Y.y);
+            // X = P - i wq = 2 X[k], Y = P + i wq = conj(2 X[256-k]), by component; m2 = (|X|^2, |Y|^2)
+            const c32 m2 = mag2(xy_re(P, wq), xy_im(P, wq));
+            d += fast_sqrt(m2.x);
+            const float my = fast_sqrt(m2.y);
             if (e == 0) m0[i] = 0.5f * my; else m += my;
         }
         dsum[i] = 0.5f * d;
@@ -441,9 +442,9 @@ __device__ __forceinline__ void stft_power(c32* sc, int lane, c32 wq, const c32*
         for (int e = 0; e < 4; ++e) {
             const c32 P = add_conj(zk[e], zp[e]), Q = sub_conj(zk[e], zp[e]);
             const c32 wQ = cmul(Q, ww[e]);
-            const c32 X = add_mi(P, wQ), Y = add_pi(P, wQ);          // 2 X[k], conj(2 X[256-k])
-            pw[4 * b + e] = 0.25f * (X.x * X.x + X.y * X.y);
-            pw[256 - 4 * b - e] = 0.25f * (Y.x * Y.x + Y.y * Y.y);   // (k = 0: X[256], written by lane 0 only)
+            const c32 m2 = mag2(xy_re(P, wQ), xy_im(P, wQ));         // (|2 X[k]|^2, |2 X[256-k]|^2)
+            pw[4 * b + e] = 0.25f * m2.x;
+            pw[256 - 4 * b - e] = 0.25f * m2.y;                      // (k = 0: X[256], written by lane 0 only)
         }
     }
     if (q == 0) pw[128] = z128;                            // X[128] = conj(Z[128]); after the loop: b = 32 is nobody's
