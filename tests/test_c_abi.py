@@ -46,6 +46,17 @@ def test_argument_checks_return_einval_without_a_gpu():
     assert lib.ss_audio_obs_f32(one, one, one, one, null, null, 1, 32000, 16000, 1, 16000, 16000, 16000, 0, 0, null) == -1
     assert lib.ss_intensity_f32(one, one, 1, 16000, 0, null) == -1
     assert lib.ss_intensity_f32(null, one, 1, 16000, 150, null) == -1
+    f = ctypes.c_float
+    assert lib.ss_logmel_f32(one, one, 1, 16000, 0, one, one, 64, 23, f(1e-6), null) == -1          # max_len % 4
+    assert lib.ss_logmel_f32(one, one, 1, 16000, 0, one, one, 129, 24, f(1e-6), null) == -1         # too many bands
+    assert lib.ss_logmel_f32(one, one, 1, 16000, 0, one, one, 128, 36, f(1e-6), null) == -1         # table > 4096
+    assert lib.ss_logmel_f32(one, one, 1, 16000, 0, one, one, 64, 24, f(0.0), null) == -1           # eps must be > 0
+    assert lib.ss_logmel_f32(one, one, 1, 16000, 0, one, ctypes.c_void_p(20), 64, 24, f(1e-6), null) == -1   # unaligned table
+    assert lib.ss_logmel_f32(one, one, 0, 16000, 0, one, one, 64, 24, f(1e-6), null) == 0           # empty batch
+    assert lib.ss_gccphat_f32(one, one, 1, 16000, 0, 33, f(1e-8), null) == -1                       # max_lag > 32
+    assert lib.ss_gccphat_f32(one, one, 1, 16000, 0, 0, f(1e-8), null) == -1
+    assert lib.ss_gccphat_f32(one, one, 1, 100, 0, 8, f(1e-8), null) == -1                          # too short
+    assert lib.ss_gccphat_f32(one, null, 1, 16000, 0, 8, f(1e-8), null) == -1
 
 
 def test_python_layer_refuses_cpu_tensors():
