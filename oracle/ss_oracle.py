@@ -16,6 +16,9 @@ checkout):
 * ``ss_baselines/savi/pretraining/audiogoal_dataset.py:114-156``
 * ``ss_baselines/av_wan/avwan_sensors.py:91-100``  ``Intensity``
 
+and, clearly separated at the end of the file, two EXTENSION definitions that have no
+counterpart in the reference (``compute_logmel``, ``compute_gcc_phat``): "parity unpinned".
+
 Pinning status
 --------------
 * Convolution half: PINNED.  ``tests/golden/make_golden.py`` executes the
