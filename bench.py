@@ -103,6 +103,12 @@ def main():
                          "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); 1 = every step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank flow on a 1-GPU box)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams that consecutive steps alternate between; 0 = auto: 1 on one GPU (per-launch durations "
+                         "stay comparable with the rocprofv3 kernel trace), 2 when the all-gather overlaps the kernels "
+                         "(RCCL's workgroups cannot share a CU with the 148 KB / 512-VGPR workgroups of k_conv, so a "
+                         "256-row launch on fewer than 256 free CUs needs a second wave of rows unless the next step's "
+                         "rows may already start)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
@@ -155,18 +161,25 @@ def main():
     sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(2)]
     ag_buf = torch.empty((N, 2, sr), dtype=torch.float32, device=dev) if (args.with_audiogoal or sr > P.KB) else None
 
+    S = args.streams if args.streams > 0 else (2 if ex is not None else 1)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+    sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
+    ag_bufs = [ag_buf] + [torch.empty_like(ag_buf) for _ in range(S - 1)] if ag_buf is not None else [None] * S
+
     def step(k):
-        if ex is not None:
-            if chunk["n"] == 0:
-                chunk["buf"] = ex.next_local()                 # [G*N, 65, T4, 2]: G consecutive steps of this rank
-            i = chunk["n"]
-            r.render(descs[k], spectrogram_out=chunk["buf"][i * N:(i + 1) * N], audiogoal_out=ag_buf)
-            chunk["n"] += 1
-            if chunk["n"] == G:
-                ex.gather()
-                chunk["n"] = 0
-        else:
-            r.render(descs[k], spectrogram_out=sg_buf[k & 1], audiogoal_out=ag_buf)
+        st = streams[k % S]
+        with torch.cuda.stream(st):
+            if ex is not None:
+                if chunk["n"] == 0:
+                    chunk["buf"] = ex.next_local(streams)      # [G*N, 65, T4, 2]: G consecutive steps of this rank
+                i = chunk["n"]
+                r.render(descs[k], spectrogram_out=chunk["buf"][i * N:(i + 1) * N], audiogoal_out=ag_bufs[k % S])
+                chunk["n"] += 1
+                if chunk["n"] == G:
+                    ex.gather(streams)
+                    chunk["n"] = 0
+            else:
+                r.render(descs[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
 
     def fence():
         if world > 1:
@@ -176,30 +189,35 @@ def main():
     def flush():
         if ex is not None:
             if chunk["n"]:                                     # partial last chunk
-                ex.gather()
+                ex.gather(streams)
                 chunk["n"] = 0
-            ex.wait()
+            ex.wait(streams)
 
     if ex is not None:                                         # RCCL communicator / channel set-up (seconds, lazy on
         for _ in range(2):                                     # the first collective) must not land in the timed region
-            ex.next_local()                                    # whatever --warmup is; both buffers, full-size gathers
-            ex.gather()
-        ex.wait()
+            ex.next_local(streams)                             # whatever --warmup is; both buffers, full-size gathers
+            ex.gather(streams)
+        ex.wait(streams)
         torch.cuda.synchronize()
+    torch.cuda.synchronize()                                   # banks / spectra were built on the default stream
     for k in range(args.warmup):
         step(k)
     flush()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
-    ev0.record()
+    ev0.record(streams[0])
     for k in range(args.warmup, total):
         step(k)
-    ev1.record()
+    if S > 1:
+        for st in streams[1:]:
+            streams[0].wait_stream(st)
+    ev1.record(streams[0])
     flush()
     fence()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps           # avg launch duration on the launch stream
+    # avg launch duration on the launch stream (S > 1: launches overlap, this is the issue-to-issue average)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -245,7 +263,8 @@ def main():
                                    f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident), "
                                    "cache-miss path, spectrogram [65,%d,2] f32 out" % t4,
                        "envs_per_gpu": N, "sampling_rate": sr, "rir_len": L,
-                       "exchange": ((args.exchange + f" every {G} steps") if (world > 1 and args.exchange == "allgather") else "none"), "kernel": "k_conv<fused>" if fused else
+                       "exchange": ((args.exchange + f" every {G} steps") if (world > 1 and args.exchange == "allgather") else "none"),
+                       "streams": S, "kernel": "k_conv<fused>" if fused else
                        "k_conv + k_spectrogram"},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -47,27 +47,34 @@ class SlabExchange:
         if self._cuda:
             self.stream = torch.cuda.Stream(device=self.device)
             self.ready = [torch.cuda.Event() for _ in range(depth)]     # gather k finished
-            self.filled = [torch.cuda.Event() for _ in range(depth)]    # slab k written by the compute stream
 
-    def next_local(self) -> torch.Tensor:
-        """Buffer the renderer should write this step's slab into (waits for the gather that last used it)."""
+    def _producers(self, streams):
+        return list(streams) if streams else [torch.cuda.current_stream(self.device)]
+
+    def next_local(self, streams=None) -> torch.Tensor:
+        """Buffer the renderer should write this step's slab into (waits for the gather that last used it).
+        `streams`: the compute streams that will write into it (default: the current stream)."""
         i = self._k % self.depth
         if self._cuda and self._k >= self.depth:
-            torch.cuda.current_stream(self.device).wait_event(self.ready[i])
+            for st in self._producers(streams):
+                st.wait_event(self.ready[i])
         return self.local[i]
 
-    def gather(self) -> torch.Tensor:
+    def gather(self, streams=None) -> torch.Tensor:
         """Issue the all-gather of the slab handed out by the last next_local(); returns the [world*n, ...] tensor
-        (valid on the side stream after self.ready[i]; call wait() before consuming on the compute stream)."""
+        (valid on the side stream after self.ready[i]; call wait() before consuming on the compute stream).
+        `streams`: every compute stream that wrote part of the slab (default: the current stream)."""
         i = self._k % self.depth
         self._k += 1
         if self.world == 1:
             self.full[i] = self.local[i]
             return self.full[i]
         if self._cuda:
-            self.filled[i].record(torch.cuda.current_stream(self.device))
+            for st in self._producers(streams):             # the slab is complete when all of its writers are
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                self.stream.wait_event(self.filled[i])
                 dist.all_gather_into_tensor(self.full[i], self.local[i], group=self.group)
                 self.ready[i].record(self.stream)
         else:
@@ -78,7 +85,8 @@ class SlabExchange:
                 dist.all_gather(parts, self.local[i], group=self.group)
         return self.full[i]
 
-    def wait(self) -> None:
-        """Make the compute stream wait for the most recent gather."""
+    def wait(self, streams=None) -> None:
+        """Make the compute stream(s) wait for the most recent gather."""
         if self._cuda and self.world > 1 and self._k > 0:
-            torch.cuda.current_stream(self.device).wait_event(self.ready[(self._k - 1) % self.depth])
+            for st in self._producers(streams):
+                st.wait_event(self.ready[(self._k - 1) % self.depth])
