@@ -257,3 +257,8 @@ def test_randomised_edge_cases(seed):
     assert not out[0][:, n_valid:].any()
     if np.abs(ref).max() > 1e-3 * bound:
         check(sg[0], O.compute_spectrogram(ref.astype(np.float32)), tol=1e-4)
+    if not kw["fuse"] and not kw["interleaved"] and not (cap & 1) and cap <= P.KB:
+        # the persistent row kernel on the same ragged / odd-sized case (3 copies of the unit: rows walk 2 workgroups)
+        out3, _ = hs.run([src], bank, [L], [dict(sound=0, t0=t0, rir=0)] * 3, n_valid, sr, persist=2)
+        for k in range(3):
+            np.testing.assert_array_equal(out3[k], out[0])
