@@ -66,3 +66,29 @@ def test_python_layer_refuses_cpu_tensors():
         ops.spectrogram(torch.zeros((1, 2, 16000)))
     with pytest.raises(_lib.SsHipError):
         ops.intensity(torch.zeros((1, 2, 16000)))
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/ss_hip.h must compile as C99 (no C++-isms, no HIP/torch types) and a C
+    translation unit must link against the library's symbols."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_abi.c"
+    src.write_text(
+        '#include "ss_hip.h"\n'
+        'int main(void) {\n'
+        '  /* argument checks only: no device needed */\n'
+        '  if (ss_block_len() != 16384 || ss_spec_floats() != 32768) return 1;\n'
+        '  if (ss_spectrogram_f32((const float*)16, (float*)16, 1, 100, SS_PAD_REFLECT, 0) != SS_EINVAL) return 2;\n'
+        '  if (ss_gccphat_f32((const float*)16, (float*)16, 1, 16000, SS_PAD_CONSTANT, 99, 1e-8f, 0) != SS_EINVAL) return 3;\n'
+        '  if (ss_fftconv_binaural_f32(0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 1, SS_FLAG_NO_DISTRACTOR, 0) != 0) return 4;\n'
+        '  return 0;\n'
+        '}\n')
+    exe = tmp_path / "use_abi"
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", so_dir, "-lss_hip", "-Wl,-rpath," + so_dir])
+    assert subprocess.run([str(exe)]).returncode == 0
