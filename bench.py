@@ -292,6 +292,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
