@@ -14,11 +14,23 @@ SOURCES = ["ss_hip.hip", "ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp", o
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
+STAMP = os.path.join(CSRC, ".libss_hip.srchash")
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for s in SOURCES:
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def up_to_date():
-    if not os.path.exists(SO):
+    """By content, not mtime: the snapshot that carries the prebuilt library to the GPU box does not keep timestamps."""
+    if not (os.path.exists(SO) and os.path.exists(STAMP)):
         return False
-    t = os.path.getmtime(SO)
-    return all(os.path.getmtime(os.path.join(CSRC, s)) <= t for s in SOURCES)
+    return open(STAMP).read().strip() == _source_hash()
 
 
 def build(force=False, verbose=True):
@@ -32,6 +44,8 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd[:-1] + [tmp_so], cwd=CSRC)
     guard_isa(hipcc, verbose)
     os.replace(tmp_so, SO)
+    with open(STAMP, "w") as f:
+        f.write(_source_hash() + "\n")
     return SO
 
 
