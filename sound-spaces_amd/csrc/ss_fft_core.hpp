@@ -361,6 +361,17 @@ __device__ __forceinline__ void pass2(c32* lds, c32 wbase, int t) {
 }
 
 // pass 3 forward: read layout A, write layout B.  thread = d*256 + ab.
+// The literal twiddle set depends on d = t>>8 (wave-uniform).  Each of the four cases carries the REST of the pass
+// (barrier + stores) inside its branch: if the branches only did the multiplies and met again before the stores, the
+// compiler would merge four differently allocated copies of x[] with ~28 v_mov per thread (seen in the ISA), as much
+// work as the multiplies themselves.  The barrier is executed exactly once by every wave whichever branch it takes.
+template <int D>
+__device__ __forceinline__ void pass3_fwd_tail(c32* dst, c32 (&x)[16]) {
+    if (D) twiddle16_const<false, D>(x);
+    lds_barrier();                       // every layout-A read done before layout-B writes
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[c] = x[c];
+}
 __device__ __forceinline__ void pass3_fwd(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
     const c32* src = lds + 65 * ab + d;           // posA(ab*64 + 4c + d) = 65*ab + d + 4c
@@ -369,13 +380,22 @@ __device__ __forceinline__ void pass3_fwd(c32* lds, int t) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = lds_ld(src + 4 * c);
     fft16<false>(x);
-    twiddle16_d<false>(x, __builtin_amdgcn_readfirstlane(d));
-    lds_barrier();                       // every layout-A read done before layout-B writes
-#pragma unroll
-    for (int c = 0; c < 16; ++c) dst[c] = x[c];
+    const int du = __builtin_amdgcn_readfirstlane(d);
+    if (du == 0) pass3_fwd_tail<0>(dst, x);
+    else if (du == 1) pass3_fwd_tail<1>(dst, x);
+    else if (du == 2) pass3_fwd_tail<2>(dst, x);
+    else pass3_fwd_tail<3>(dst, x);
 }
 
 // pass 3 inverse: read layout B, write layout A.
+template <int D>
+__device__ __forceinline__ void pass3_inv_tail(c32* dst, c32 (&x)[16]) {
+    if (D) twiddle16_const<true, D>(x);
+    fft16<true>(x);
+    lds_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dst[4 * c] = x[c];
+}
 __device__ __forceinline__ void pass3_inv(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
     const c32* src = lds + 4352 * d + 17 * ab;
@@ -383,11 +403,11 @@ __device__ __forceinline__ void pass3_inv(c32* lds, int t) {
     c32 x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = lds_ld(src + c);
-    twiddle16_d<true>(x, __builtin_amdgcn_readfirstlane(d));
-    fft16<true>(x);
-    lds_barrier();
-#pragma unroll
-    for (int c = 0; c < 16; ++c) dst[4 * c] = x[c];
+    const int du = __builtin_amdgcn_readfirstlane(d);
+    if (du == 0) pass3_inv_tail<0>(dst, x);
+    else if (du == 1) pass3_inv_tail<1>(dst, x);
+    else if (du == 2) pass3_inv_tail<2>(dst, x);
+    else pass3_inv_tail<3>(dst, x);
 }
 
 // ---- Hermitian split / merge on one bin pair (k, 16384-k) ---------------------
