@@ -17,6 +17,11 @@
 
 namespace ssk {
 
+__device__ __forceinline__ void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);           // nothing moves across this point in the machine scheduler
+#endif
+}
 __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b; return r; }
 
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
@@ -145,45 +150,22 @@ __global__ __launch_bounds__(1024) void k_source_windows(SrcParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // STFT -> |.| -> 4x4 mean-pool -> log1p for one 4-frame time block per wave.
-// y: audiogoal row (LDS or global), length len.  Frame tf covers y[160*tf-256 .. 160*tf+255]
-// (librosa centre padding: reflect (pad_mode 0) or zeros (pad_mode 1)).
-// phase A: windowed frame samples -> registers (packed even/odd).  lane = f*16 + q.
-// Interior frames (all but the first two and last two of a row) take the branch-free path: 16 aligned
-// 8-byte loads of the row and 16 of the window table; edge frames go through the padding logic per sample.
-__device__ __forceinline__ void stft_load(const float* y, int len, int tf, int n_frames, int q, int pad_mode,
-                                          const float* __restrict__ win, c32 (&x)[16]) {
-    const int base = kHop * tf - kNfft / 2;
-    const c32* w2 = reinterpret_cast<const c32*>(win) + q;
+// Frame tf covers y[160*tf-256 .. 160*tf+255] of the audiogoal row y (librosa centre padding: reflect (pad_mode 0) or
+// zeros (pad_mode 1)); every kernel materialises the padding once, in LDS, before the frames are read.
+// phase A: windowed frame samples -> registers (packed even/odd), lane = f*16 + q, for a row that sits in LDS WITH its
+// centre padding materialised: every live frame is 16 aligned 8-byte reads of the row and 16 of the window table
+__device__ __forceinline__ void stft_load_padded(const float* padded, int tf, int n_frames, int q, const float* win,
+                                                 c32 (&x)[16]) {
     if (tf >= n_frames) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) x[j] = mk2(0.f, 0.f);
-    } else if (base >= 0 && base + kNfft <= len && !(reinterpret_cast<size_t>(y) & 7)) {
-        const c32* y2 = reinterpret_cast<const c32*>(y + base) + q;
+    } else {
+        const c32* y2 = reinterpret_cast<const c32*>(padded + kHop * tf) + q;
+        const c32* w2 = reinterpret_cast<const c32*>(win) + q;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const c32 s = lds_ld(y2 + 16 * j), w = lds_ld(w2 + 16 * j);
             x[j] = mk2(w.x * s.x, w.y * s.y);
-        }
-    } else {
-        // edge frame: librosa's centre padding resolved by index arithmetic and unconditional (clamped) loads, so the
-        // two or three waves per row that own edge frames do not fall into divergent per-sample branches
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = base + 2 * (q + 16 * j);
-            const c32 w = lds_ld(w2 + 16 * j);
-            float sv[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                int i = n + u;
-                if (pad_mode == 0) {                       // reflect (wave-uniform switch)
-                    i = i < 0 ? -i : i;
-                    i = i >= len ? 2 * (len - 1) - i : i;
-                }
-                const bool ok = (i >= 0) && (i < len);
-                const float v = y[ok ? i : 0];
-                sv[u] = ok ? v : 0.f;
-            }
-            x[j] = mk2(w.x * sv[0], w.y * sv[1]);
         }
     }
 }
@@ -879,24 +861,37 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
 // Fused STFT phase (out_len <= kB, t4 <= 26): the 1-s row goes from registers into LDS and feeds the STFT directly.
 __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
                                                  const float* s_win, const c32* s_tw512, c32 wq) {
-    float* yl = reinterpret_cast<float*>(lds);
+    // The row goes to LDS with librosa's centre padding materialised around it (256 samples on each side), so that
+    // every frame is an aligned, branch-free read.  (With the padding resolved per sample at load time, the three
+    // waves that own the first / last frames ran a ~300-instruction edge path on top of their two blocks; two of them
+    // share SIMD 0, which made the whole phase ~20 % longer than its arithmetic.)
+    float* yl = reinterpret_cast<float*>(lds) + kNfft / 2;          // sample 0 of the row
+    const int len = p.out_len;
     lds_barrier();   // all pass-1' reads of layout A are done
-    c32* yl2 = lds + t;                                   // the row as packed pairs: one ds_write_b64 per pair
+    c32* yl2 = reinterpret_cast<c32*>(yl) + t;            // the row as packed pairs: one ds_write_b64 per pair
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         const int n = 2 * (t + 1024 * a);
-        yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);
+        yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);   // zeros beyond n_valid
+    }
+    lds_barrier();
+    if (t < kNfft / 2) {                                  // the two pads: reflect (excluding the edge sample) or zeros
+        const bool refl = p.pad_mode == 0;
+        const float l = refl ? yl[1 + t] : 0.f, r = refl ? yl[len - 2 - t] : 0.f;
+        yl[-1 - t] = l;
+        yl[len + t] = r;
     }
     lds_barrier();
     const int lane = t & 63, wv = t >> 6;
-    // The row (<= 16384 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch overlays the whole
-    // buffer, so every wave first pulls the frames of BOTH its time blocks (wv and wv+16; t4 <= 26) into registers;
-    // after one barrier the row is dead and each wave runs its two blocks back to back in its private scratch with
-    // wave-scope synchronisation only (no workgroup barrier, waves free-running).
+    // The padded row (<= 16896 floats) sits at the start of the LDS buffer and the 16 waves' STFT scratch overlays the
+    // whole buffer, so every wave first pulls the frames of BOTH its time blocks (wv and wv+16; t4 <= 26) into
+    // registers; after one barrier the row is dead and each wave runs its two blocks back to back in its private
+    // scratch with wave-scope synchronisation only (no workgroup barrier, waves free-running).
     c32 x0[16], x1[16];
     const bool two = wv + 16 < p.t4;
-    stft_load(yl, p.out_len, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x0);
-    stft_load(yl, p.out_len, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, p.pad_mode, s_win, x1);
+    const float* padded = reinterpret_cast<const float*>(lds);   // frame tf = floats [160 tf, 160 tf + 512)
+    stft_load_padded(padded, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, s_win, x0);
+    stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
     lds_barrier();
     float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
     if (wv < p.t4)
