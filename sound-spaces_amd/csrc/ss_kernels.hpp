@@ -916,10 +916,13 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     // leaves free, and the lane's 256-point twiddle is fetched now, so the STFT phase starts no global loads
     __shared__ float s_win[FUSE ? kNfft : 1];
     __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
-    c32 wq = mk2(1.f, 0.f);
+    // The table values are only FETCHED here (three registers); they go to LDS after the convolution.  Staging them
+    // right away put two load -> s_waitcnt vmcnt(0) -> ds_write round trips (~1.7 us) in front of the RIR loads.
+    c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
+    float win_v = 0.f;
     if (FUSE) {
-        if (t < kNfft) s_win[t] = p.tb.win[t];
-        if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
+        if (t < kNfft) win_v = p.tb.win[t];
+        if (t < 256) tw512_v = p.tb.tw512[t];
         wq = p.tb.twM[64 * (t & 15)];
     }
 
@@ -993,7 +996,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
         }
     }
     store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
-    if (FUSE) fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
+    if (FUSE) {
+        if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
+        if (t < 256) s_tw512[posN(t)] = tw512_v;
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
