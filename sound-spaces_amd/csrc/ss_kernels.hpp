@@ -933,17 +933,24 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
         const int ridx = __builtin_amdgcn_readfirstlane(d[0]);
         bool active = false;
         if (ridx >= 0) {
+            const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
+            const int es = p.rir_elem_stride, cap = p.rir_cap;
+            const bool planar = es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7);   // 8-byte aligned rows
+            // the row's address needs only ridx: its loads go out BEFORE the length / window words are waited for
+            c32 hraw[8];
+            if (planar) {
+                const c32* h2 = reinterpret_cast<const c32*>(h);
+                const int m_end = cap >> 1;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) hraw[a] = (t + 1024 * a < m_end) ? h2[t + 1024 * a] : mk2(0.f, 0.f);
+            }
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
             const int m_min = __builtin_amdgcn_readfirstlane(d[2]);
             const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
             if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
-                const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
-                const int es = p.rir_elem_stride, cap = p.rir_cap;
-                if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
-                    const c32* h2 = reinterpret_cast<const c32*>(h);
-                    const int m_end = cap >> 1;
-                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? h2[m] : mk2(0.f, 0.f); });
+                if (planar) {
+                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return hraw[(m - t) >> 10]; });
                 } else {
                     pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
                         const int n = 2 * m;
