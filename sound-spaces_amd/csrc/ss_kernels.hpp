@@ -1038,16 +1038,26 @@ __device__ __forceinline__ int uniform_load(const int* ptr) {      // wave-unifo
 #endif
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 uniform_load4(const int* ptr) {   // 16-byte aligned, wave-uniform address
+#if defined(__HIP_DEVICE_COMPILE__)
+    i32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+#else
+    return i32x4{ptr[0], ptr[1], ptr[2], ptr[3]};
+#endif
+}
+
 __device__ __forceinline__ RowInfo row_info(const ConvParams& p, int row) {
-    const int* d = p.desc + 8 * (row >> 1);
     RowInfo r{0, 0, reinterpret_cast<const c32*>(p.rir)};      // inactive: a valid address for the dummy prefetch
-    const int ridx = uniform_load(d);
+    const i32x4 d = uniform_load4(p.desc + 8 * (row >> 1));    // {rir index, first slot, m_min, count}: one round trip
+    const int ridx = d.x;
     if (ridx < 0) return r;
-    const int L = uniform_load(p.rir_len + ridx);
-    const int spec0 = uniform_load(d + 1), m_min = uniform_load(d + 2), m_cnt = uniform_load(d + 3);
-    if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
+    const int L = uniform_load(p.rir_len + ridx);              // the only dependent access
+    if (L > 0 && d.z <= 0 && d.z + d.w > 0) {
         r.active = 1;
-        r.slot = spec0 - m_min;
+        r.slot = d.y - d.z;
         r.h2 = reinterpret_cast<const c32*>(p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)(row & 1) * p.rir_chan_stride);
     }
     return r;
