@@ -278,12 +278,28 @@ struct SpecParams {
 constexpr int kSegFrames = 16, kSegLen = kHop * (kSegFrames - 1) + kNfft;     // 2912 samples
 constexpr int kSegQuads = kSegLen / 4;                                         // 728 float4 per ear
 
-// the (up to) 3 float4 of the two-ear segment of group g that thread t stages: quad e4 = t + 512 k
+// the (up to) 3 float4 of the two-ear segment of group g that thread t stages: quad e4 = t + 512 k.
+// Interior groups (the segment lies inside the row; workgroup-uniform test) take a path WITHOUT per-lane branches:
+// three unconditional 16-byte loads from clamped addresses and nothing that touches the loaded values.  With the per-lane
+// "in range ? vector load : four padded scalar loads" form the compiler closed every quad with s_waitcnt vmcnt(0)
+// before issuing the next (seen in the ISA): three serialised HBM round trips, also in the "prefetch" of the next
+// group, which therefore ran in front of the math instead of under it.
 __device__ __forceinline__ void spec_seg_load(const SpecParams& p, const float* row0, int g, int t, f32x4 (&r)[3]) {
     const int s0 = kHop * kSegFrames * g - kNfft / 2;
     const bool vec_ok = !(p.len & 3) && !(reinterpret_cast<size_t>(row0) & 15);
+    if (vec_ok && s0 >= 0 && s0 + kSegLen <= p.len) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 3; ++k) {
+            const int e4 = t + 512 * k;
+            const int e = e4 < 2 * kSegQuads ? e4 : 0;      // clamp: the load is unconditional
+            const int c = e >= kSegQuads, n = s0 + 4 * (e - c * kSegQuads);
+            // no select on the loaded value (it would force the wait here): quads >= 2*kSegQuads are never stored
+            r[k] = *reinterpret_cast<const f32x4*>(row0 + (size_t)c * p.len + n);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                           // first / last group of a row, odd lengths, unaligned rows
         const int e4 = t + 512 * k;
         const int c = e4 >= kSegQuads, n = s0 + 4 * (e4 - c * kSegQuads);
         const float* row = row0 + (size_t)c * p.len;
@@ -322,7 +338,10 @@ __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
     spec_seg_load(p, row0, g0, t, r);
     s_win[t] = p.tb.win[t];
     if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
-    const c32 wq = p.tb.twM[64 * (lane & 15)];
+    c32 wq = p.tb.twM[64 * (lane & 15)];
+    // waited for HERE: if this load were still "pending" for the compiler inside the loop, its first use there would
+    // get an s_waitcnt vmcnt(0), which (one in-order counter) also waits for the next segment's prefetch
+    SSK_OPAQUE2(wq);
     for (int g = g0; g < g1; ++g) {
         // the barrier at the end of the previous round made the scratch (and res) dead
 #pragma unroll
@@ -456,7 +475,10 @@ __global__ __launch_bounds__(512) void k_logmel(MelParams p) {
     if (t < 256) s_tw512[posN(t)] = p.tb.tw512[t];
     for (int e = t; e < p.n_mels * p.max_len; e += 512) s_w[e] = p.w[e];
     if (t < p.n_mels) s_start[t] = p.start[t];
-    const c32 wq = p.tb.twM[64 * (lane & 15)];
+    c32 wq = p.tb.twM[64 * (lane & 15)];
+    // waited for HERE: if this load were still "pending" for the compiler inside the loop, its first use there would
+    // get an s_waitcnt vmcnt(0), which (one in-order counter) also waits for the next segment's prefetch
+    SSK_OPAQUE2(wq);
     for (int g = g0; g < g1; ++g) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -596,7 +618,8 @@ __global__ __launch_bounds__(256) void k_gccphat(GccParams p) {
     sp.x = p.x; sp.len = p.len; sp.pad_mode = p.pad_mode;
     for (int e = t; e < kNfft; e += 256) s_win[e] = p.tb.win[e];
     s_tw512[posN(t)] = p.tb.tw512[t];
-    const c32 wq = p.tb.twM[64 * q];
+    c32 wq = p.tb.twM[64 * q];
+    SSK_OPAQUE2(wq);                                        // see k_spectrogram
     const float eps4 = 4.f * p.eps;                         // the split yields 2X, so the products carry a factor 4
     for (int g = g0; g < g1; ++g) {
         // stage the two padded segments (same helper as k_spectrogram, written for 512 threads: two half rounds)
