@@ -61,8 +61,7 @@ int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, int 
     const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
     // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
     const bool planar = p.rir_elem_stride == 1 && !(p.rir_cap & 1) && !(reinterpret_cast<size_t>(p.rir) & 7) &&
-                        !(p.rir_unit_stride & 1) && !(p.rir_chan_stride & 1) && p.rir_cap >= 2 &&
-                        !(reinterpret_cast<size_t>(p.desc) & 15);          // descriptor rows read as one 16-byte scalar load
+                        !(p.rir_unit_stride & 1) && !(p.rir_chan_stride & 1) && p.rir_cap >= 2;
     static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
     if constexpr (!FUSE) {              // the fused kernel gains nothing from it (measured), see k_conv_rows
         if (simple && planar && !no_rows && 2 * n_units > n_cus) {

@@ -17,11 +17,29 @@
 
 namespace ssk {
 
-__device__ __forceinline__ void sched_fence() {
+// wave-uniform words through the scalar cache (s_load, counted by lgkmcnt - independent of the vector-memory queue)
+__device__ __forceinline__ int uniform_load(const int* ptr) {      // wave-uniform address -> scalar cache
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);           // nothing moves across this point in the machine scheduler
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+#else
+    return *ptr;
 #endif
 }
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 uniform_load4(const int* ptr) {   // 4 consecutive words, wave-uniform address
+#if defined(__HIP_DEVICE_COMPILE__)
+    int a, b, c, d;                     // four dword loads, ONE wait (no alignment requirement beyond 4 bytes)
+    asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x4\n\ts_load_dword %2, %4, 0x8\n\t"
+                 "s_load_dword %3, %4, 0xc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(ptr) : "memory");
+    return i32x4{a, b, c, d};
+#else
+    return i32x4{ptr[0], ptr[1], ptr[2], ptr[3]};
+#endif
+}
+
 __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b; return r; }
 
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
@@ -991,12 +1009,12 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     } else
     for (int term = 0; term < 2; ++term) {
         // descriptor words are workgroup-uniform: keep them in SGPRs
-        const int ridx = __builtin_amdgcn_readfirstlane(d[4 * term]);
+        // through the scalar cache: two short round trips instead of two vector-memory ones in front of the RIR loads
+        const i32x4 dw = uniform_load4(d + 4 * term);
+        const int ridx = dw.x;
         if (ridx < 0) continue;
-        const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
-        const int spec0 = __builtin_amdgcn_readfirstlane(d[4 * term + 1]);
-        const int m_min = __builtin_amdgcn_readfirstlane(d[4 * term + 2]);
-        const int m_cnt = __builtin_amdgcn_readfirstlane(d[4 * term + 3]);
+        const int L = uniform_load(p.rir_len + ridx);
+        const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
         const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
         const int nbh = (L + kB - 1) / kB;
         for (int i = 0; i < nbh; ++i) {
@@ -1051,26 +1069,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 // Preconditions checked by the launcher: planar bank rows (elem stride 1), even capacity <= kB, 8-byte aligned rows.
 struct RowInfo { int active, slot; const c32* h2; };
 
-__device__ __forceinline__ int uniform_load(const int* ptr) {      // wave-uniform address -> scalar cache
-#if defined(__HIP_DEVICE_COMPILE__)
-    int v;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
-    return v;
-#else
-    return *ptr;
-#endif
-}
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4 uniform_load4(const int* ptr) {   // 16-byte aligned, wave-uniform address
-#if defined(__HIP_DEVICE_COMPILE__)
-    i32x4 v;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
-    return v;
-#else
-    return i32x4{ptr[0], ptr[1], ptr[2], ptr[3]};
-#endif
-}
 
 __device__ __forceinline__ RowInfo row_info(const ConvParams& p, int row) {
     RowInfo r{0, 0, reinterpret_cast<const c32*>(p.rir)};      // inactive: a valid address for the dummy prefetch
