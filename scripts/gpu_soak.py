@@ -70,3 +70,58 @@ for rnd in range(rounds):
     del r
 print(f"soak seed {seed0}: {rounds} batches, {n_checked} units checked in {time.time() - t_start:.0f} s; worst rel err {worst}")
 assert max(worst.values()) <= 1e-4, worst
+
+
+# ---- 44.1 kHz (partitioned rows, unfused spectrogram) and SoundSpaces-2.0 stepping (0.25-s steps, wrapping index) ----
+worst2 = {"44k_audiogoal": 0.0, "44k_spectrogram": 0.0, "ss2_audiogoal": 0.0, "ss2_spectrogram": 0.0}
+for rnd in range(max(2, rounds // 6)):
+    rng = np.random.default_rng(seed0 * 7919 + rnd)
+    sr = 44100
+    src = [O.synth_sources(rng, sr, k=1, seconds=int(rng.integers(1, 3)))[0] for _ in range(2)]
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=int(rng.integers(1000, sr + 1)), n=1)[0].T) for _ in range(3)]
+    r = BatchedAudioRenderer(sr, device=dev)
+    for i, s_ in enumerate(src):
+        r.add_source(f"s{i}", s_)
+    r.set_rir_bank(RirBank.from_arrays(rirs, dev))
+    N = int(rng.choice([1, 5, 40, 140]))
+    units, meta = [], []
+    for n in range(N):
+        s_, h_ = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+        idx = int(rng.integers(0, len(src[s_]) // sr))
+        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_)); meta.append((s_, h_, idx))
+    ag, sg = r.render(r.plan(units), want_audiogoal=True)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    cache = {}
+    for n in sorted(set(rng.integers(0, N, min(N, 12)).tolist())):
+        m = meta[n]
+        if m not in cache:
+            a = O.compute_audiogoal(src[m[0]], rirs[m[1]], sr, audio_index=m[2])
+            cache[m] = (a, O.compute_spectrogram(a.astype(np.float32)))
+        worst2["44k_audiogoal"] = max(worst2["44k_audiogoal"], O.relerr(ag[n], cache[m][0]))
+        worst2["44k_spectrogram"] = max(worst2["44k_spectrogram"], O.relerr(sg[n], cache[m][1]))
+    del r
+    # SS2.0
+    sr = 16000
+    # 3-s clips (1-s ones are tiled x3 at load, continuous_simulator.py:408-410): the early branch never meets the clip end
+    src = [O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=int(rng.choice([1, 3])))[0], sr) for _ in range(2)]
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=int(rng.integers(500, 40000)), n=1)[0].T) for _ in range(3)]
+    r = BatchedAudioRenderer(sr, device=dev, step_time=0.25, wrap=True)
+    for i, s_ in enumerate(src):
+        r.add_source(f"s{i}", s_)
+    r.set_rir_bank(RirBank.from_arrays(rirs, dev))
+    N = int(rng.choice([3, 50, 200]))
+    units, meta = [], []
+    for n in range(N):
+        s_, h_ = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+        si = int(rng.integers(0, len(src[s_])))
+        units.append(UnitRequest(s_, P.window_start_continuous(si), h_)); meta.append((s_, h_, si))
+    ag, sg = r.render(r.plan(units), want_audiogoal=True)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    for n in sorted(set(rng.integers(0, N, min(N, 12)).tolist())):
+        s_, h_, si = meta[n]
+        a = O.convolve_with_rir(src[s_], rirs[h_], sr, si, 0.25)
+        worst2["ss2_audiogoal"] = max(worst2["ss2_audiogoal"], O.relerr(ag[n], a))
+        worst2["ss2_spectrogram"] = max(worst2["ss2_spectrogram"], O.relerr(sg[n], O.compute_spectrogram(a.astype(np.float32))))
+    del r
+print(f"soak seed {seed0} (44.1 kHz, SS2.0): worst rel err {worst2}")
+assert max(worst2.values()) <= 1e-4, worst2
