@@ -91,6 +91,16 @@ __device__ __forceinline__ c32 lds_ld(const c32* p) {
 #endif
 }
 
+// LDS store that is not paired into ds_write2_b64 (13 cycles of store-data transfer for 16 bytes against 6 + 6)
+__device__ __forceinline__ void lds_st(c32* p, c32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef volatile __attribute__((address_space(3))) c32* lds_vptr;
+    *(lds_vptr)(p) = v;
+#else
+    *p = v;
+#endif
+}
+
 constexpr int kM = 16384;            // complex points of one block FFT
 constexpr int kB = 16384;            // real samples of one partition block (FFT covers 2*kB)
 constexpr int kT = 1024;             // threads per workgroup
@@ -357,7 +367,7 @@ __device__ __forceinline__ void pass2(c32* lds, c32 wbase, int t) {
     fft16<INV>(x);
     if (!INV) twiddle16<false>(x, w);
 #pragma unroll
-    for (int b = 0; b < 16; ++b) base[65 * b] = x[b];
+    for (int b = 0; b < 16; ++b) lds_st(base + 65 * b, x[b]);
 }
 
 // pass 3 forward: read layout A, write layout B.  thread = d*256 + ab.
@@ -370,7 +380,7 @@ __device__ __forceinline__ void pass3_fwd_tail(c32* dst, c32 (&x)[16]) {
     if (D) twiddle16_const<false, D>(x);
     lds_barrier();                       // every layout-A read done before layout-B writes
 #pragma unroll
-    for (int c = 0; c < 16; ++c) dst[c] = x[c];
+    for (int c = 0; c < 16; ++c) lds_st(dst + c, x[c]);
 }
 __device__ __forceinline__ void pass3_fwd(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
@@ -394,7 +404,7 @@ __device__ __forceinline__ void pass3_inv_tail(c32* dst, c32 (&x)[16]) {
     fft16<true>(x);
     lds_barrier();
 #pragma unroll
-    for (int c = 0; c < 16; ++c) dst[4 * c] = x[c];
+    for (int c = 0; c < 16; ++c) lds_st(dst + 4 * c, x[c]);
 }
 __device__ __forceinline__ void pass3_inv(c32* lds, int t) {
     const int d = t >> 8, ab = t & 255;
@@ -495,7 +505,7 @@ __device__ __forceinline__ void item_store_inv(c32* lds, c32 wbase, int q, c32 (
     bfly4<true>(y[0], y[1], y[2], y[3]);
     bfly4<true>(y[4], y[5], y[6], y[7]);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) { pa[4352 * d] = y[d]; pb[4352 * d] = y[4 + d]; }
+    for (int d = 0; d < 4; ++d) { lds_st(pa + 4352 * d, y[d]); lds_st(pb + 4352 * d, y[4 + d]); }
 }
 
 }  // namespace ssk

@@ -79,7 +79,7 @@ __device__ __forceinline__ void pass1_fwd(c32* lds, c32 wbase, int t, LOADER loa
     twiddle16<false>(x, w);
     c32* base = lds + t + (t >> 6);             // posA(t + 1024*a) = t + (t>>6) + 1040*a
 #pragma unroll
-    for (int a = 0; a < 16; ++a) base[1040 * a] = x[a];
+    for (int a = 0; a < 16; ++a) lds_st(base + 1040 * a, x[a]);
 }
 
 // pass 1 inverse: LDS layout A -> registers; only the upper half (packed samples 8192..16383, i.e. the
@@ -201,14 +201,14 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
     SSK_OPAQUE2(wq);
     twiddle16<false>(x, wq);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
+    for (int r = 0; r < 16; ++r) lds_st(fr + r * 17 + q, x[r]);
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
     fft16<false>(x);                         // x[s] = Z[q + 16 s]
     wave_sync();
 #pragma unroll
-    for (int s = 0; s < 16; ++s) fn[q + posN(16 * s)] = x[s];   // posN(q + 16 s) = q + posN(16 s)
+    for (int s = 0; s < 16; ++s) lds_st(fn + q + posN(16 * s), x[s]);   // posN(q + 16 s) = q + posN(16 s)
     wave_sync();
     // |rFFT_512| pooled over 4 bins.  Bins come in Hermitian pairs (k, 256-k) that share P, Q and w*Q, so a lane
     // takes the pooled rows b = q and q+16 (bins 4b..4b+3 < 128) together with their mirror bins 256-4b-e:
@@ -426,7 +426,7 @@ __device__ __forceinline__ void stft_power(c32* sc, int lane, c32 wq, const c32*
     SSK_OPAQUE2(wq);
     twiddle16<false>(x, wq);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
+    for (int r = 0; r < 16; ++r) lds_st(fr + r * 17 + q, x[r]);
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
@@ -577,7 +577,7 @@ __device__ __forceinline__ void frame_fft_fwd(c32* tile, c32* nat, int lane, c32
     SSK_OPAQUE2(wq);
     twiddle16<false>(x, wq);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fr[r * 17 + q] = x[r];
+    for (int r = 0; r < 16; ++r) lds_st(fr + r * 17 + q, x[r]);
     wave_sync();
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = lds_ld(fr + q * 17 + r);
