@@ -39,6 +39,14 @@ extern "C" {
 #define SS_PAD_CONSTANT 1  /* librosa >= 0.10 default */
 /* flags: promises from the caller that let the library pick a leaner kernel */
 #define SS_FLAG_NO_DISTRACTOR 1  /* term 1 of every unit descriptor is absent ([4] == -1); it is then ignored */
+/* SoundSpaces 2.0 CROSSFADE (soundspaces/continuous_simulator.py:47-53, 422-424): term 1 of a unit descriptor is the
+ * PREVIOUS step's RIR (`_last_rir`), not a distractor: where it is present the row is
+ *   out[:, n] = conv(term 1)[n] * (F - n)/F + conv(term 0)[n] * n/F   for n <= F = int(0.05 * out_len),
+ *   out[:, n] = conv(term 0)[n]                                         beyond
+ * (rows are 1 s long in both simulators, so out_len is the sampling rate); units whose term 1 is absent
+ * (first step of an episode, `_last_rir is None`) are not blended.  One launch; with ss_audio_obs_f32 the spectrogram
+ * is taken from the blended row. */
+#define SS_FLAG_CROSSFADE 2
 
 /* Geometry constants of the partitioned convolution. */
 int ss_block_len(void);        /* kB = 16384 real samples per partition block                     */

@@ -357,9 +357,12 @@ def synth_sources(rng, sr, k=4, seconds=1):
 
 def relerr(got, ref):
     """max |got - ref| / max |ref|  — the parity figure of SURVEY.md 8(c)."""
-    ref = np.asarray(ref, dtype=np.float64)
+    ref = np.asarray(ref)
+    got = np.asarray(got)
+    wide = np.complex128 if (np.iscomplexobj(ref) or np.iscomplexobj(got)) else np.float64
+    ref = ref.astype(wide)
     den = np.abs(ref).max()
-    num = np.abs(np.asarray(got, dtype=np.float64) - ref).max()
+    num = np.abs(got.astype(wide) - ref).max()
     return num / den if den > 0 else num
 
 

@@ -57,7 +57,8 @@ inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kP
 template <bool FUSE>
 int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
-    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.rir_cap <= ssk::kB;
+    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && !(flags & SS_FLAG_CROSSFADE) && nb_y == 1 && p.rir_cap <= ssk::kB;
+    if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
     const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
     // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
     const bool planar = p.rir_elem_stride == 1 && !(p.rir_cap & 1) && !(reinterpret_cast<size_t>(p.rir) & 7) &&
@@ -69,7 +70,8 @@ int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, int 
             return hip_err(hipGetLastError());
         }
     }
-    if (simple) hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+    if (flags & SS_FLAG_CROSSFADE) hipLaunchKernelGGL((ssk::k_conv<FUSE, false, true>), grid, block, 0, st, p);
+    else if (simple) hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }
@@ -123,6 +125,7 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.n_frames = n_frames_of(out_len);
     p.t4 = t4_of(out_len);
     p.pad_mode = 0;
+    p.fade_len = static_cast<int>(0.05 * out_len);     // crossfade_samples = int(0.05 * sr), rows are 1 s (out_len == sr)
     return 0;
 }
 

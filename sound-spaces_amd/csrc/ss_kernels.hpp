@@ -44,6 +44,7 @@ __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b
 
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
 constexpr int kNfft = 512, kHop = 160, kPool = 4, kBins4 = 65;   // 257 bins -> 65 pooled rows
+constexpr int kPrevPairs = 1104;          // XFADE: packed pairs of the cross-fade ramp kept per row (fade_len <= 2206)
 constexpr int kFrameStride = 272;         // transpose tiles (16 x 17 complex per frame); = 16 mod 32 so that the four
                                           // frames of a wave start 32 banks apart (ds_read/write_b64 rules)
 constexpr int kNatStride = 288;           // natural-order spectra per frame; = 0 mod 32 (ds_read_b128 lane groups)
@@ -771,6 +772,7 @@ struct ConvParams {
     int n_valid;                 // samples computed per row (<= gridDim.y*kB); [n_valid, out_len) is zero-filled
     int out_len;                 // row length
     int n_frames, t4, pad_mode;  // spectrogram geometry for the fused path
+    int fade_len;                // XFADE kernels: cross-fade ramp covers samples 0..fade_len (continuous_simulator.py:47-53)
 };
 
 // forward FFT of RIR block i of one ear + multiply by the window spectrum `slot` -> acc (= or +=)
@@ -946,8 +948,14 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
 
 // SIMPLE: the caller guarantees one output block (gridDim.y == 1), RIR capacity <= kB and no distractor term,
 // so a unit is at most ONE forward FFT: straight-line code, no accumulator carried across passes, no scratch.
-template <bool FUSE, bool SIMPLE>
+// XFADE (SoundSpaces 2.0 CROSSFADE, continuous_simulator.py:47-53, 422-424): term 1 of the descriptor is not a
+// distractor to be added but the PREVIOUS step's RIR: the row is convolved with it first, the first fade_len+1 samples
+// of that result (at most two packed pairs per thread) are kept in registers, then the row is convolved with the
+// current RIR (term 0) and the head of the row becomes prev*(fade-n)/fade + cur*n/fade.  One launch, and in the
+// fused kernel the spectrogram is taken from the blended row without it ever leaving the CU.
+template <bool FUSE, bool SIMPLE, bool XFADE = false>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
+    static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
     const int unit = blockIdx.x >> 1, ch = blockIdx.x & 1, j = SIMPLE ? 0 : blockIdx.y;
@@ -1006,41 +1014,80 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 #pragma unroll
             for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
         }
-    } else
-    for (int term = 0; term < 2; ++term) {
-        // descriptor words are workgroup-uniform: keep them in SGPRs
-        // through the scalar cache: two short round trips instead of two vector-memory ones in front of the RIR loads
-        const i32x4 dw = uniform_load4(d + 4 * term);
-        const int ridx = dw.x;
-        if (ridx < 0) continue;
-        const int L = uniform_load(p.rir_len + ridx);
-        const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
-        const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
-        const int nbh = (L + kB - 1) / kB;
-        for (int i = 0; i < nbh; ++i) {
-            const int m = j - i;
-            if (m < m_min || m >= m_min + m_cnt) continue;
-            // lane id made opaque per iteration: otherwise LICM hoists every lane-invariant address and
-            // predicate of the (large) body out of the loop and the 128-VGPR budget spills them all.
+    }
+    // XFADE: the head (samples 0..fade_len <= 4095) of the row convolved with the previous RIR waits here, in the LDS
+    // the FFT buffer leaves free, while the row is convolved with the current RIR: kept in registers it spilled
+    // (the loop kernel already carries the accumulator across the passes at the 128-VGPR cap)
+    __shared__ c32 s_prev[XFADE ? kPrevPairs : 1];
+    bool have_prev = false;
+    if (!SIMPLE) {
+        // XFADE: round 0 = term 1 alone (previous RIR; only block 0 holds ramp samples), round 1 = term 0.
+        // The two rounds are two inlined copies of the body; each works on its own opaque copy of the lane id so that
+        // nothing lane-invariant (addresses, twiddle chains) is shared between the copies and kept alive across them.
+#pragma unroll
+        for (int round = XFADE ? 0 : 1; round < 2; ++round) {
+            const int term_lo = XFADE ? 1 - round : 0, term_hi = XFADE ? term_lo + 1 : 2;
+            if (XFADE && round == 0 && j != 0) continue;
+            bool present = false;
+            any = false;
+            for (int term = term_lo; term < term_hi; ++term) {
+                // descriptor words are workgroup-uniform: keep them in SGPRs
+                // through the scalar cache: two short round trips instead of two vector-memory ones in front of the RIR loads
+                const i32x4 dw = uniform_load4(d + 4 * term);
+                const int ridx = dw.x;
+                if (ridx < 0) continue;
+                present = true;
+                const int L = uniform_load(p.rir_len + ridx);
+                const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
+                const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
+                const int nbh = (L + kB - 1) / kB;
+                for (int i = 0; i < nbh; ++i) {
+                    const int m = j - i;
+                    if (m < m_min || m >= m_min + m_cnt) continue;
+                    // lane id made opaque per iteration: otherwise LICM hoists every lane-invariant address and
+                    // predicate of the (large) body out of the loop and the 128-VGPR budget spills them all.
+                    int tl = t;
+                    SSK_OPAQUE1(tl);
+                    if (!any) {
+                        conv_block<false, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
+                        any = true;
+                    } else {
+                        lds_barrier();                   // previous block's item reads of layout B are done
+                        conv_block<true, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
+                    }
+                }
+            }
+            if (XFADE && round == 0 && !present) continue;   // no previous RIR (first step of an episode): no blend
             int tl = t;
-            SSK_OPAQUE1(tl);
-            if (!any) {
-                conv_block<false, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
-                any = true;
+            if (XFADE) SSK_OPAQUE1(tl);
+            if (any) {
+                lds_barrier();
+                items_to_time(lds, tw, tl, acc, y);
             } else {
-                lds_barrier();                   // previous block's item reads of layout B are done
-                conv_block<true, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+            }
+            if (XFADE && round == 0) {
+                have_prev = true;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (tl + 1024 * a < kPrevPairs) s_prev[tl + 1024 * a] = y[a];
+                lds_barrier();                           // pass-1' reads of layout A done before the next pass 1 writes it
             }
         }
-    }
-
-    if (!SIMPLE) {
-        if (any) {
-            lds_barrier();
-            items_to_time(lds, tw, t, acc, y);
-        } else {
+        if (XFADE && have_prev) {
+            // crossfade(): x1[:, :n+1] * flip(arange(n+1)/n) + x2[:, :n+1] * (arange(n+1)/n), n = fade_len
+            const float fl = (float)p.fade_len;
 #pragma unroll
-            for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+            for (int a = 0; a < 2; ++a) {
+                const int m = t + 1024 * a, n0 = 2 * m;
+                if (n0 <= p.fade_len) {                  // own slot: written by this thread, no barrier needed
+                    const c32 yp = s_prev[m];
+                    y[a].x = yp.x * ((float)(p.fade_len - n0) / fl) + y[a].x * ((float)n0 / fl);
+                    if (n0 + 1 <= p.fade_len)
+                        y[a].y = yp.y * ((float)(p.fade_len - n0 - 1) / fl) + y[a].y * ((float)(n0 + 1) / fl);
+                }
+            }
         }
     }
     store_row_block(p, t, (size_t)unit * 2 + ch, j, y);

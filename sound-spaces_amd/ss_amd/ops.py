@@ -17,6 +17,7 @@ from .planning import KB, SPEC_FLOATS, ceil_div, spectrogram_shape
 
 PAD_REFLECT, PAD_CONSTANT = 0, 1
 FLAG_NO_DISTRACTOR = 1      # SS_FLAG_NO_DISTRACTOR: every unit descriptor has term 1 absent
+FLAG_CROSSFADE = 2          # SS_FLAG_CROSSFADE: term 1 = previous step's RIR, blended over the first int(0.05*sr)+1 samples
 
 _PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
 
@@ -185,10 +186,10 @@ def _register():
     lib = torch.library.Library("ss_hip", "DEF")
     lib.define("source_windows(Tensor src, Tensor win_desc) -> Tensor")
     lib.define("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, "
-               "int out_len, bool interleaved=False) -> Tensor")
+               "int out_len, bool interleaved=False, int flags=0) -> Tensor")
     lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
     lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
-               "int pad_mode=0, bool interleaved=False) -> (Tensor, Tensor)")
+               "int pad_mode=0, bool interleaved=False, int flags=0) -> (Tensor, Tensor)")
     lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
     lib.define("gccphat(Tensor x, int max_lag=32, float eps=1e-8, int pad_mode=0) -> Tensor")
     lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0: gccphat(x, max_lag, eps, pad_mode), "CUDA")
@@ -204,17 +205,17 @@ def _register():
     lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
     lib.impl("spectrogram", lambda x, pad_mode=0: spectrogram(x, pad_mode), "CUDA")
 
-    def _audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode=0, interleaved=False):
-        ag, sg = audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode, True, interleaved)
+    def _audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode=0, interleaved=False, flags=0):
+        ag, sg = audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode, True, interleaved, flags)
         return ag, sg
     lib.impl("audio_obs", _audio_obs, "CUDA")
 
     # shape functions (Meta) so the ops compose with tracing / fake tensors
     lib.impl("source_windows", lambda src, wd: src.new_empty((wd.shape[0], SPEC_FLOATS)), "Meta")
-    lib.impl("fftconv_binaural", lambda spec, b, l, d, n_valid, out_len, interleaved=False:
+    lib.impl("fftconv_binaural", lambda spec, b, l, d, n_valid, out_len, interleaved=False, flags=0:
              spec.new_empty((d.shape[0], 2, out_len)), "Meta")
     lib.impl("spectrogram", lambda x, pad_mode=0: x.new_empty((x.shape[0],) + spectrogram_shape(x.shape[2])), "Meta")
-    lib.impl("audio_obs", lambda spec, b, l, d, n_valid, out_len, pad_mode=0, interleaved=False:
+    lib.impl("audio_obs", lambda spec, b, l, d, n_valid, out_len, pad_mode=0, interleaved=False, flags=0:
              (spec.new_empty((d.shape[0], 2, out_len)), spec.new_empty((d.shape[0],) + spectrogram_shape(out_len))),
              "Meta")
     return lib

@@ -104,6 +104,15 @@ class UnitRequest:
     silent: bool = False
     dis_sound: int = -1
     dis_rir: int = -1
+    # SoundSpaces 2.0 only (renderer built with wrap=True):
+    # wrap: the reference wraps the clip around ONLY in its steady branch (continuous_simulator.py:438-447,
+    #   index >= rir length); the early branch slices source[:index+num_sample] and reads zeros past the clip end
+    #   (:433-437).  None = "steady branch" (wrap), False = early branch.
+    # last_rir: bank slot of the previous step's RIR (`_last_rir`) for CROSSFADE (:422-424), -1 = none; last_wrap is
+    #   the branch `_convolve_with_rir(self._last_rir)` takes for THAT RIR's length.
+    wrap: Optional[bool] = None
+    last_rir: int = -1
+    last_wrap: Optional[bool] = None
 
 
 @dataclass
@@ -173,38 +182,66 @@ class BatchedAudioRenderer:
             wd_dev = torch.from_numpy(np.ascontiguousarray(wd)).to(self.device)
             ops.source_windows_into(self.sources.flat(), wd_dev, self._spec[first:first + len(wd)])
 
+    def _wrap_of(self, sound: int, t0: int, wrap: Optional[bool]) -> bool:
+        """Effective wrap flag of a window key: only SS2.0 renderers wrap, only in the reference's steady branch, and
+        only windows that actually run past the clip end differ from the non-wrapping ones (fewer distinct keys)."""
+        if not self.wrap or wrap is False:
+            return False
+        return t0 + self.n_valid > self.sources.lengths[sound]
+
     def plan(self, units: Sequence[UnitRequest]) -> Plan:
         """-> unit descriptors (int32 [N, 8]) on the device; computes any missing source-window spectra."""
         assert self.rirs is not None, "set_rir_bank() first"
-        keys = []
+        keys, ukeys = [], []
         for u in units:
+            k0 = k1 = None
             if not u.silent and u.rir >= 0:
-                keys.append((u.sound, u.t0, self.wrap))
-                if u.dis_rir >= 0:
-                    keys.append((u.dis_sound, 0, False))          # distractor: whole clip, full conv (:659-664)
+                k0 = (u.sound, u.t0, self._wrap_of(u.sound, u.t0, u.wrap))
+                keys.append(k0)
+                if u.last_rir >= 0:                               # CROSSFADE: same window, previous RIR's branch
+                    assert u.dis_rir < 0, "a unit carries either a distractor or a previous RIR in term 1"
+                    k1 = (u.sound, u.t0, self._wrap_of(u.sound, u.t0, u.wrap if u.last_wrap is None else u.last_wrap))
+                    keys.append(k1)
+                elif u.dis_rir >= 0:
+                    k1 = (u.dis_sound, 0, False)                  # distractor: whole clip, full conv (:659-664)
+                    keys.append(k1)
+            ukeys.append((k0, k1))
         self._ensure_windows(keys)
         desc = np.zeros((len(units), 8), np.int32)
         flags = ops.FLAG_NO_DISTRACTOR
+        xfade = any(u.last_rir >= 0 and not u.silent and u.rir >= 0 for u in units)
         for n, u in enumerate(units):
-            if u.silent or u.rir < 0:
+            k0, k1 = ukeys[n]
+            if k0 is None:
                 desc[n] = P.unit_desc_row()
                 continue
-            s0, ws = self._windows[(u.sound, u.t0, self.wrap)]
-            if u.dis_rir >= 0:
-                d0, dws = self._windows[(u.dis_sound, 0, False)]
-                desc[n] = P.unit_desc_row(u.rir, s0, ws, u.dis_rir, d0, dws)
+            s0, ws = self._windows[k0]
+            if k1 is not None:
+                assert xfade == (u.last_rir >= 0), "cross-faded and distractor units cannot share a launch"
+                d0, dws = self._windows[k1]
+                desc[n] = P.unit_desc_row(u.rir, s0, ws, u.last_rir if xfade else u.dis_rir, d0, dws)
                 flags = 0
             else:
                 desc[n] = P.unit_desc_row(u.rir, s0, ws)
+        if xfade:
+            flags = ops.FLAG_CROSSFADE
         return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), flags)
 
-    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> Plan:
+    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray, rotations: int = 1) -> Plan:
         """Vectorised plan() for the common no-distractor case (rir < 0 = silent): the per-step host cost is a handful
-        of numpy operations on the N-vectors plus one dict lookup per *distinct* (sound, t0) pair."""
+        of numpy operations on the N-vectors plus one dict lookup per *distinct* (sound, t0) pair.
+        ``rotations`` = R > 1: every env yields R units (unit n*R + k) that hear the same clip window through the R
+        ADJACENT bank rows rir[n] + k -- the azimuths of one (receiver, source) pair stored side by side
+        (RirStore(group=R); BASELINE configs[2]: "4 agent rotations per step"), so the 2R rows of an env are one
+        contiguous stretch of the bank."""
         assert self.rirs is not None, "set_rir_bank() first"
         sound = np.asarray(sound, np.int64)
         t0 = np.asarray(t0, np.int64)
         rir = np.asarray(rir, np.int64)
+        if rotations > 1:
+            k = np.arange(rotations, dtype=np.int64)
+            sound, t0 = np.repeat(sound, rotations), np.repeat(t0, rotations)
+            rir = np.where(rir[:, None] >= 0, rir[:, None] + k[None, :], -1).reshape(-1)
         active = rir >= 0
         desc = np.zeros((sound.shape[0], 8), np.int32)
         desc[:, 0] = -1
@@ -247,16 +284,20 @@ class BatchedAudioRenderer:
                                   flags=plan.flags)
         return out
 
-    def render_crossfaded(self, desc_last: Plan, desc_cur: Plan):
-        """SS2.0 CROSSFADE (continuous_simulator.py:47-53, 422-424): the step is convolved with the previous and the
-        current RIR and blended by a linear ramp over int(0.05*sr)+1 samples.  Two convolution launches, a torch
-        blend on the first 801/2206 samples, then the stand-alone spectrogram kernel."""
-        a_last = self.render_audiogoal(desc_last)
-        a_cur = self.render_audiogoal(desc_cur)
-        n = int(0.05 * self.sr)
-        w2 = torch.arange(n + 1, device=self.device, dtype=torch.float32) / n
-        a_cur[:, :, :n + 1] = a_last[:, :, :n + 1] * w2.flip(0) + a_cur[:, :, :n + 1] * w2
-        return a_cur, ops.spectrogram(a_cur, self.pad_mode)
+    def render_crossfaded(self, units: Sequence[UnitRequest], want_audiogoal: bool = True):
+        """SS2.0 CROSSFADE (continuous_simulator.py:47-53, 422-424) in ONE launch: every unit carries the previous
+        step's RIR in ``last_rir``; the loop kernel convolves the step with it first, keeps the ramp's
+        int(0.05*sr)+1 samples on the CU, convolves with the current RIR and blends in registers; the spectrogram is
+        taken from the blended row (fused at 16 kHz).  Returns (audiogoal or None, spectrogram)."""
+        return self.render(self.plan(units), want_audiogoal=want_audiogoal)
+
+
+def _planar(rir) -> np.ndarray:
+    """float32 [2, L] from a wav-layout [L, 2] / planar [2, L] array; None / empty -> [2, 0]."""
+    if rir is None or not np.size(rir):
+        return np.zeros((2, 0), np.float32)
+    r = np.asarray(rir, dtype=np.float32)
+    return r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
 
 
 class RirStore:
@@ -265,60 +306,143 @@ class RirStore:
     The reference re-reads ``<rir_dir>/<azimuth>/<recv>_<src>.wav`` from disk on every cache-missing step
     (simulator.py:615-618); here the first visit of a pose pays that read + one H2D copy and later visits read HBM.
     Live RIRs (SS2.0 / habitat_sim audio sensor: a new RIR every step) use a per-env key with ``refresh=True``.
-    Rows are zeroed beyond the RIR's length (precondition of the kernel); RIRs longer than ``cap`` are truncated,
-    which is exact for 1-s clips as long as cap >= sr (only h[0:sr] reaches y[0:sr])."""
+    Rows are zeroed beyond the RIR's length (precondition of the kernel).
 
-    def __init__(self, slots: int, cap: int, device):
+    Row capacity.  ``truncate_to = n`` keeps only h[0:n] of every RIR: exact as long as every clip is a 1-s clip
+    convolved from its start (simulator.py:629-632: only h[0:sr] reaches y[0:sr]) and keeps rows <= one partition
+    block (the loop-free kernel).  With ``truncate_to = None`` (multi-second sounds, simulator.py:634-647, and SS2.0,
+    whose outputs depend on the whole RIR) nothing is ever cut: a longer RIR GROWS the bank (reallocated at the new
+    capacity, contents kept, ``on_grow(bank)`` tells the renderer), up to ``max_cap`` samples, beyond which it raises.
+
+    ``group`` > 1 stores the entries of one key in ``group`` ADJACENT slots (the 4 azimuths of one (receiver, source)
+    pair: SURVEY 8(f)2), loaded and evicted together; ``slot()`` then returns the first slot of the group."""
+
+    def __init__(self, slots: int, cap: int, device, truncate_to: Optional[int] = None, max_cap: int = 1 << 18,
+                 on_grow=None, group: int = 1):
         cap += cap & 1
-        self.bank = RirBank(torch.zeros((slots, 2, cap), dtype=torch.float32, device=device),
-                            torch.zeros((slots,), dtype=torch.int32, device=device))
-        self.slots, self.cap = slots, cap
+        assert slots % group == 0
+        self.device = torch.device(device)
+        self.bank = RirBank(torch.zeros((slots, 2, cap), dtype=torch.float32, device=self.device),
+                            torch.zeros((slots,), dtype=torch.int32, device=self.device))
+        self.slots, self.cap, self.group = slots, cap, group
+        self.truncate_to, self.max_cap, self.on_grow = truncate_to, max_cap, on_grow
+        self.host_len = np.zeros((slots,), np.int32)          # host mirror of bank.lengths (branch selection, planning)
         self._slot_of: Dict[object, int] = {}      # insertion order == LRU order (oldest first)
-        self._free: List[int] = list(range(slots - 1, -1, -1))
-        self.hits = self.misses = 0
+        self._free: List[int] = list(range(slots - group, -1, -group))
+        self._batch = 0
+        self._batch_of = np.full((slots,), -1, np.int64)      # batch in which the slot was last handed out
+        self.hits = self.misses = self.grown = 0
+        self._clipped = np.zeros((slots,), bool)              # the stored row is shorter than its RIR (truncate_to)
+        # pinned staging ring for single-row uploads (a pageable torch copy blocks the host for the whole transfer)
+        self._stage = None
+        self._stage_ev: List = []
+        self._stage_k = 0
 
-    def _upload(self, slot: int, rir: Optional[np.ndarray]) -> None:
-        row = np.zeros((2, self.cap), np.float32)
-        n = 0
-        if rir is not None and np.size(rir):
-            r = np.asarray(rir, dtype=np.float32)
-            r = r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
-            n = min(r.shape[1], self.cap)
-            row[:, :n] = r[:, :n]
-        self.bank.data[slot].copy_(torch.from_numpy(row))
-        self.bank.lengths[slot] = n
+    # ---- batches -----------------------------------------------------------------------------------------
+    def begin_batch(self) -> None:
+        """Slots handed out from here on belong to one launch: none of them may be evicted for another key of the same
+        batch (a store smaller than one step's distinct poses would otherwise render an env with another pose's RIR)."""
+        self._batch += 1
+
+    def clear(self) -> None:
+        """Forget every entry (the rows are rewritten on the next miss)."""
+        self._slot_of.clear()
+        self._free = list(range(self.slots - self.group, -1, -self.group))
+        self.host_len[:] = 0
+        self.bank.lengths.zero_()
+        self._clipped[:] = False
+
+    # ---- capacity ------------------------------------------------------------------------------------------
+    def _kept_len(self, n: int) -> int:
+        return n if self.truncate_to is None else min(n, self.truncate_to)
+
+    def _ensure_cap(self, n: int) -> None:
+        """Make rows at least n samples long (n = what will be stored, i.e. already clipped by truncate_to)."""
+        if n <= self.cap:
+            return
+        if n > self.max_cap:
+            raise ValueError(f"RIR of {n} samples exceeds RirStore.max_cap = {self.max_cap}")
+        new_cap = min(self.max_cap + (self.max_cap & 1), -(-n // 2048) * 2048)
+        data = torch.zeros((self.slots, 2, new_cap), dtype=torch.float32, device=self.device)
+        data[:, :, :self.cap] = self.bank.data
+        self.bank = RirBank(data, self.bank.lengths)
+        self.cap = new_cap
+        self._stage = None
+        self.grown += 1
+        if self.on_grow is not None:
+            self.on_grow(self.bank)
+
+    # ---- uploads ---------------------------------------------------------------------------------------------
+    def _stage_row(self):
+        """-> (pinned [2, cap] staging row as torch + numpy views, its slot in the ring).  CPU stores: plain memory."""
+        if self.device.type != "cuda":
+            t = torch.zeros((2, self.cap), dtype=torch.float32)
+            return t, t.numpy(), -1
+        if self._stage is None:
+            self._stage = torch.zeros((8, 2, self.cap), dtype=torch.float32, pin_memory=True)
+            self._stage_ev = [None] * 8
+        k = self._stage_k % 8
+        self._stage_k += 1
+        if self._stage_ev[k] is not None:
+            self._stage_ev[k].synchronize()                     # the copy that last read this staging row has run
+        return self._stage[k], self._stage[k].numpy(), k
+
+    def _upload(self, slot: int, rir) -> None:
+        r = _planar(rir)
+        n = self._kept_len(r.shape[1])
+        self._clipped[slot] = n < r.shape[1]
+        self._ensure_cap(n)
+        row_t, row, k = self._stage_row()
+        row[:, :n] = r[:, :n]
+        row[:, n:] = 0.0
+        self.bank.data[slot].copy_(row_t, non_blocking=True)
+        if k >= 0:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_ev[k] = ev
+        self.bank.lengths[slot:slot + 1].fill_(n)
+        self.host_len[slot] = n
+
+    def _take_slot(self) -> int:
+        if self._free:
+            return self._free.pop()
+        victim = next(iter(self._slot_of))
+        slot = self._slot_of[victim]
+        if self._batch and self._batch_of[slot] == self._batch:     # (callers that never open a batch: no guard)
+            raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
+                               "(an entry handed out for this launch would be overwritten); raise rir_slots")
+        del self._slot_of[victim]
+        return slot
 
     def slot(self, key, loader, refresh: bool = False) -> int:
-        """Bank slot of ``key``; ``loader()`` -> float array [L,2] / [2,L] or None is only called on a miss
-        (or always with ``refresh=True``: live RIRs that change every step keep their slot)."""
+        """Bank slot of ``key`` (first slot of its group); ``loader()`` -> float array [L,2] / [2,L] or None (a list of
+        ``group`` of them when group > 1) is only called on a miss (or always with ``refresh=True``: live RIRs that
+        change every step keep their slot)."""
         if key in self._slot_of:
             slot = self._slot_of.pop(key)
             self._slot_of[key] = slot                   # most recently used
-            if refresh:
-                self._upload(slot, loader())
+            # a row clipped while only 1-s clips existed is reloaded once whole RIRs are needed (truncate_to = None)
+            if refresh or (self.truncate_to is None and self._clipped[slot:slot + self.group].any()):
+                self._load_into(slot, loader())
             else:
                 self.hits += 1
+            self._batch_of[slot] = self._batch
             return slot
         self.misses += 1
-        if self._free:
-            slot = self._free.pop()
-        else:
-            victim = next(iter(self._slot_of))
-            slot = self._slot_of.pop(victim)
+        slot = self._take_slot()
         self._slot_of[key] = slot
-        self._upload(slot, loader())
+        self._batch_of[slot] = self._batch
+        self._load_into(slot, loader())
         return slot
 
-
-    def _pack(self, rir: Optional[np.ndarray], row: np.ndarray) -> int:
-        row[:] = 0.0
-        if rir is None or not np.size(rir):
-            return 0
-        r = np.asarray(rir, dtype=np.float32)
-        r = r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
-        n = min(r.shape[1], self.cap)
-        row[:, :n] = r[:, :n]
-        return n
+    def _load_into(self, slot: int, loaded) -> None:
+        if self.group == 1:
+            self._upload(slot, loaded)
+            return
+        loaded = list(loaded) if loaded is not None else [None] * self.group
+        assert len(loaded) == self.group
+        for k, r in enumerate(loaded):
+            self._upload(slot + k, r)
 
     def slot_many(self, keys: Sequence, loaders: Sequence, workers: int = 8) -> List[int]:
         """Slots of many keys at once (scene load, `AudioGoalBatcher`): the misses' loaders run on a thread pool
@@ -326,47 +450,56 @@ class RirStore:
         plus one row scatter, instead of one 128 KB copy per file.  Same LRU semantics as `slot()`; a batch must fit the
         store (its slots are returned together, so none of them may evict another)."""
         from concurrent.futures import ThreadPoolExecutor
+        G = self.group
         out: List[int] = [-1] * len(keys)
         todo = []
+        if len(set(keys)) > self.slots // G:
+            raise ValueError(f"slot_many: {len(set(keys))} distinct keys do not fit a store of {self.slots // G} entries")
+        self.begin_batch()
         for i, key in enumerate(keys):
             if key in self._slot_of:
                 out[i] = self.slot(key, loaders[i])
             else:
                 todo.append(i)
-        # duplicates inside the batch load once
         first = {}
-        for i in todo:
+        for i in todo:                                   # duplicates inside the batch load once
             first.setdefault(keys[i], i)
         uniq = list(first.values())
-        if len(set(keys)) > self.slots:
-            raise ValueError(f"slot_many: {len(set(keys))} distinct keys do not fit a store of {self.slots} slots")
-        # keys of this batch that are already resident must survive the evictions below: make them most recent
-        for lo in range(0, len(uniq), self.slots):
-            part = uniq[lo:lo + self.slots]
+        chunk = max(1, 256 // G)
+        for lo in range(0, len(uniq), chunk):
+            part = uniq[lo:lo + chunk]
             if workers > 1 and len(part) > 1:
                 with ThreadPoolExecutor(max_workers=workers) as pool:
-                    rirs = list(pool.map(lambda i: loaders[i](), part))
+                    loaded = list(pool.map(lambda i: loaders[i](), part))
             else:
-                rirs = [loaders[i]() for i in part]
-            stage = torch.zeros((len(part), 2, self.cap), dtype=torch.float32,
-                                pin_memory=self.bank.data.device.type == "cuda")
+                loaded = [loaders[i]() for i in part]
+            rows = []
+            for item in loaded:
+                item = [item] if G == 1 else (list(item) if item is not None else [None] * G)
+                assert len(item) == G
+                rows += [_planar(r) for r in item]
+            kept = [self._kept_len(r.shape[1]) for r in rows]
+            self._ensure_cap(max(kept + [0]))
+            stage = torch.zeros((len(rows), 2, self.cap), dtype=torch.float32, pin_memory=self.device.type == "cuda")
             stage_np = stage.numpy()
-            lens = np.zeros((len(part),), np.int32)
+            lens = np.asarray(kept, np.int32)
             slots = []
             for j, i in enumerate(part):
-                lens[j] = self._pack(rirs[j], stage_np[j])
                 self.misses += 1
-                if self._free:
-                    sl = self._free.pop()
-                else:
-                    victim = next(iter(self._slot_of))
-                    sl = self._slot_of.pop(victim)
+                sl = self._take_slot()
                 self._slot_of[keys[i]] = sl
-                slots.append(sl)
-            dev = self.bank.data.device
-            idx = torch.as_tensor(slots, dtype=torch.long, device=dev)
-            self.bank.data.index_copy_(0, idx, stage.to(dev, non_blocking=True))
-            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(dev))
+                self._batch_of[sl] = self._batch
+                for g in range(G):
+                    r, n = rows[j * G + g], kept[j * G + g]
+                    stage_np[j * G + g, :, :n] = r[:, :n]
+                    slots.append(sl + g)
+            idx = torch.as_tensor(slots, dtype=torch.long, device=self.device)
+            self.bank.data.index_copy_(0, idx, stage.to(self.device, non_blocking=True))
+            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
+            self.host_len[np.asarray(slots)] = lens
+            self._clipped[np.asarray(slots)] = [n < r.shape[1] for n, r in zip(kept, rows)]
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()   # the pinned block dies with this scope
         for i in todo:
             out[i] = self._slot_of[keys[i]]
         return out
@@ -394,19 +527,36 @@ def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 
 
 
 class AudioEngine:
-    """Renderer + RIR store + source registry: what ``ss_amd.sim_audio`` talks to (one per process / GPU)."""
+    """Renderer + RIR store + source registry: what ``ss_amd.sim_audio`` talks to (one per process / GPU).
+
+    RIR rows: as long as every registered clip is a 1-s clip (SoundSpaces 1.0 default sounds) only h[0:sr] can reach
+    the observation (simulator.py:629-632), so rows are clipped to sr samples and the loop-free kernel runs.  The first
+    multi-second clip (simulator.py:634-647: the window also hears the reverb tail of earlier seconds) or an SS2.0
+    renderer (``step_time``) switches the store to full-length rows: rows that had been clipped reload at their next
+    use, longer RIRs grow the bank (RirStore)."""
 
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
-                 **renderer_kwargs):
+                 rir_max_cap: int = 1 << 18, rir_group: int = 1, **renderer_kwargs):
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
-        self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device)
+        full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
+        self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device,
+                              truncate_to=None if full else int(sampling_rate), max_cap=rir_max_cap,
+                              on_grow=self.renderer.set_rir_bank, group=rir_group)
         self.renderer.set_rir_bank(self.store.bank)
 
     def source_id(self, name: str, clip: np.ndarray) -> int:
+        if self.store.truncate_to is not None and np.shape(clip)[0] != self.renderer.sr:
+            self.store.truncate_to = None          # from now on whole RIRs; clipped rows reload at their next use
         return self.renderer.add_source(name, clip)
+
+    def begin_batch(self) -> None:
+        self.store.begin_batch()
 
     def rir_slot(self, key, loader, refresh: bool = False) -> int:
         return self.store.slot(key, loader, refresh)
+
+    def rir_len(self, slot: int) -> int:
+        return int(self.store.host_len[slot])
 
     def observe(self, units: Sequence[UnitRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None) -> Dict[str, torch.Tensor]:

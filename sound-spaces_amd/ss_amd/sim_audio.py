@@ -11,6 +11,9 @@ installs them on a live ``SoundSpacesSim`` so the reference's own sensors keep w
 caches live on the simulator object under the reference's attribute names, so the simulator's own
 ``reconfigure`` (simulator.py:395-397) keeps clearing them.
 
+``HipContinuousSimAudio`` / ``attach_continuous()`` do the same for ``ContinuousSoundSpacesSim``
+(soundspaces/continuous_simulator.py:413-462: live RIR, 0.25-s steps, cross-fade, no caches).
+
 ``VectorAudioObserver`` is the *batched* mode: it collects one request per env of an in-process vector env
 (ss_baselines/common/sync_vector_env.py) and renders all of them in one launch straight into a device tensor —
 what replaces the per-env sensor call + ``batch_obs`` (ss_baselines/common/utils.py:126-153) for the audio keys.
@@ -26,13 +29,21 @@ import numpy as np
 from .renderer import UnitRequest
 
 
-def wav_rir_reader(path: str) -> Optional[np.ndarray]:
-    """simulator.py:615-624: float32 [L,2] from a wav, or None (-> zero RIR) when unreadable / empty."""
+def wav_rir_reader(path: str, lenient: bool = False) -> Optional[np.ndarray]:
+    """simulator.py:615-624: float32 [L,2] from a wav, or None (-> zero RIR) when the file is not a readable wav
+    (``ValueError``, the only exception the reference catches, :617-620) or empty.  A MISSING file propagates, as it
+    does in the reference: a wrong ``binaural_rir_dir`` must not turn into a run of all-zero observations.
+    ``lenient=True`` also maps FileNotFoundError / OSError to the zero RIR (partial RIR sets)."""
     from scipy.io import wavfile
     try:
         _, rir = wavfile.read(path)
-    except (ValueError, FileNotFoundError, OSError):
+    except ValueError:
         logging.warning("%s file is not readable", path)
+        return None
+    except OSError:
+        if not lenient:
+            raise
+        logging.warning("%s file is missing", path)
         return None
     if len(rir) == 0:
         logging.debug("Empty RIR file at %s", path)
@@ -93,6 +104,8 @@ class HipSimAudio:
 
     # ---- the reference API ----------------------------------------------------------------------------------
     def _compute(self, want_spectrogram: bool):
+        if hasattr(self.engine, "begin_batch"):
+            self.engine.begin_batch()
         out = self.engine.observe([self.unit_request()], want_audiogoal=True, want_spectrogram=want_spectrogram)
         ag = out["audiogoal"][0].cpu().numpy()
         sg = out["spectrogram"][0].cpu().numpy() if want_spectrogram else None
@@ -142,6 +155,103 @@ def attach(sim, engine, rir_reader=wav_rir_reader) -> HipSimAudio:
     return backend
 
 
+class HipContinuousSimAudio:
+    """Audio of ``ContinuousSoundSpacesSim`` (SoundSpaces 2.0; the reference's default DD-PPO mode,
+    ss_baselines/av_nav/single_node.sh:14) on the HIP path:
+
+        sim._compute_audiogoal()                               soundspaces/continuous_simulator.py:413-426
+        sim._convolve_with_rir(rir)                            soundspaces/continuous_simulator.py:428-456
+        sim.get_current_audiogoal_observation()                :458-459   (uncached)
+        sim.get_current_spectrogram_observation(fn)            :461-462   (uncached)
+
+    State read, exactly what the reference reads: ``_episode_step_count`` / ``_duration`` (silence), the live RIR
+    ``_prev_sim_obs["audio_sensor"]`` ([2][L] from the ray tracer, transposed at :419), ``_last_rir`` and
+    ``config.AUDIO.CROSSFADE`` (:422-424), ``_current_sample_index`` (advanced by the simulator's own ``step``, :389-390),
+    ``config.STEP_TIME``, ``current_source_sound`` (1-s clips already tiled x3 by ``_load_single_source_sound``,
+    :408-410).  The engine must be an SS2.0 one: ``AudioEngine(sr, step_time=STEP_TIME, wrap=True)``.
+
+    Live RIRs change every step, so each env owns two bank slots used alternately: the RIR uploaded as "current" at
+    step k is the "previous" RIR of step k+1 and is recognised by content (``_last_rir`` is a fresh transposed copy in
+    the simulator), so a cross-faded step uploads ONE new RIR, not two, and the two sensors of a step (audiogoal and
+    spectrogram both call ``_compute_audiogoal`` in the reference) upload it once."""
+
+    def __init__(self, sim, engine):
+        self.sim, self.engine = sim, engine
+        self._held = [None, None]             # the arrays living in this env's two live slots
+        self._slots = [-1, -1]
+        self._turn = 0
+        r = getattr(engine, "renderer", None)
+        if r is not None:
+            want = int(self.sr * float(sim.config.STEP_TIME))
+            if r.n_valid != want or not r.wrap:
+                raise ValueError(f"continuous simulator needs AudioEngine(sr, step_time={sim.config.STEP_TIME}, wrap=True); "
+                                 f"got n_valid={r.n_valid}, wrap={r.wrap}")
+
+    @property
+    def sr(self) -> int:
+        return int(self.sim.config.AUDIO.RIR_SAMPLING_RATE)
+
+    def _live_slot(self, rir: np.ndarray, avoid: int = -1) -> int:
+        """Bank slot holding ``rir`` ([L, 2] wav layout); uploads into this env's other live slot unless one of the
+        two already holds exactly this array."""
+        for k in (0, 1):
+            h = self._held[k]
+            if h is not None and (h is rir or (h.shape == rir.shape and np.array_equal(h, rir))):
+                return self._slots[k]
+        k = self._turn
+        if self._slots[k] == avoid and avoid >= 0:
+            k ^= 1
+        self._turn = k ^ 1
+        self._held[k] = rir
+        self._slots[k] = self.engine.rir_slot(("live", id(self.sim), k), lambda: rir, refresh=True)
+        return self._slots[k]
+
+    def unit_request(self) -> UnitRequest:
+        sim = self.sim
+        if sim._episode_step_count > sim._duration:                                                  # :415
+            return UnitRequest(silent=True)
+        clip = sim.current_source_sound
+        sound = self.engine.source_id(sim._current_sound, clip)
+        rir = np.transpose(np.asarray(sim._prev_sim_obs["audio_sensor"], dtype=np.float32))         # :419  [L, 2]
+        index = int(sim._current_sample_index)                                                       # :432
+        cur = self._live_slot(rir)
+        # :433 early branch (index - L < 0): source[:index+num_sample], zeros past the clip end; steady branch wraps
+        req = UnitRequest(sound=sound, t0=index, rir=cur, wrap=index - rir.shape[0] >= 0)
+        last = getattr(sim, "_last_rir", None)
+        if sim.config.AUDIO.CROSSFADE and last is not None:                                          # :422
+            last = np.asarray(last, dtype=np.float32)
+            req.last_rir = self._live_slot(last, avoid=cur)
+            req.last_wrap = index - last.shape[0] >= 0
+        return req
+
+    def _compute(self, want_spectrogram: bool):
+        if hasattr(self.engine, "begin_batch"):
+            self.engine.begin_batch()
+        out = self.engine.observe([self.unit_request()], want_audiogoal=True, want_spectrogram=want_spectrogram)
+        ag = out["audiogoal"][0].cpu().numpy()
+        sg = out["spectrogram"][0].cpu().numpy() if want_spectrogram else None
+        return ag, sg
+
+    def get_current_audiogoal_observation(self):                                                     # :458-459
+        return self._compute(False)[0]
+
+    def get_current_spectrogram_observation(self, audiogoal2spectrogram=None):                       # :461-462
+        if audiogoal2spectrogram is not None and not getattr(audiogoal2spectrogram, "_ss_hip_fused", False):
+            return audiogoal2spectrogram(self.get_current_audiogoal_observation())
+        return self._compute(True)[1]
+
+
+def attach_continuous(sim, engine) -> HipContinuousSimAudio:
+    """Install the HIP audio path on a live ``ContinuousSoundSpacesSim``; the task sensors keep calling
+    ``sim.get_current_*_observation``."""
+    backend = HipContinuousSimAudio(sim, engine)
+    sim.get_current_audiogoal_observation = backend.get_current_audiogoal_observation
+    sim.get_current_spectrogram_observation = backend.get_current_spectrogram_observation
+    sim._compute_audiogoal = lambda: backend._compute(False)[0]
+    sim._ss_hip_audio = backend
+    return backend
+
+
 class VectorAudioObserver:
     """Batched mode: one launch per vector step for all envs of this process."""
 
@@ -151,6 +261,8 @@ class VectorAudioObserver:
     def observe(self, spectrogram_out=None, audiogoal_out=None):
         """-> {"spectrogram": device tensor [N,65,T4,2], ("audiogoal": [N,2,sr])}; cache-free (every env renders its
         current pose), i.e. the reference's HAS_DISTRACTOR_SOUND / continuous behaviour."""
+        if hasattr(self.engine, "begin_batch"):
+            self.engine.begin_batch()                 # no RIR slot of this step may be evicted by another env of it
         units = [b.unit_request() for b in self.backends]
         return self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
                                    want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)

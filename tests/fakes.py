@@ -50,11 +50,69 @@ class FakeSim:
         return self.rir_files.get(path)
 
 
+class FakeContinuousSim:
+    """The attributes of soundspaces.continuous_simulator.ContinuousSoundSpacesSim that its audio code touches
+    (continuous_simulator.py:370-462); `step()` advances them exactly like the reference's `step` (:384-390)."""
+
+    def __init__(self, sr, sounds, rir_fn, step_time=0.25, crossfade=True, start_index=0):
+        self.config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, CROSSFADE=crossfade), STEP_TIME=step_time)
+        self._source_sound_dict = {k: O.tile_short_source(v, sr) for k, v in sounds.items()}      # :408-410
+        self._current_sound = next(iter(sounds))
+        self._episode_step_count = 0
+        self._duration = 500
+        self._rir_fn = rir_fn                       # step number -> [2][L] nested lists, like the habitat_sim audio sensor
+        self._k = 0
+        self._prev_sim_obs = {"audio_sensor": rir_fn(0)}
+        self._last_rir = None                       # reconfigure (:341)
+        self._current_sample_index = start_index    # reconfigure draws randint(sr * STEP_TIME) (:342)
+
+    @property
+    def current_source_sound(self):
+        return self._source_sound_dict[self._current_sound]
+
+    def step(self):
+        self._last_rir = np.transpose(np.array(self._prev_sim_obs["audio_sensor"]))               # :384
+        self._k += 1
+        self._prev_sim_obs = {"audio_sensor": self._rir_fn(self._k)}
+        self._episode_step_count += 1
+        self._current_sample_index = int(self._current_sample_index + self.config.AUDIO.RIR_SAMPLING_RATE *
+                                         self.config.STEP_TIME) % self.current_source_sound.shape[0]   # :389-390
+
+    def reference_audiogoal(self):
+        """continuous_simulator.py:413-426 via the oracle's restatement."""
+        sr = self.config.AUDIO.RIR_SAMPLING_RATE
+        rir = np.transpose(np.array(self._prev_sim_obs["audio_sensor"]))
+        return O.compute_audiogoal_continuous(self.current_source_sound, rir, sr, self._current_sample_index,
+                                              self.config.STEP_TIME, last_rir=self._last_rir,
+                                              use_crossfade=self.config.AUDIO.CROSSFADE,
+                                              silent=self._episode_step_count > self._duration)
+
+
+def window_conv(source, rir, t0, n, wrap):
+    """out[c, t] = sum_k rir[k, c] x[t0 + t - k], t < n, with x = 0 for negative indices and, past the clip end, either
+    0 or (wrap) the clip again from its start -- the UnitRequest semantics, evaluated directly with scipy."""
+    from scipy.signal import fftconvolve
+    S, L = source.shape[0], rir.shape[0]
+    idx = np.arange(t0 - L + 1, t0 + n)
+    seg = np.zeros(idx.shape[0], np.float64)
+    inside = (idx >= 0) & (idx < S)
+    seg[inside] = source[idx[inside]]
+    if wrap:
+        over = (idx >= S) & (idx < 2 * S)
+        seg[over] = source[idx[over] - S]
+    if L == 0:
+        return np.zeros((2, n))
+    return np.stack([fftconvolve(seg, rir[:, c].astype(np.float64), mode="valid") for c in range(2)])
+
+
 class OracleEngine:
-    def __init__(self, sr):
+    def __init__(self, sr, step_time=None):
         self.sr = sr
+        self.n_valid = sr if step_time is None else int(sr * step_time)
+        self.wrap = step_time is not None
         self.sources, self.names, self.rirs, self.keys = [], {}, [], {}
         self.calls = 0
+        self.uploads = 0
 
     def source_id(self, name, clip):
         if name not in self.names:
@@ -66,6 +124,7 @@ class OracleEngine:
         if key in self.keys and not refresh:
             return self.keys[key]
         r = loader()
+        self.uploads += 1
         r = O.zero_rir(self.sr) if r is None else np.asarray(r, np.float32)
         if key in self.keys:
             self.rirs[self.keys[key]] = r
@@ -80,6 +139,15 @@ class OracleEngine:
         for u in units:
             if u.silent or u.rir < 0:
                 a = np.zeros((2, sr), np.float32)
+            elif self.wrap:                       # SS2.0 engine: 0.25-s steps, wrap in the steady branch, cross-fade
+                src = self.sources[u.sound]
+                a = np.zeros((2, sr))
+                a[:, :self.n_valid] = window_conv(src, self.rirs[u.rir], u.t0, self.n_valid, u.wrap is not False)
+                if u.last_rir >= 0:
+                    lw = u.wrap if u.last_wrap is None else u.last_wrap
+                    b = np.zeros((2, sr))
+                    b[:, :self.n_valid] = window_conv(src, self.rirs[u.last_rir], u.t0, self.n_valid, lw is not False)
+                    a = O.crossfade(b, a, sr)
             else:
                 a = O.conv_window_fft(self.sources[u.sound], self.rirs[u.rir], u.t0, sr)
                 if u.dis_rir >= 0:

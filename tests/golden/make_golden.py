@@ -205,6 +205,21 @@ def main():
     add("cont_crossfade", y, sr=sr, src_seed=1, src_k=3, src_sel=0, rir_seed=8, rir_len=9000, rir_n=2,
         rir_sel=0, last_rir_sel=1, sample_index=20000, step_time=0.25)
 
+    # ---- early branch running past the clip end (:433-437): a 3.1-s RIR (irTime allows up to 4 s), index < L, and
+    # index + num_sample > len(source): the slice source[:index+num_sample] just ends, i.e. ZEROS past the clip end,
+    # not the wrap-around of the steady branch
+    rl = O.synth_rir(np.random.default_rng(9), sr, length=50000, n=2)
+    rl = rl * np.exp(-np.arange(50000) / 20000.0)[None, None, :].astype(np.float32)
+    y = run_cont(sr, src3, wav_layout(rl[0]), 46000)
+    add("cont_early_past_end", y, sr=sr, src_seed=1, src_k=3, src_sel=0, rir_seed=9, rir_len=50000, rir_n=2,
+        rir_sel=0, rir_decay=20000, sample_index=46000, step_time=0.25)
+    # ---- cross-fade whose two RIRs take DIFFERENT branches: current RIR 9000 taps (steady, wraps), previous RIR
+    # 50000 taps (early, zeros past the end), both at index 46000
+    y = run_cont(sr, src3, wav_layout(rc[0]), 46000, last_rir=wav_layout(rl[1]).astype(np.float64), use_crossfade=True)
+    add("cont_crossfade_mixed", y, sr=sr, src_seed=1, src_k=3, src_sel=0, rir_seed=8, rir_len=9000, rir_n=2, rir_sel=0,
+        last_rir_seed=9, last_rir_len=50000, last_rir_n=2, last_rir_pick=1, rir_decay_last=20000, sample_index=46000,
+        step_time=0.25)
+
     # ---- savi AudioGoalDataset.compute_audiogoal (random index stubbed)
     class FakeRandom:
         idx = 0

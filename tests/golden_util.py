@@ -41,8 +41,16 @@ def case_inputs(name):
         d["rir"] = np.ascontiguousarray(bank[p.get("rir_sel", 0)].T)
         if "dis_rir_sel" in p:
             d["distractor_rir"] = np.ascontiguousarray(bank[p["dis_rir_sel"]].T)
+        if "rir_decay" in p:
+            bank = bank * np.exp(-np.arange(L) / float(p["rir_decay"]))[None, None, :].astype(np.float32)
+            d["rir"] = np.ascontiguousarray(bank[p.get("rir_sel", 0)].T)
         if "last_rir_sel" in p:
             d["last_rir"] = np.ascontiguousarray(bank[p["last_rir_sel"]].T)
+        if "last_rir_seed" in p:
+            Ll = p["last_rir_len"]
+            lb = O.synth_rir(np.random.default_rng(p["last_rir_seed"]), sr, length=Ll, n=p["last_rir_n"])
+            lb = lb * np.exp(-np.arange(Ll) / float(p["rir_decay_last"]))[None, None, :].astype(np.float32)
+            d["last_rir"] = np.ascontiguousarray(lb[p["last_rir_pick"]].T)
     return d
 
 

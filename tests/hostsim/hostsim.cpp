@@ -130,6 +130,9 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.n_frames = 1 + out_len / ssk::kHop;
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
+    p.fade_len = static_cast<int>(0.05 * out_len);
+    const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
+    if (xfade) simple = 0;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (persist > 0) {                                  // k_conv_rows: `persist` workgroups walk the 2*n_units rows
@@ -149,7 +152,8 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
         for (int b = 0; b < 2 * n_units; ++b) {
             blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
             int rc = run_block(ssk::kT, [&] {
-                if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
+                if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
+                else if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
                 else { if (simple) ssk::k_conv<false, true>(p); else ssk::k_conv<false, false>(p); }
             });
             if (rc) return rc;

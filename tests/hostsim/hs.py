@@ -33,9 +33,10 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True, persist=0):
+        interleaved=False, simple=True, persist=0, crossfade=False):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
-    {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent).
+    {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
+    {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
     Returns (audiogoal [N,2,out_len], spectrogram [N,65,T4,2] or None)."""
     L = lib()
     rir_bank = np.ascontiguousarray(rir_bank, dtype=np.float32)
@@ -60,7 +61,10 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
             desc[n] = P.unit_desc_row()
             continue
         s0, ws = slot_of(u["sound"], u["t0"], u.get("wrap", False))
-        if u.get("dis_rir", -1) >= 0:
+        if crossfade and u.get("last_rir", -1) >= 0:
+            d0, dws = slot_of(u["sound"], u["t0"], u.get("last_wrap", u.get("wrap", False)))
+            desc[n] = P.unit_desc_row(u["rir"], s0, ws, u["last_rir"], d0, dws)
+        elif u.get("dis_rir", -1) >= 0:
             d0, dws = slot_of(u["dis_sound"], u.get("dis_t0", 0), False)
             desc[n] = P.unit_desc_row(u["rir"], s0, ws, u["dis_rir"], d0, dws)
         else:
@@ -81,6 +85,8 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     else:
         bank, us, cs, es = rir_bank, 2 * cap, cap, 1
     simple = int(simple and not any(u.get("dis_rir", -1) >= 0 for u in units) and cap <= P.KB and nby == 1)
+    if crossfade:
+        simple = 2
     rc = L.hs_conv(int(fuse), simple, _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
                    _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
                    N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode, persist)

@@ -108,16 +108,94 @@ def test_continuous_simulator(name):
     check(sg[0].cpu().numpy(), ref_s)
 
 
-def test_continuous_crossfade():
+@pytest.mark.parametrize("name", ["cont_crossfade", "cont_crossfade_mixed", "cont_early_past_end"])
+def test_continuous_crossfade_one_launch(name):
+    """SS2.0 CROSSFADE in ONE fused launch (SS_FLAG_CROSSFADE: previous RIR = term 1, blended on the CU), against the
+    vectors from running the reference's _compute_audiogoal; `mixed` = the two RIRs take different branches
+    (steady+wrap vs early, 50000 taps = 4 partition blocks); `past_end` = the early branch reading zeros past the clip
+    end (no cross-fade) -- the corner ADVICE r1 flagged."""
     from ss_amd.renderer import UnitRequest
-    d = case_inputs("cont_crossfade")
+    d = case_inputs(name)
     sr = d["sr"]
-    ref_a, ref_s, stride = case_outputs("cont_crossfade")
-    r = make_renderer(sr, [O.tile_short_source(d["source"], sr)], [d["rir"], d["last_rir"]], step_time=0.25, wrap=True)
-    ag, sg = r.render_crossfaded(r.plan([UnitRequest(0, d["sample_index"], 1)]),
-                                 r.plan([UnitRequest(0, d["sample_index"], 0)]))
-    check(ag[0].cpu().numpy()[:, ::stride], ref_a)
+    ref_a, ref_s, stride = case_outputs(name)
+    rirs = [d["rir"]] + ([d["last_rir"]] if "last_rir" in d else [])
+    r = make_renderer(sr, [O.tile_short_source(d["source"], sr)], rirs, step_time=0.25, wrap=True)
+    idx = d["sample_index"]
+    u = UnitRequest(0, idx, 0, wrap=idx - d["rir"].shape[0] >= 0)
+    if "last_rir" in d:
+        u.last_rir, u.last_wrap = 1, idx - d["last_rir"].shape[0] >= 0
+    plain = UnitRequest(0, idx, 0, wrap=u.wrap)                         # same step without a previous RIR
+    ag, sg = r.render_crossfaded([u, plain])
+    assert r.plan([u, plain]).flags == (2 if "last_rir" in d else 1)
+    ag = ag.cpu().numpy()
+    check(ag[0][:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
+    check(ag[1], O.convolve_with_rir(O.tile_short_source(d["source"], sr), d["rir"], sr, idx, 0.25))
+    # AudioGoal-only configuration: the unfused loop kernel with the same flag
+    ag2 = r.render_audiogoal(r.plan([u, plain])).cpu().numpy()
+    assert np.abs(ag2 - ag).max() <= 2e-6 * np.abs(ag).max()
+
+
+def test_continuous_adapter_episode_on_gpu():
+    """attach_continuous() on a stand-in ContinuousSoundSpacesSim with the real AudioEngine: 14 steps of 0.25 s with
+    CROSSFADE, live RIRs of varying length (one longer than a partition block: the store grows), index wrapping
+    around the clip; every step against the oracle's restatement of continuous_simulator.py:413-456."""
+    from fakes import FakeContinuousSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    sr = 16000
+    rng = np.random.default_rng(31)
+    sounds = {"telephone": O.synth_sources(rng, sr, k=1)[0]}
+    lens = [9000, 12000, 20000, 7000, 16000]
+    bank = [O.synth_rir(rng, sr, length=L, n=1)[0] for L in lens]
+    sim = FakeContinuousSim(sr, sounds, lambda k: bank[k % 5].astype(np.float64).tolist(), start_index=37000)
+    eng = AudioEngine(sr, device=DEV, rir_slots=8, step_time=0.25, wrap=True)
+    sim_audio.attach_continuous(sim, eng)
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    for step in range(14):
+        ref = sim.reference_audiogoal()
+        a = ag_sensor.get_observation(observations=None, episode=None)
+        s = sg_sensor.get_observation(observations=None, episode=None)
+        check(a, ref)
+        check(s, O.compute_spectrogram(ref.astype(np.float32)))
+        sim.step()
+    assert eng.store.grown >= 1 and eng.store.cap >= 20000
+    assert eng.store.misses == 2                          # two live slots for the env, refreshed in place afterwards
+
+
+def test_long_rir_multisecond_clip_through_the_engine_store():
+    """RirStore used to cut RIRs at `cap` = sr, wrong for multi-second sounds (simulator.py:641-647 convolves
+    with the full RIR).  A 1.5-s RIR with a 5-s clip driven through AudioEngine / attach() / the sensors against the
+    reference-run vectors multi_L1.5_i*; the store starts at sr-sample rows (1-s clip registered first, row clipped),
+    then a multi-second clip arrives: rows reload whole and the bank grows."""
+    from fakes import FakeSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    d = case_inputs("multi_L1.5_i0")
+    sr = d["sr"]
+    one = case_inputs("clip1s")
+    path = "rirs/replica/apartment_0/90/3_7.wav"
+    sim = FakeSim(sr, {"short.wav": one["source"], "long.wav": d["source"]}, {path: d["rir"]})
+    eng = AudioEngine(sr, device=DEV, rir_slots=8)
+    sim_audio.attach(sim, eng, rir_reader=sim.reader)
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    # 1-s clip: only h[0:sr] matters, the row is clipped to sr and the loop-free kernel runs
+    a = ag_sensor.get_observation(observations=None, episode=None)
+    check(a, O.compute_audiogoal(one["source"], d["rir"], sr))
+    assert eng.store.cap == sr and int(eng.store.host_len[0]) == sr
+    sim._current_sound = "long.wav"
+    for idx in (0, 1, 2, 4):
+        ref_a, ref_s, stride = case_outputs(f"multi_L1.5_i{idx}")
+        sim._audio_index = idx
+        sim._audiogoal_cache, sim._spectrogram_cache = {}, {}
+        s = sg_sensor.get_observation(observations=None, episode=None)
+        a = ag_sensor.get_observation(observations=None, episode=None)
+        check(a[:, ::stride], ref_a)
+        check(s, ref_s)
+        assert sim._audio_index == (idx + 1) % 5
+    assert eng.store.cap >= 24000 and int(eng.store.host_len[0]) == 24000 and eng.store.grown == 1
 
 
 def test_44k_partitioned():
@@ -162,6 +240,30 @@ def test_spectrogram_kernel(pad_mode):
     assert ops.spectrogram(torch.ones((1, 2, 44100), device=DEV)).shape == (1, 65, 69, 2)
 
 
+@pytest.mark.parametrize("pad_mode", ["reflect", "constant"])
+@pytest.mark.parametrize("sr", [16000, 44100])
+def test_spectrogram_kernel_vs_torch_stft_on_the_box(sr, pad_mode):
+    """Independent of oracle/: nav.py:86-100 restated with torch.stft (the north star names it) computed on the GPU box
+    itself -- hann(400, periodic) centred in 512, hop 160, centre padding, |.|, 4x4 mean INCLUDING the zero padding of
+    the last row / column block (skimage.block_reduce), log1p, channel-last."""
+    from ss_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn((4, 2, sr), generator=g).to(DEV)
+    x[1, :, : sr // 3] = 0.0
+    x[2] *= torch.linspace(0.0, 3.0, sr, device=DEV)
+    got = ops.spectrogram(x, pad_mode)
+    st = torch.stft(x.reshape(-1, sr), n_fft=512, hop_length=160, win_length=400,
+                    window=torch.hann_window(400, periodic=True, device=DEV), center=True, pad_mode=pad_mode,
+                    return_complex=True).abs()                                        # [8, 257, T]
+    T = st.shape[2]
+    pad = torch.nn.functional.pad(st, (0, (-T) % 4, 0, (-257) % 4))
+    pooled = torch.nn.functional.avg_pool2d(pad[:, None], 4)[:, 0]                    # mean over 16 incl. the padding
+    ref = torch.log1p(pooled).reshape(4, 2, 65, -1).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= TOL, err
+
+
 def _random_batch(sr, n_units, n_src, n_rir, seed, ragged=False):
     rng = np.random.default_rng(seed)
     src = O.synth_sources(rng, sr, k=n_src)
@@ -192,6 +294,90 @@ def test_baseline_configs_vs_oracle(sr, n_units, ragged):
             cache[key] = (a, O.compute_spectrogram(a))
         check(ag[n], cache[key][0])
         check(sg[n], cache[key][1])
+
+
+def test_baseline_config2_128_envs_x_4_rotations_44k():
+    """BASELINE.json configs[2] at its stated shape: 128 envs x 4 agent rotations @44.1 kHz = 512 units in one launch
+    pair, ragged RIRs, the 4 azimuths of an env's (receiver, source) pair in 4 ADJACENT bank rows
+    (RirStore(group=4) + plan_arrays(rotations=4)); every unit against the oracle."""
+    from ss_amd.renderer import BatchedAudioRenderer, RirStore
+    sr, n_env, R = 44100, 128, 4
+    rng = np.random.default_rng(44)
+    src = O.synth_sources(rng, sr, k=6)
+    n_pairs = 24                                                    # distinct (receiver, source) pairs; envs share them
+    groups = [[np.ascontiguousarray(O.synth_rir(rng, sr, length=int(rng.uniform(0.3, 1.0) * sr), n=1)[0].T)
+               for _ in range(R)] for _ in range(n_pairs)]
+    r = BatchedAudioRenderer(sr, device=DEV)
+    for i, s_ in enumerate(src):
+        r.add_source(f"s{i}", s_)
+    store = RirStore(slots=R * 32, cap=sr, device=DEV, group=R, on_grow=r.set_rir_bank)
+    r.set_rir_bank(store.bank)
+    base = store.slot_many([("scene", p) for p in range(n_pairs)], [(lambda p=p: groups[p]) for p in range(n_pairs)])
+    assert all(b % R == 0 for b in base)
+    sel_s, sel_p = rng.integers(0, len(src), n_env), rng.integers(0, n_pairs, n_env)
+    silent = rng.uniform(size=n_env) < 0.05
+    rir = np.where(silent, -1, np.asarray(base)[sel_p])
+    plan = r.plan_arrays(sel_s, np.zeros(n_env, np.int64), rir, rotations=R)
+    assert len(plan) == n_env * R
+    ag, sg = r.render(plan, want_audiogoal=True)
+    assert tuple(sg.shape) == (512, 65, 69, 2)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    cache = {}
+    for n in range(n_env):
+        for k in range(R):
+            u = n * R + k
+            if silent[n]:
+                assert not ag[u].any() and not sg[u].any()
+                continue
+            key = (int(sel_s[n]), int(sel_p[n]), k)
+            if key not in cache:
+                a = O.compute_audiogoal(src[key[0]], groups[key[1]][k], sr)
+                cache[key] = (a, O.compute_spectrogram(a))
+            check(ag[u], cache[key][0])
+            check(sg[u], cache[key][1])
+
+
+def test_baseline_config4_256_envs_distractor_multisecond_all_outputs():
+    """BASELINE.json configs[4] at its stated shape: savi semantic_audionav -- 256 envs, 21-sound bank with clips of
+    1-20 s (all three windowing branches of simulator.py:629-647), a distractor on every env (:649-664, two convolutions
+    + add in the loop kernel), audiogoal AND spectrogram, plus the two extension sensors (log-mel, GCC-PHAT) on the
+    audiogoal; every unit against the oracle."""
+    from ss_amd import ops
+    from ss_amd.renderer import UnitRequest
+    sr, n_env = 16000, 256
+    rng = np.random.default_rng(54)
+    secs = [1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20]
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in secs]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=48)]
+    r = make_renderer(sr, src, rirs)
+    units, refs = [], []
+    for n in range(n_env):
+        s_, d_ = int(rng.integers(0, 21)), int(rng.integers(0, 3))             # distractors are 1-s clips
+        h_, hd = int(rng.integers(0, 48)), int(rng.integers(0, 48))
+        idx = int(rng.integers(0, secs[s_]))
+        silent = n % 61 == 7
+        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_, silent=silent, dis_sound=d_, dis_rir=hd))
+        refs.append(None if silent else O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx, distractor=src[d_],
+                                                            distractor_rir=rirs[hd]))
+    plan = r.plan(units)
+    assert plan.flags == 0
+    ag, sg = r.render(plan, want_audiogoal=True)
+    ms, mw, _ = P.mel_filterbank_sparse(sr, 64)
+    lm = ops.logmel(ag, torch.from_numpy(ms).to(DEV), torch.from_numpy(mw).to(DEV), 1e-6)
+    gp = ops.gccphat(ag, 32, 1e-8)
+    ag, sg, lm, gp = ag.cpu().numpy(), sg.cpu().numpy(), lm.cpu().numpy(), gp.cpu().numpy()
+    for n in range(n_env):
+        if refs[n] is None:
+            assert not ag[n].any() and not sg[n].any()
+            continue
+        a = refs[n].astype(np.float32)
+        check(ag[n], a)
+        check(sg[n], O.compute_spectrogram(a))
+        if n % 16 == 0:                                                           # the extensions: a sample of units
+            ref_lm = O.compute_logmel(a, sr, 64, 1e-6)
+            assert np.abs(lm[n] - ref_lm).max() <= 2e-3 * np.abs(ref_lm).max()    # log of small band energies
+            ref_gp = O.compute_gcc_phat(a, 32, 1e-8)
+            assert np.abs(gp[n] - ref_gp).max() <= 2e-3
 
 
 def test_persistent_row_kernel_large_batches():

@@ -121,17 +121,59 @@ def test_savi_dataset_variant(name):
     check(sg[0], ref_s)
 
 
-@pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap"])
+@pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap", "cont_early_past_end"])
 def test_continuous_simulator_windows(name):
     d = case_inputs(name)
     sr = d["sr"]
     ref_a, ref_s, stride = case_outputs(name)
     src3 = O.tile_short_source(d["source"], sr)
     ns = int(sr * d["step_time"])
+    wrap = d["sample_index"] - d["rir"].shape[0] >= 0         # the reference wraps only in its steady branch
     out, sg = hs.run([src3], planar(d["rir"]), [d["rir"].shape[0]],
-                     [dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=True)],
+                     [dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=wrap)],
                      ns, sr, fuse=True)
     assert not out[0][:, ns:].any()
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_continuous_crossfade_in_kernel(fuse):
+    """SS_FLAG_CROSSFADE: previous RIR = term 1, blended in registers by the loop kernel (one launch) -- against the
+    vector produced by running the reference's _compute_audiogoal with CROSSFADE on; a unit without a previous RIR
+    (first step of an episode) in the same batch stays unblended."""
+    d = case_inputs("cont_crossfade")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("cont_crossfade")
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    bank = np.concatenate([planar(d["rir"]), planar(d["last_rir"])])
+    L = [d["rir"].shape[0], d["last_rir"].shape[0]]
+    t0 = P.window_start_continuous(d["sample_index"])
+    units = [dict(sound=0, t0=t0, rir=0, wrap=True, last_rir=1), dict(sound=0, t0=t0, rir=0, wrap=True)]
+    out, sg = hs.run([src3], bank, L, units, ns, sr, fuse=fuse, want_spectrogram=True, crossfade=True)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+    plain = O.convolve_with_rir(src3, d["rir"], sr, d["sample_index"], d["step_time"])
+    check(out[1], plain)
+    n = int(0.05 * sr)
+    assert np.abs(out[0][:, n + 1:] - out[1][:, n + 1:]).max() == 0.0          # beyond the ramp: the current RIR alone
+    assert np.abs(out[0][:, :n] - out[1][:, :n]).max() > 0.0
+
+
+def test_continuous_crossfade_branches_differ_between_the_two_rirs():
+    """cont_crossfade_mixed: current RIR (9000 taps) is in the steady branch and wraps around the clip, the previous
+    RIR (50000 taps, 4 partition blocks) is in the early branch and reads zeros past the clip end."""
+    d = case_inputs("cont_crossfade_mixed")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("cont_crossfade_mixed")
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    cap = 50000
+    bank = np.concatenate([planar(d["rir"], cap), planar(d["last_rir"], cap)])
+    units = [dict(sound=0, t0=d["sample_index"], rir=0, wrap=True, last_rir=1, last_wrap=False)]
+    out, sg = hs.run([src3], bank, [d["rir"].shape[0], d["last_rir"].shape[0]], units, ns, sr, fuse=True,
+                     crossfade=True)
     check(out[0][:, ::stride], ref_a)
     check(sg[0], ref_s)
 

@@ -89,7 +89,7 @@ def test_unified_window_formula(name):
         assert np.abs(got - ref[:, a:a + 96]).max() < 2e-6 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap"])
+@pytest.mark.parametrize("name", ["cont_early", "cont_steady", "cont_wrap", "cont_early_past_end"])
 def test_unified_window_formula_continuous(name):
     d = case_inputs(name)
     sr = d["sr"]
@@ -97,9 +97,15 @@ def test_unified_window_formula_continuous(name):
     ref = oracle_audiogoal(name)
     ns = int(sr * d["step_time"])
     assert not ref[:, ns:].any()
+    # the reference wraps the clip around only in its steady branch (index >= rir length, :438-447); the early branch
+    # slices source[:index+num_sample], i.e. reads zeros past the clip end (:433-437)
+    wrap = d["sample_index"] - d["rir"].shape[0] >= 0
     for a in (0, 1500, ns - 96):
-        got = O.conv_window_direct(src3, d["rir"], d["sample_index"] + a, 96, wrap=True)
+        got = O.conv_window_direct(src3, d["rir"], d["sample_index"] + a, 96, wrap=wrap)
         assert np.abs(got - ref[:, a:a + 96]).max() < 2e-6 * np.abs(ref).max()
+    if name == "cont_early_past_end":           # and wrapping there WOULD be wrong (the case is discriminating)
+        bad = O.conv_window_direct(src3, d["rir"], d["sample_index"] + ns - 96, 96, wrap=True)
+        assert np.abs(bad - ref[:, ns - 96:ns]).max() > 1e-3 * np.abs(ref).max()
 
 
 # ---- librosa.stft / skimage.block_reduce restatements, independent checks ----

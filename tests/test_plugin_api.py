@@ -1,11 +1,13 @@
 """The Habitat plugin boundary: sensor classes, simulator audio adapter with the reference's cache
 semantics, batched observer, RIR store.  CPU only: the engine is an oracle-backed test double (tests/fakes.py)."""
+import types
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ss_oracle as O
-from fakes import FakeSim, OracleEngine, NS
+from fakes import FakeContinuousSim, FakeSim, OracleEngine, NS
 from ss_amd import sensors, sim_audio
 from ss_amd.habitat_compat import SensorTypes, registry
 from ss_amd.renderer import RirStore, UnitRequest
@@ -137,6 +139,63 @@ def test_vector_observer_batches_all_envs_in_one_launch():
     assert torch.equal(rs.observations["audiogoal"][1], obs["audiogoal"]) and rs.step == 1
 
 
+def _continuous(crossfade=True, rir_len=9000, start=123, seconds=1):
+    rng = np.random.default_rng(21)
+    sounds = {"telephone": O.synth_sources(rng, SR, k=1, seconds=seconds)[0]}
+    bank = O.synth_rir(rng, SR, length=rir_len, n=40)
+    sim = FakeContinuousSim(SR, sounds, lambda k: bank[k % 40].astype(np.float64).tolist(), crossfade=crossfade,
+                            start_index=start)
+    eng = OracleEngine(SR, step_time=0.25)
+    return sim, eng, sim_audio.attach_continuous(sim, eng)
+
+
+@pytest.mark.parametrize("crossfade", [True, False])
+def test_continuous_sim_adapter_follows_the_reference_for_an_episode(crossfade):
+    """ContinuousSoundSpacesSim semantics (continuous_simulator.py:413-462) over 30 steps of 0.25 s: live RIR from
+    _prev_sim_obs, _last_rir cross-fade from the second step on, sample index advancing and wrapping around the
+    3x-tiled clip, early -> steady branch change, no caches (every call computes), silence after the duration."""
+    sim, eng, backend = _continuous(crossfade)
+    sg_fn = sensors.SpectrogramSensor.compute_spectrogram
+    seen_wrap = seen_early = False
+    for step in range(30):
+        ref = sim.reference_audiogoal()
+        a = sim.get_current_audiogoal_observation()
+        assert a.shape == (2, SR) and O.relerr(a, ref) < 1e-5
+        assert not a[:, SR // 4:].any()
+        calls = eng.calls
+        s = sim.get_current_spectrogram_observation(sg_fn)
+        assert eng.calls == calls + 1                                            # uncached (:458-462)
+        assert O.relerr(s, O.compute_spectrogram(ref.astype(np.float32))) < 1e-5
+        idx = sim._current_sample_index
+        seen_early |= idx < 9000
+        seen_wrap |= idx >= 9000 and idx + SR // 4 >= 3 * SR
+        sim.step()
+    assert seen_early and seen_wrap
+    # one new RIR upload per step although both sensors ran and (with CROSSFADE) two RIRs are convolved per step
+    assert eng.uploads == 30
+    sim._episode_step_count = sim._duration + 1
+    assert not sim.get_current_audiogoal_observation().any()
+    assert sim.get_current_spectrogram_observation(lambda a: a.sum()) == 0.0      # foreign callable on the host
+
+
+def test_continuous_adapter_rejects_a_ss1_engine():
+    sim, _, _ = _continuous()
+    with pytest.raises(ValueError):
+        sim_audio.attach_continuous(sim, types.SimpleNamespace(renderer=types.SimpleNamespace(n_valid=SR, wrap=False)))
+
+
+def test_continuous_vector_observer_one_launch():
+    sims = [_continuous(start=1000 * i)[0] for i in range(4)]
+    eng = OracleEngine(SR, step_time=0.25)
+    backends = [sim_audio.HipContinuousSimAudio(s, eng) for s in sims]
+    for s in sims[:2]:
+        s.step()
+    obs = sim_audio.VectorAudioObserver(eng, backends, want_audiogoal=True).observe()
+    assert eng.calls == 1
+    for i, s in enumerate(sims):
+        assert O.relerr(obs["audiogoal"][i].numpy(), s.reference_audiogoal()) < 1e-5
+
+
 def test_rir_store_lru_and_refresh():
     st = RirStore(slots=3, cap=100, device="cpu")
     loads = []
@@ -149,13 +208,47 @@ def test_rir_store_lru_and_refresh():
     a = st.slot("a", loader("a", 10)); b = st.slot("b", loader("b", 20)); c = st.slot("c", loader("c", 30))
     assert len({a, b, c}) == 3 and st.misses == 3
     assert st.slot("a", loader("a", 10)) == a and st.hits == 1 and loads == ["a", "b", "c"]
-    d = st.slot("d", loader("d", 200))                                            # evicts LRU = "b"; truncated to cap
-    assert d == b and int(st.bank.lengths[d]) == 100
+    d = st.slot("d", loader("d", 200))                                            # evicts LRU = "b"; nothing is cut:
+    assert d == b and int(st.bank.lengths[d]) == 200 and st.cap >= 200 and st.grown == 1   # the bank grew instead
+    assert int(st.bank.lengths[a]) == 10 and float(st.bank.data[a, 0, 9]) == 1.0  # earlier rows survive the growth
     assert st.slot("b", loader("b", 20)) == c                                     # now "c" is the oldest
     assert int(st.bank.lengths[c]) == 20 and not st.bank.data[c, :, 20:].any()    # rows zero beyond their length
     live = st.slot(("live", 1), loader("l", 5))
     assert st.slot(("live", 1), loader("l2", 7), refresh=True) == live and int(st.bank.lengths[live]) == 7
     assert st.slot("none", lambda: None) is not None                              # unreadable -> zero RIR, length 0
+
+
+def test_rir_store_truncation_policy_and_batch_guard():
+    """truncate_to (exact for 1-s clips only) vs whole RIRs; rows clipped earlier reload once whole RIRs are needed; a
+    store too small for one batch raises instead of handing two envs the same slot."""
+    rir = np.arange(2 * 300, dtype=np.float32).reshape(300, 2)
+    st = RirStore(slots=2, cap=100, device="cpu", truncate_to=100)
+    s0 = st.slot("k", lambda: rir)
+    assert st.host_len[s0] == 100 and st.cap == 100 and st._clipped[s0]
+    st.truncate_to = None                                                         # a multi-second clip was registered
+    assert st.slot("k", lambda: rir) == s0 and st.host_len[s0] == 300 and st.cap >= 300   # reloaded whole, bank grown
+    np.testing.assert_array_equal(st.bank.data[s0, :, :300].numpy(), rir.T)
+    with pytest.raises(ValueError):
+        RirStore(slots=2, cap=100, device="cpu", max_cap=256).slot("x", lambda: np.zeros((300, 2), np.float32))
+    st.begin_batch()
+    st.slot("a", lambda: rir[:10]); st.slot("b", lambda: rir[:10])
+    with pytest.raises(RuntimeError):
+        st.slot("c", lambda: rir[:10])                                            # would overwrite a slot of this batch
+    st.begin_batch()
+    st.slot("c", lambda: rir[:10])                                                # next step: fine
+
+
+def test_rir_store_groups_keep_azimuths_adjacent():
+    st = RirStore(slots=8, cap=16, device="cpu", group=4)
+    mk = lambda v: [np.full((5 + k, 2), v + k, np.float32) for k in range(4)]
+    a = st.slot(("scene", 3, 7), lambda: mk(10.0))
+    b = st.slot(("scene", 3, 8), lambda: mk(20.0))
+    assert a % 4 == 0 and b % 4 == 0 and a != b
+    assert [int(st.host_len[a + k]) for k in range(4)] == [5, 6, 7, 8] and float(st.bank.data[b + 2, 1, 0]) == 22.0
+    c = st.slot(("scene", 3, 9), lambda: mk(30.0))                                # evicts the whole group of the LRU key
+    assert c == a and ("scene", 3, 7) not in st._slot_of
+    out = st.slot_many([("s", 1), ("s", 2)], [lambda: mk(1.0), lambda: mk(2.0)], workers=1)
+    assert sorted(out) == [0, 4] and float(st.bank.data[out[1] + 3, 0, 0]) == 5.0
 
 
 def test_unit_request_defaults():
