@@ -1,6 +1,7 @@
 """Habitat task sensors of the audio path — drop-ins for soundspaces/tasks/nav.py:37-105.
 
-Same registry names (``AudioGoalSensor``, ``SpectrogramSensor``), same uuids (``audiogoal`` / ``spectrogram``),
+Same registry names (``AudioGoalSensor``, ``SpectrogramSensor``, av_wan's ``Intensity``), same uuids (``audiogoal`` /
+``spectrogram`` / ``intensity``),
 same ``SensorTypes.PATH``, same ``spaces.Box`` (float32, shape (2, sr) / (65, T4, 2) channel-last), same constructor
 and ``get_observation`` signatures, same delegation to ``sim.get_current_*_observation``; the arithmetic behind
 runs on the MI355X (ss_amd.sim_audio.attach installs it on the simulator)."""
@@ -68,6 +69,41 @@ class SpectrogramSensor(Sensor):
 
     def get_observation(self, *args: Any, observations, episode, **kwargs: Any):
         return self._sim.get_current_spectrogram_observation(self.compute_spectrogram)
+
+
+@registry.register_sensor(name="Intensity")
+class Intensity(Sensor):
+    """av_wan's intensity placeholder sensor (ss_baselines/av_wan/avwan_sensors.py:60-100; selected by
+    ``TASK.INTENSITY.TYPE = "Intensity"``, av_wan/config/default.py:191-194): onset = first sample above 0.1 * max over
+    both ears (the earlier of the two ears), value = mean square of the 150 samples from the onset.  Same registry name,
+    uuid, sensor type and Box as the reference; the reduction runs in ``k_intensity`` (``ss_intensity_f32``)."""
+
+    def __init__(self, sim, config, *args: Any, **kwargs: Any):
+        self._sim = sim
+        super().__init__(config=config)
+
+    def _get_uuid(self, *args: Any, **kwargs: Any):
+        return "intensity"
+
+    def _get_sensor_type(self, *args: Any, **kwargs: Any):
+        return SensorTypes.COLOR                                                   # avwan_sensors.py:72 (sic)
+
+    def _get_observation_space(self, *args: Any, **kwargs: Any):
+        return spaces.Box(low=0, high=1, shape=(1,), dtype=bool)                   # avwan_sensors.py:75-80 (sic)
+
+    @staticmethod
+    def compute_intensity(audiogoal, num_frame: int = 150):
+        """[2, T] (numpy -> python float) or [N, 2, T] CUDA tensor (-> CUDA tensor [N])."""
+        import torch
+        from . import ops
+        if isinstance(audiogoal, torch.Tensor):
+            return ops.intensity(audiogoal.to(torch.float32).contiguous(), num_frame)
+        x = torch.from_numpy(np.ascontiguousarray(audiogoal, dtype=np.float32))[None].to("cuda")
+        return float(ops.intensity(x, num_frame)[0])
+
+    def get_observation(self, *args: Any, observations, episode, **kwargs: Any):
+        audiogoal = self._sim.get_current_audiogoal_observation()
+        return [self.compute_intensity(audiogoal, 150)]                             # avwan_sensors.py:93-100: [rms]
 
 
 # lets HipSimAudio recognise "the spectrogram of this package" and use the fused kernel's output for it

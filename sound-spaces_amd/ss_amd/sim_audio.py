@@ -255,8 +255,11 @@ def attach_continuous(sim, engine) -> HipContinuousSimAudio:
 class VectorAudioObserver:
     """Batched mode: one launch per vector step for all envs of this process."""
 
-    def __init__(self, engine, backends: List[HipSimAudio], want_audiogoal: bool = False):
-        self.engine, self.backends, self.want_audiogoal = engine, backends, want_audiogoal
+    def __init__(self, engine, backends: List[HipSimAudio], want_audiogoal: bool = False, want_intensity: bool = False):
+        """want_intensity: also return av_wan's ``intensity`` [N, 1] (ss_baselines/av_wan/avwan_sensors.py:91-100),
+        reduced on the device from the batch's audiogoal."""
+        self.engine, self.backends = engine, backends
+        self.want_audiogoal, self.want_intensity = want_audiogoal or want_intensity, want_intensity
 
     def observe(self, spectrogram_out=None, audiogoal_out=None):
         """-> {"spectrogram": device tensor [N,65,T4,2], ("audiogoal": [N,2,sr])}; cache-free (every env renders its
@@ -264,8 +267,12 @@ class VectorAudioObserver:
         if hasattr(self.engine, "begin_batch"):
             self.engine.begin_batch()                 # no RIR slot of this step may be evicted by another env of it
         units = [b.unit_request() for b in self.backends]
-        return self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
-                                   want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+        out = self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
+                                  want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+        if self.want_intensity:
+            from .sensors import Intensity
+            out["intensity"] = Intensity.compute_intensity(out["audiogoal"], 150).reshape(-1, 1)
+        return out
 
     def observe_into(self, rollouts):
         """Render this vector step straight into the rollout rows the next `rollouts.insert()` fills

@@ -486,6 +486,25 @@ def test_intensity_sensor():
         np.testing.assert_allclose(got[n], O.intensity(x[n])[0], rtol=2e-6, atol=1e-12)
 
 
+def test_intensity_sensor_class_and_batched_observer():
+    """av_wan Intensity as a Habitat sensor (avwan_sensors.py:60-100) on the stand-in sim + real engine, and as a
+    device-side column of the batched observer."""
+    from fakes import FakeSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    d = case_inputs("clip1s")
+    sr = d["sr"]
+    sim = FakeSim(sr, {"telephone.wav": d["source"]}, {"rirs/replica/apartment_0/90/3_7.wav": d["rir"]})
+    eng = AudioEngine(sr, device=DEV, rir_slots=16)
+    sim_audio.attach(sim, eng, rir_reader=sim.reader)
+    got = sensors.Intensity(sim, NS()).get_observation(observations=None, episode=None)
+    assert isinstance(got, list) and len(got) == 1
+    np.testing.assert_allclose(got[0], golden()[0]["clip1s/intensity"][0], rtol=2e-6)
+    obs = sim_audio.VectorAudioObserver(eng, [sim._ss_hip_audio] * 3, want_intensity=True).observe()
+    assert tuple(obs["intensity"].shape) == (3, 1) and obs["intensity"].is_cuda
+    np.testing.assert_allclose(obs["intensity"].cpu().numpy()[:, 0], golden()[0]["clip1s/intensity"][0], rtol=2e-6)
+
+
 def test_audiogoal_batcher_savi_semantics():
     from ss_amd.datasets import AudioGoalBatcher
     d0, d2 = case_inputs("savi_i0"), case_inputs("savi_i2")

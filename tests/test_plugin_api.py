@@ -41,6 +41,9 @@ def test_sensor_contract():
     assert ag.observation_space.low == np.finfo(np.float32).min
     sim.config.AUDIO.RIR_SAMPLING_RATE = 44100
     assert sensors.SpectrogramSensor(sim=sim, config=NS()).observation_space.shape == (65, 69, 2)
+    it = sensors.Intensity(sim, NS())                                             # avwan_sensors.py:60-80
+    assert it.uuid == "intensity" and it.sensor_type == SensorTypes.COLOR and it.observation_space.shape == (1,)
+    assert registry.get_sensor("Intensity") is sensors.Intensity
     assert registry.get_sensor("AudioGoalSensor") is sensors.AudioGoalSensor
     assert registry.get_sensor("SpectrogramSensor") is sensors.SpectrogramSensor
     assert sensors.SpectrogramSensor.cls_uuid == "spectrogram"
