@@ -112,6 +112,64 @@ int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode
 int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mode, int max_lag, float eps,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Context API: the self-contained entry.  One call per vector step does what the reference does per env
+ * in Python -- SoundSpacesSim._compute_audiogoal (soundspaces/simulator.py:608-666) /
+ * ContinuousSoundSpacesSim._compute_audiogoal + _convolve_with_rir (soundspaces/continuous_simulator.py:413-456) and
+ * SpectrogramSensor.compute_spectrogram (soundspaces/tasks/nav.py:86-100) -- for ALL envs: the caller hands over what a
+ * simulator knows (which sound, which clip window, which RIR), the library plans the partitions, keeps the
+ * source-window spectra it needs in a bounded cache, uploads the descriptors and launches.  A C caller therefore needs
+ * neither ss_amd/planning.py nor the opaque spectrum slots of the entry points above.
+ *
+ * A context is bound to the HIP device that is current when it is created and serves one stream at a time.
+ * ---------------------------------------------------------------------------------------------------------------*/
+typedef struct ss_ctx ss_ctx;
+
+/* The units of one step, struct-of-arrays, HOST memory, n entries per column; optional columns may be NULL.
+ * unit i:  out[c,t] = sum_k rir[c,k] * x[t0 + t - k], t < n_valid (rest of the 1-s row zero), x = clip `sound`,
+ *   x[<0] = 0 and past the clip end 0 or -- contexts created with wrap_mode 1, units with wrap != 0 -- the clip again
+ *   from its start (the reference wraps only in its steady branch, continuous_simulator.py:438-447).
+ *   t0 per reference branch: 0 (1-s clip, simulator.py:629-632); _audio_index * sr (multi-second, :634-647);
+ *   _current_sample_index (continuous_simulator.py:432).
+ *   rir < 0: silent unit (simulator.py:610-612) -> exact zeros.
+ *   dis_sound / dis_rir: distractor (whole clip through a second RIR, added; simulator.py:649-664), -1 = none.
+ *   last_rir: the previous step's RIR for SS2.0 CROSSFADE (see SS_FLAG_CROSSFADE), -1 = none; last_wrap = the branch
+ *   flag of THAT RIR (defaults to wrap).  A step has either distractors or cross-fades, not both. */
+typedef struct ss_units {
+    const int* sound;
+    const int* t0;
+    const int* rir;
+    const int* dis_sound;            /* optional */
+    const int* dis_rir;              /* optional */
+    const int* last_rir;             /* optional */
+    const unsigned char* wrap;       /* optional; NULL = 1 for every unit */
+    const unsigned char* last_wrap;  /* optional; NULL = same as wrap */
+} ss_units;
+
+/* n_valid = samples computed per row: sampling_rate (SoundSpacesSim) or int(sampling_rate * STEP_TIME) (Continuous);
+ * rows are sampling_rate long.  wrap_mode: 0 = SoundSpaces 1.0, 1 = SoundSpaces 2.0 semantics (see ss_units).
+ * max_window_sets = initial capacity of the window-spectra cache in (sound, t0) keys (128 KiB of HBM per stored
+ * window; <= 0: 256); the cache is LRU and only grows when one step itself needs more keys than it holds. */
+int ss_ctx_create(ss_ctx** ctx, int sampling_rate, int n_valid, int pad_mode, int wrap_mode, int max_window_sets);
+int ss_ctx_destroy(ss_ctx* ctx);
+/* Register a mono clip, float32, already at the simulator rate (the reference's _source_sound_dict,
+ * simulator.py:595-600).  `clip` is host memory (on_device = 0) or device memory.  Returns the sound id >= 0. */
+int ss_ctx_add_source(ss_ctx* ctx, const float* clip, int len, int on_device);
+int ss_ctx_add_source_len(ss_ctx* ctx, int len);   /* planner-only registration (no device memory; for ss_ctx_plan) */
+/* RIR bank in device memory, addressing as for ss_fftconv_binaural_f32; the pointers are borrowed. */
+int ss_ctx_set_rir_bank(ss_ctx* ctx, const float* rir, const int* rir_len, long long rir_unit_stride,
+                        int rir_chan_stride, int rir_elem_stride, int rir_cap);
+/* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
+ * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
+int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);
+/* The planner alone (host only, needs no GPU): unit_desc_out int32 [n,8] as ss_fftconv_binaural_f32 takes them,
+ * *flags_out the SS_FLAG_* of the launch, *n_new_windows_out the source windows whose spectra would be computed,
+ * new_windows_out (optional, int32 [cap,5]) = {src_offset, src_len, start, wrap, pool slot} of those windows. */
+int ss_ctx_plan(ss_ctx* ctx, const ss_units* units, int n, int* unit_desc_out, int* flags_out, int* n_new_windows_out,
+                int* new_windows_out, int new_windows_cap);
+/* out8 = {cache hits, misses, evictions, grows, capacity (keys), keys resident, pool slots per key, steps planned} */
+int ss_ctx_stats(ss_ctx* ctx, long long* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,9 +3,11 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "../../include/ss_hip.h"
+#include "ss_context.hpp"
 #include "ss_kernels.hpp"
 #include "ss_tables.hpp"
 
@@ -98,8 +100,24 @@ int ss_source_windows_f32(const float* src, const int* win_desc, float* spec_out
     p.src = src;
     p.desc = win_desc;
     p.spec = reinterpret_cast<ssk::f32x4*>(spec_out);
+    p.desc_stride = 4;
+    p.scale = ssk::kWindowScale;
     hipLaunchKernelGGL(ssk::k_source_windows, dim3(n_windows), dim3(ssk::kT), 0,
                        static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
+// window spectra scattered into a pool: desc rows {src_offset, src_len, start, wrap, pool slot}
+static int launch_windows_scatter(const float* src, const int* win_desc5, float* pool, int n_windows, hipStream_t st) {
+    ssk::SrcParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.src = src;
+    p.desc = win_desc5;
+    p.spec = reinterpret_cast<ssk::f32x4*>(pool);
+    p.desc_stride = 5;
+    p.scale = ssk::kWindowScale;
+    hipLaunchKernelGGL(ssk::k_source_windows, dim3(n_windows), dim3(ssk::kT), 0, st, p);
     return hip_err(hipGetLastError());
 }
 
@@ -257,6 +275,257 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
     p.num_frame = num_frame;
     hipLaunchKernelGGL(ssk::k_intensity, dim3(n_units), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hip_err(hipGetLastError());
+}
+
+
+// ---- context API (include/ss_hip.h): planner + window-spectra cache + descriptor ring inside the library --------------
+struct ss_ctx { ssctx::Context c; };
+
+int ss_ctx_create(ss_ctx** out, int sampling_rate, int n_valid, int pad_mode, int wrap_mode, int max_window_sets) {
+    if (!out || sampling_rate <= 0 || n_valid < 0 || n_valid > sampling_rate || n_valid > 3 * ssk::kB) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    ss_ctx* h = new (std::nothrow) ss_ctx();
+    if (!h) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    c.sr = sampling_rate; c.n_valid = n_valid; c.out_len = sampling_rate; c.pad_mode = pad_mode;
+    c.wrap_mode = wrap_mode ? 1 : 0;
+    c.kb = ssk::kB; c.spec_floats = 2 * ssk::kSpecComplex;
+    c.n_entries = max_window_sets > 0 ? max_window_sets : 256;
+    c.stride = n_valid > 0 ? ssctx::ceil_div(n_valid, ssk::kB) : 1;                 // nbh_max (= 1 until a bank is set) + nby - 1
+    ssctx::cache_reset(c);
+    *out = h;
+    return 0;
+}
+
+static void ctx_free_device(ssctx::Context& c) {
+    if (c.pool) (void)hipFree(c.pool);
+    if (c.src_dev) (void)hipFree(c.src_dev);
+    if (c.d_desc) (void)hipFree(c.d_desc);
+    if (c.d_win) (void)hipFree(c.d_win);
+    if (c.h_desc) (void)hipHostFree(c.h_desc);
+    if (c.h_win) (void)hipHostFree(c.h_win);
+    if (c.ag_scratch) (void)hipFree(c.ag_scratch);
+    c.ag_scratch = nullptr; c.ag_cap = 0;
+    if (c.ev_made)
+        for (int k = 0; k < ssctx::kRing; ++k) { (void)hipEventDestroy(c.ev_copy[k]); (void)hipEventDestroy(c.ev_done[k]); }
+    c.pool = nullptr; c.src_dev = nullptr; c.d_desc = nullptr; c.d_win = nullptr; c.h_desc = nullptr; c.h_win = nullptr;
+    c.ev_made = false;
+}
+
+int ss_ctx_destroy(ss_ctx* h) {
+    if (!h) return 0;
+    ctx_free_device(h->c);
+    delete h;
+    return 0;
+}
+
+// `clip` is HOST memory unless on_device != 0.  Returns the sound id (>= 0) or a negative error.
+int ss_ctx_add_source(ss_ctx* h, const float* clip, int len, int on_device) {
+    if (!h || !clip || len <= 0) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    const size_t need = c.src_used + static_cast<size_t>(len);
+    if (need > c.src_cap) {                                    // grow the flat bank (rare: once per new sound at most)
+        size_t cap = c.src_cap ? c.src_cap : (1u << 20);
+        while (cap < need) cap *= 2;
+        float* nb = nullptr;
+        hipError_t e = hipMalloc(&nb, cap * sizeof(float));
+        if (e != hipSuccess) return hip_err(e);
+        if (c.src_used) {
+            e = hipDeviceSynchronize();                        // launches that read the old bank
+            if (e == hipSuccess) e = hipMemcpy(nb, c.src_dev, c.src_used * sizeof(float), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { (void)hipFree(nb); return hip_err(e); }
+        }
+        if (c.src_dev) (void)hipFree(c.src_dev);
+        c.src_dev = nb;
+        c.src_cap = cap;
+    }
+    hipError_t e = hipMemcpy(c.src_dev + c.src_used, clip, static_cast<size_t>(len) * sizeof(float),
+                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_err(e);
+    c.src_off.push_back(static_cast<int>(c.src_used));
+    c.src_len.push_back(len);
+    c.src_used = need;
+    return static_cast<int>(c.src_len.size()) - 1;
+}
+
+// planning-only registration (tests of the planner on machines without a GPU): lengths only, no device memory
+int ss_ctx_add_source_len(ss_ctx* h, int len) {
+    if (!h || len <= 0) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    c.src_off.push_back(static_cast<int>(c.src_used));
+    c.src_len.push_back(len);
+    c.src_used += static_cast<size_t>(len);
+    return static_cast<int>(c.src_len.size()) - 1;
+}
+
+int ss_ctx_set_rir_bank(ss_ctx* h, const float* rir, const int* rir_len, long long unit_stride, int chan_stride,
+                        int elem_stride, int rir_cap) {
+    if (!h || rir_cap < 0 || elem_stride < 1 || chan_stride < 0 || unit_stride < 0) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    const int nbh_old = c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1;
+    const int nbh_new = rir_cap > 0 ? ssctx::ceil_div(rir_cap, c.kb) : 1;
+    c.rir = rir; c.rir_len = rir_len; c.rir_us = unit_stride; c.rir_cs = chan_stride; c.rir_es = elem_stride;
+    c.rir_cap = rir_cap;
+    if (nbh_new != nbh_old) {                                  // the set of partition offsets per key changes
+        const int nby = c.n_valid > 0 ? ssctx::ceil_div(c.n_valid, c.kb) : 1;
+        c.stride = nbh_new + nby - 1;
+        ssctx::cache_reset(c);
+        if (c.pool) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_err(e);
+            (void)hipFree(c.pool);
+            c.pool = nullptr;
+            c.pool_entries = 0;
+        }
+    }
+    return 0;
+}
+
+int ss_ctx_plan(ss_ctx* h, const ss_units* units, int n, int* unit_desc_out, int* flags_out, int* n_new_windows_out,
+                int* new_windows_out, int new_windows_cap) {
+    if (!h || !unit_desc_out) return SS_EINVAL;
+    ssctx::PlanResult res;
+    int rc = ssctx::plan_units(h->c, units, n, unit_desc_out, &res);
+    if (rc) return rc;
+    if (flags_out) *flags_out = res.flags;
+    if (n_new_windows_out) *n_new_windows_out = res.n_new_windows;
+    if (new_windows_out) {
+        const int k = res.n_new_windows < new_windows_cap ? res.n_new_windows : new_windows_cap;
+        std::memcpy(new_windows_out, h->c.new_win.data(), sizeof(int) * 5 * static_cast<size_t>(k));
+    }
+    return 0;
+}
+
+int ss_ctx_stats(ss_ctx* h, long long* out8) {
+    if (!h || !out8) return SS_EINVAL;
+    const ssctx::Context& c = h->c;
+    out8[0] = c.hits; out8[1] = c.misses; out8[2] = c.evictions; out8[3] = c.grows;
+    out8[4] = c.n_entries; out8[5] = static_cast<long long>(c.map.size()); out8[6] = c.stride; out8[7] = c.tick;
+    return 0;
+}
+
+static int ctx_ensure_ring(ssctx::Context& c, int n, int n_win, hipStream_t st) {
+    hipError_t e;
+    if (!c.ev_made) {
+        for (int k = 0; k < ssctx::kRing; ++k) {
+            e = hipEventCreateWithFlags(&c.ev_copy[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_err(e);
+            e = hipEventCreateWithFlags(&c.ev_done[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_err(e);
+        }
+        c.ev_made = true;
+    }
+    if (n > c.ring_cap) {
+        e = hipDeviceSynchronize();                            // slots of the old ring may still be read
+        if (e != hipSuccess) return hip_err(e);
+        int cap = c.ring_cap ? c.ring_cap : 256;
+        while (cap < n) cap *= 2;
+        if (c.h_desc) (void)hipHostFree(c.h_desc);
+        if (c.d_desc) (void)hipFree(c.d_desc);
+        c.h_desc = nullptr; c.d_desc = nullptr; c.ring_cap = 0;
+        const size_t bytes = sizeof(int) * 8 * static_cast<size_t>(cap) * ssctx::kRing;
+        e = hipHostMalloc(reinterpret_cast<void**>(&c.h_desc), bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return hip_err(e);
+        e = hipMalloc(reinterpret_cast<void**>(&c.d_desc), bytes);
+        if (e != hipSuccess) return hip_err(e);
+        c.ring_cap = cap;
+    }
+    if (n_win > c.win_cap) {
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return hip_err(e);
+        int cap = c.win_cap ? c.win_cap : 256;
+        while (cap < n_win) cap *= 2;
+        if (c.h_win) (void)hipHostFree(c.h_win);
+        if (c.d_win) (void)hipFree(c.d_win);
+        c.h_win = nullptr; c.d_win = nullptr; c.win_cap = 0;
+        const size_t bytes = sizeof(int) * 5 * static_cast<size_t>(cap) * ssctx::kRing;
+        e = hipHostMalloc(reinterpret_cast<void**>(&c.h_win), bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return hip_err(e);
+        e = hipMalloc(reinterpret_cast<void**>(&c.d_win), bytes);
+        if (e != hipSuccess) return hip_err(e);
+        c.win_cap = cap;
+    }
+    (void)st;
+    return 0;
+}
+
+static int ctx_ensure_pool(ssctx::Context& c, hipStream_t st) {
+    if (c.pool && c.pool_entries >= c.n_entries) return 0;
+    const size_t per_entry = static_cast<size_t>(c.stride) * c.spec_floats * sizeof(float);
+    float* np = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&np), per_entry * static_cast<size_t>(c.n_entries));
+    if (e != hipSuccess) return hip_err(e);
+    if (c.pool) {                                              // grown: keep the spectra already computed
+        e = hipMemcpyAsync(np, c.pool, per_entry * static_cast<size_t>(c.pool_entries), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipDeviceSynchronize();       // earlier launches (any stream) still read the old pool
+        if (e != hipSuccess) { (void)hipFree(np); return hip_err(e); }
+        (void)hipFree(c.pool);
+    }
+    c.pool = np;
+    c.pool_entries = c.n_entries;
+    return 0;
+}
+
+// One step: plan the units (host), compute the missing source-window spectra, render.  `units` are HOST arrays.
+// audiogoal / spectrogram are DEVICE buffers [n,2,sr] / [n,65,T4,2]; either may be NULL (not both).
+int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
+    if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
+    if (n == 0) return 0;
+    ssctx::Context& c = h->c;
+    if (!c.rir || !c.rir_len || !c.src_dev) return SS_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = ctx_ensure_ring(c, n, 0, st);
+    if (rc) return rc;
+    const int k = c.ring_k;
+    c.ring_k = (k + 1) % ssctx::kRing;
+    hipError_t e = hipEventSynchronize(c.ev_copy[k]);          // the copy that last read this pinned slot has run
+    if (e != hipSuccess) return hip_err(e);
+    e = hipStreamWaitEvent(st, c.ev_done[k], 0);               // the launch that last read the device slot (any stream)
+    if (e != hipSuccess) return hip_err(e);
+    int* hd = c.h_desc + static_cast<size_t>(k) * c.ring_cap * 8;
+    int* dd = c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
+    ssctx::PlanResult res;
+    rc = ssctx::plan_units(c, units, n, hd, &res);
+    if (rc) return rc;
+    rc = ctx_ensure_pool(c, st);
+    if (rc) return rc;
+    if (res.n_new_windows > 0) {
+        rc = ctx_ensure_ring(c, n, res.n_new_windows, st);
+        if (rc) return rc;
+        int* hw = c.h_win + static_cast<size_t>(k) * c.win_cap * 5;
+        int* dw = c.d_win + static_cast<size_t>(k) * c.win_cap * 5;
+        std::memcpy(hw, c.new_win.data(), sizeof(int) * 5 * static_cast<size_t>(res.n_new_windows));
+        e = hipMemcpyAsync(dw, hw, sizeof(int) * 5 * static_cast<size_t>(res.n_new_windows), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return hip_err(e);
+        rc = launch_windows_scatter(c.src_dev, dw, c.pool, res.n_new_windows, st);
+        if (rc) return rc;
+    }
+    e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return hip_err(e);
+    e = hipEventRecord(c.ev_copy[k], st);
+    if (e != hipSuccess) return hip_err(e);
+    if (spectrogram && !audiogoal && c.out_len > ssk::kB) {    // rows longer than one block hand over through memory
+        const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
+        if (need > c.ag_cap) {
+            e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_err(e);
+            if (c.ag_scratch) (void)hipFree(c.ag_scratch);
+            c.ag_scratch = nullptr; c.ag_cap = 0;
+            e = hipMalloc(reinterpret_cast<void**>(&c.ag_scratch), need * sizeof(float));
+            if (e != hipSuccess) return hip_err(e);
+            c.ag_cap = need;
+        }
+        audiogoal = c.ag_scratch;
+    }
+    if (spectrogram)
+        rc = ss_audio_obs_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, spectrogram, n, c.rir_us, c.rir_cs, c.rir_es,
+                              c.rir_cap, c.n_valid, c.out_len, c.pad_mode, res.flags, stream);
+    else
+        rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
+                                     c.n_valid, c.out_len, res.flags, stream);
+    if (rc) return rc;
+    e = hipEventRecord(c.ev_done[k], st);
+    return hip_err(e);
 }
 
 }  // extern "C"

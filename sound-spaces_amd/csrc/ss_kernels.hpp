@@ -128,10 +128,14 @@ __device__ __forceinline__ void items_to_time(c32* lds, const ThreadTw& tw, int 
 // at f32x4 index (s*4+h)*1024 + t, so that every consumer load is one coalesced 16-byte access per lane.
 struct SrcParams {
     const float* src;
-    const int* desc;      // [W][4]
-    f32x4* spec;         // [W][8192]
+    const int* desc;      // [W][desc_stride]; desc_stride == 5: word 4 = output slot (scattered into a pool), else slot = w
+    f32x4* spec;         // [slots][8192]
     Tables tb;
+    int desc_stride;      // 4 or 5
+    float scale;          // factor applied to 2*rFFT (window spectra: 1/(8*16384), see k_source_windows)
 };
+
+constexpr float kWindowScale = 1.0f / (8.0f * 16384.0f);   // (2X -> X) * 1/(4M): inverse packing 2x2, 1/M of the IFFT
 
 __device__ __forceinline__ float src_sample(const float* __restrict__ x, int len, int s, int wrap) {
     if (s < 0) return 0.f;
@@ -146,17 +150,18 @@ __device__ __forceinline__ float src_sample(const float* __restrict__ x, int len
 __global__ __launch_bounds__(1024) void k_source_windows(SrcParams p) {
     __shared__ c32 lds[kLdsComplex];
     const int t = threadIdx.x, w = blockIdx.x;
-    const int* d = p.desc + 4 * w;
+    const int* d = p.desc + p.desc_stride * w;
     const float* x = p.src + __builtin_amdgcn_readfirstlane(d[0]);
     const int len = __builtin_amdgcn_readfirstlane(d[1]), start = __builtin_amdgcn_readfirstlane(d[2]);
     const int wrap = __builtin_amdgcn_readfirstlane(d[3]);
+    const int slot = p.desc_stride > 4 ? __builtin_amdgcn_readfirstlane(d[4]) : w;
     const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
     pass1_fwd<false>(lds, tw.p1, t, [&](int m) {
         return mk2(src_sample(x, len, start + 2 * m, wrap), src_sample(x, len, start + 2 * m + 1, wrap));
     });
     fwd_passes(lds, tw, t);
-    constexpr float scale = 1.0f / (8.0f * 16384.0f);   // (2X -> X) * 1/(4M): inverse packing 2x2, 1/M of the IFFT
-    f32x4* o = p.spec + (size_t)w * (kSpecComplex / 2) + t;
+    const float scale = p.scale;                         // window spectra: (2X -> X) * 1/(4M) = 1/(8*16384)
+    f32x4* o = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         c32 v[8];

@@ -9,7 +9,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libss_hip.so"))
 
 EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source_windows_f32",
-           "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32", "ss_gccphat_f32")
+           "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32", "ss_gccphat_f32",
+           "ss_ctx_create", "ss_ctx_destroy", "ss_ctx_add_source", "ss_ctx_add_source_len", "ss_ctx_set_rir_bank",
+           "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats")
+
+
+class SsUnits(ctypes.Structure):
+    """struct ss_units of include/ss_hip.h: host struct-of-arrays descriptors of one step."""
+    _fields_ = [("sound", ctypes.c_void_p), ("t0", ctypes.c_void_p), ("rir", ctypes.c_void_p),
+                ("dis_sound", ctypes.c_void_p), ("dis_rir", ctypes.c_void_p), ("last_rir", ctypes.c_void_p),
+                ("wrap", ctypes.c_void_p), ("last_wrap", ctypes.c_void_p)]
 
 _lib = None
 
@@ -38,6 +47,15 @@ def load() -> ctypes.CDLL:
     lib.ss_intensity_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp]
     lib.ss_gccphat_f32.argtypes = [vp, vp, c_int, c_int, c_int, c_int, ctypes.c_float, vp]
     lib.ss_logmel_f32.argtypes = [vp, vp, c_int, c_int, c_int, vp, vp, c_int, c_int, ctypes.c_float, vp]
+    pp = ctypes.POINTER(ctypes.c_void_p)
+    lib.ss_ctx_create.argtypes = [pp, c_int, c_int, c_int, c_int, c_int]
+    lib.ss_ctx_destroy.argtypes = [vp]
+    lib.ss_ctx_add_source.argtypes = [vp, vp, c_int, c_int]
+    lib.ss_ctx_add_source_len.argtypes = [vp, c_int]
+    lib.ss_ctx_set_rir_bank.argtypes = [vp, vp, vp, c_ll, c_int, c_int, c_int]
+    lib.ss_ctx_observe.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp]
+    lib.ss_ctx_plan.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp, vp, c_int]
+    lib.ss_ctx_stats.argtypes = [vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib

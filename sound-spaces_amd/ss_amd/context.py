@@ -1,0 +1,155 @@
+"""``AudioContext`` — Python face of the library's context API (include/ss_hip.h: ``ss_ctx_*``).
+
+The planner, the bounded cache of source-window spectra and the pinned descriptor ring live INSIDE libss_hip.so
+(csrc/ss_context.hpp); a vector step is ONE ctypes call taking numpy columns {sound, t0, rir, ...} of all envs.  This is
+what the batched observers use (``VectorAudioObserver``, ``bench.py --path plugin``): no per-unit Python, no torch
+tensor construction, no pageable H2D copy on the per-step path.  ``BatchedAudioRenderer.plan()/render()`` (descriptor
+planning in Python, ``planning.py``) remains for pre-planned batches and as the executable specification the C++
+planner is tested against (tests/test_context.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .planning import spectrogram_shape
+
+_PAD = {"reflect": 0, "constant": 1, 0: 0, 1: 1}
+
+
+def _col(a, dtype):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class AudioContext:
+    def __init__(self, sampling_rate: int, step_time: Optional[float] = None, wrap: bool = False,
+                 pad_mode="reflect", max_window_sets: int = 256):
+        """step_time None: SoundSpaces 1.0 (1-s observations); step_time = STEP_TIME with wrap=True: SoundSpaces 2.0."""
+        self.lib = _lib.load()
+        self.sr = int(sampling_rate)
+        self.n_valid = self.sr if step_time is None else int(self.sr * step_time)
+        self.wrap = bool(wrap)
+        self.spectrogram_shape = spectrogram_shape(self.sr)
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.ss_ctx_create(ctypes.byref(h), self.sr, self.n_valid, _PAD[pad_mode], int(self.wrap),
+                                          int(max_window_sets)), "ss_ctx_create")
+        self._h = h
+        self._names: Dict[str, int] = {}
+        self.lengths = []
+        self._bank = None                    # keeps the borrowed tensors alive
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ss_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- banks ---------------------------------------------------------------------------------------------
+    def add_source(self, name: str, clip) -> int:
+        """Register a mono clip (numpy float32 on the host, or a CUDA tensor); idempotent per name."""
+        if name in self._names:
+            return self._names[name]
+        if hasattr(clip, "is_cuda"):
+            import torch
+            t = clip.to(torch.float32).contiguous().reshape(-1)
+            if not t.is_cuda:
+                raise _lib.SsHipError("add_source: tensors must live on the GPU (pass host clips as numpy arrays)")
+            with torch.cuda.device(t.device):
+                sid = self.lib.ss_ctx_add_source(self._h, t.data_ptr(), int(t.numel()), 1)
+            n = int(t.numel())
+        else:
+            a = np.ascontiguousarray(clip, dtype=np.float32).reshape(-1)
+            sid = self.lib.ss_ctx_add_source(self._h, a.ctypes.data, int(a.shape[0]), 0)
+            n = int(a.shape[0])
+        if sid < 0:
+            _lib.check(sid, "ss_ctx_add_source")
+        self._names[name] = sid
+        self.lengths.append(n)
+        return sid
+
+    def add_source_len(self, name: str, length: int) -> int:
+        """Planner-only registration (no device memory): for plan() on machines without a GPU."""
+        if name in self._names:
+            return self._names[name]
+        sid = self.lib.ss_ctx_add_source_len(self._h, int(length))
+        if sid < 0:
+            _lib.check(sid, "ss_ctx_add_source_len")
+        self._names[name] = sid
+        self.lengths.append(int(length))
+        return sid
+
+    def set_rir_bank(self, data, lengths, interleaved: bool = False) -> None:
+        """data: CUDA float32 [R,2,cap] (planar) or [R,cap,2] (wav-interleaved); lengths: CUDA int32 [R]."""
+        if interleaved:
+            R, cap, _ = data.shape
+            us, cs, es = 2 * cap, 1, 2
+        else:
+            R, _, cap = data.shape
+            us, cs, es = 2 * cap, cap, 1
+        _lib.check(self.lib.ss_ctx_set_rir_bank(self._h, data.data_ptr(), lengths.data_ptr(), us, cs, es, int(cap)),
+                   "ss_ctx_set_rir_bank")
+        self._bank = (data, lengths)
+        self.rir_cap = int(cap)
+
+    def set_rir_cap_for_planning(self, cap: int) -> None:
+        """plan()-only use without a GPU: the bank capacity decides how many partition blocks a key needs."""
+        _lib.check(self.lib.ss_ctx_set_rir_bank(self._h, None, None, 2 * cap, cap, 1, int(cap)), "ss_ctx_set_rir_bank")
+        self.rir_cap = int(cap)
+
+    # ---- one step -------------------------------------------------------------------------------------------
+    def _units(self, sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap):
+        cols = [_col(sound, np.int32), _col(t0, np.int32), _col(rir, np.int32), _col(dis_sound, np.int32),
+                _col(dis_rir, np.int32), _col(last_rir, np.int32), _col(wrap, np.uint8), _col(last_wrap, np.uint8)]
+        n = int(cols[0].shape[0])
+        for c in cols:
+            assert c is None or c.shape == (n,)
+        u = _lib.SsUnits(*[None if c is None else c.ctypes.data for c in cols])
+        return u, n, cols
+
+    def observe(self, sound, t0, rir, spectrogram_out=None, audiogoal_out=None, dis_sound=None, dis_rir=None,
+                last_rir=None, wrap=None, last_wrap=None, stream: Optional[int] = None) -> None:
+        """Render one step into the given CUDA tensors ([n,65,T4,2] and / or [n,2,sr], float32, contiguous) on the
+        current torch stream (or `stream`, a raw hipStream_t).  rir < 0 = silent unit."""
+        import torch
+        u, n, keep = self._units(sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap)
+        sg = ag = None
+        dev = None
+        if spectrogram_out is not None:
+            assert spectrogram_out.is_cuda and spectrogram_out.dtype == torch.float32 and spectrogram_out.is_contiguous()
+            assert tuple(spectrogram_out.shape) == (n,) + self.spectrogram_shape
+            sg, dev = spectrogram_out.data_ptr(), spectrogram_out.device
+        if audiogoal_out is not None:
+            assert audiogoal_out.is_cuda and audiogoal_out.dtype == torch.float32 and audiogoal_out.is_contiguous()
+            assert tuple(audiogoal_out.shape) == (n, 2, self.sr)
+            ag, dev = audiogoal_out.data_ptr(), audiogoal_out.device
+        if dev is None:
+            raise ValueError("observe: pass spectrogram_out and / or audiogoal_out")
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.ss_ctx_observe(self._h, ctypes.byref(u), n, ag, sg, stream), "ss_ctx_observe")
+
+    def plan(self, sound, t0, rir, dis_sound=None, dis_rir=None, last_rir=None, wrap=None, last_wrap=None):
+        """The planner alone (host only): -> (unit descriptors int32 [n,8], launch flags, new windows int32 [w,5])."""
+        u, n, keep = self._units(sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap)
+        desc = np.zeros((n, 8), np.int32)
+        flags, nw = ctypes.c_int(0), ctypes.c_int(0)
+        cap = 4 * n + 16
+        wins = np.zeros((cap, 5), np.int32)
+        _lib.check(self.lib.ss_ctx_plan(self._h, ctypes.byref(u), n, desc.ctypes.data, ctypes.addressof(flags),
+                                        ctypes.addressof(nw), wins.ctypes.data, cap), "ss_ctx_plan")
+        assert nw.value <= cap
+        return desc, flags.value, wins[:nw.value]
+
+    def stats(self) -> Dict[str, int]:
+        out = np.zeros(8, np.int64)
+        _lib.check(self.lib.ss_ctx_stats(self._h, out.ctypes.data), "ss_ctx_stats")
+        keys = ("hits", "misses", "evictions", "grows", "capacity", "resident", "slots_per_key", "steps")
+        return dict(zip(keys, (int(v) for v in out)))

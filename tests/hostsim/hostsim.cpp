@@ -110,6 +110,7 @@ extern "C" {
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
     p.src = src; p.desc = desc; p.spec = reinterpret_cast<ssk::f32x4*>(spec); p.tb = host_tables();
+    p.desc_stride = 4; p.scale = ssk::kWindowScale;
     gridDim = dim3{(unsigned)n_windows, 1, 1};
     for (int w = 0; w < n_windows; ++w) {
         blockIdx = dim3{(unsigned)w, 0, 0};

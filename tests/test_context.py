@@ -1,0 +1,234 @@
+"""The context API of libss_hip.so (include/ss_hip.h: ss_ctx_*).  The planner + window cache are host C++ inside the
+library and run without a GPU (ss_ctx_plan), so they are checked here against the Python planner (ss_amd/planning.py,
+the executable specification) on random steps; the GPU half (ss_ctx_observe) is in the `-m gpu` tests below."""
+import numpy as np
+import pytest
+
+from oracle import ss_oracle as O
+from ss_amd import planning as P
+from ss_amd.context import AudioContext
+
+SR = 16000
+
+
+def py_plan(lengths, cap, n_valid, wrap_mode, sound, t0, rir, dis_sound=None, dis_rir=None, last_rir=None, wrap=None,
+            last_wrap=None):
+    """planning.py applied unit by unit -> per unit ((rir, m_min, count, starts...), (term-1 ...)) without slot numbers."""
+    nbh_max, nby = max(1, P.ceil_div(cap, P.KB)), max(1, P.ceil_div(n_valid, P.KB))
+    out = []
+    for i in range(len(sound)):
+        if rir[i] < 0:
+            out.append(None)
+            continue
+        L = lengths[sound[i]]
+        over = t0[i] + n_valid > L
+        w0 = bool(wrap_mode and over and (wrap is None or wrap[i]))
+        ws = P.plan_window_set(L, int(t0[i]), nbh_max, nby, w0)
+        if ws.count == 0:
+            out.append(None)
+            continue
+        a = (int(rir[i]), ws.m_min, ws.count, ws.starts, w0, int(sound[i]))
+        b = None
+        if last_rir is not None and last_rir[i] >= 0:
+            lw = wrap if last_wrap is None else last_wrap
+            w1 = bool(wrap_mode and over and (lw is None or lw[i]))
+            ws1 = P.plan_window_set(L, int(t0[i]), nbh_max, nby, w1)
+            b = (int(last_rir[i]), ws1.m_min, ws1.count, ws1.starts, w1, int(sound[i]))
+        elif dis_rir is not None and dis_rir[i] >= 0:
+            ws1 = P.plan_window_set(lengths[dis_sound[i]], 0, nbh_max, nby, False)
+            if ws1.count:
+                b = (int(dis_rir[i]), ws1.m_min, ws1.count, ws1.starts, False, int(dis_sound[i]))
+        out.append((a, b))
+    return out
+
+
+def check_against_python(ctx, lengths, offsets, cap, n_valid, wrap_mode, pool, **cols):
+    """pool: dict slot -> (src_offset, src_len, start, wrap) of every window the context has ever planned."""
+    desc, flags, wins = ctx.plan(**cols)
+    for w in wins:
+        pool[int(w[4])] = tuple(int(v) for v in w[:4])
+    ref = py_plan(lengths, cap, n_valid, wrap_mode, **cols)
+    any_b = False
+    for i, r in enumerate(ref):
+        d = desc[i]
+        if r is None:
+            assert d[0] == -1 and d[4] == -1
+            continue
+        for term, t in enumerate(r):
+            row = d[4 * term:4 * term + 4]
+            if t is None:
+                assert row[0] == -1
+                continue
+            any_b |= term == 1
+            ridx, m_min, count, starts, w, snd = t
+            assert (row[0], row[2], row[3]) == (ridx, m_min, count)
+            for k in range(count):                       # the slots hold exactly the windows planning.py asks for
+                assert pool[int(row[1]) + k] == (offsets[snd], lengths[snd], starts[k], int(w))
+    if cols.get("last_rir") is not None and any(r is not None and r[1] is not None for r in ref):
+        assert flags == 2
+    else:
+        assert flags == (0 if any_b else 1)
+    return desc, wins
+
+
+@pytest.mark.parametrize("cap,n_valid,wrap_mode", [(16000, 16000, 0), (40000, 16000, 0), (44100, 44100, 0),
+                                                   (20000, 4000, 1), (50000, 4000, 1)])
+def test_cxx_planner_equals_python_planner(cap, n_valid, wrap_mode):
+    rng = np.random.default_rng(cap + n_valid)
+    sr = 44100 if n_valid == 44100 else SR
+    lengths = [sr, sr, 3 * sr, 5 * sr, 20 * sr]
+    offsets = list(np.cumsum([0] + lengths[:-1]))
+    ctx = AudioContext(sr, step_time=None if n_valid == sr else n_valid / sr, wrap=bool(wrap_mode), max_window_sets=32)
+    for i, L in enumerate(lengths):
+        assert ctx.add_source_len(f"s{i}", L) == i
+    ctx.set_rir_cap_for_planning(cap)
+    pool = {}
+    for step in range(30):
+        n = int(rng.integers(1, 70))
+        sound = rng.integers(0, 5, n)
+        if wrap_mode:
+            t0 = np.array([rng.integers(0, lengths[s]) for s in sound])
+        else:
+            t0 = np.array([0 if lengths[s] == sr else rng.integers(0, lengths[s] // sr + 1) * sr for s in sound])
+        rir = rng.integers(-1, 50, n)
+        cols = dict(sound=sound, t0=t0, rir=rir)
+        if wrap_mode:
+            cols["wrap"] = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+            if step % 2:
+                cols["last_rir"] = rng.integers(-1, 50, n)
+                cols["last_wrap"] = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+        elif step % 3 == 0:
+            cols["dis_sound"] = rng.integers(0, 2, n)
+            cols["dis_rir"] = rng.integers(-1, 50, n)
+        check_against_python(ctx, lengths, offsets, cap, n_valid, wrap_mode, pool, **cols)
+    st = ctx.stats()
+    assert st["steps"] == 30 and st["hits"] > 0 and st["misses"] > 0
+    assert st["slots_per_key"] == max(1, P.ceil_div(cap, P.KB)) + max(1, P.ceil_div(n_valid, P.KB)) - 1
+
+
+def test_cache_is_bounded_lru_and_grows_only_when_one_step_needs_it():
+    """the Python renderer's window cache only grew (SS2.0 draws a new t0 per env and step -> HBM leak).  The
+    context's cache recycles least-recently-used keys; keys of recent steps are protected; a step that alone needs
+    more keys than the cache holds grows it."""
+    ctx = AudioContext(SR, step_time=0.25, wrap=True, max_window_sets=16)
+    ctx.add_source_len("s", 3 * SR)
+    ctx.set_rir_cap_for_planning(SR)
+    z = lambda n: np.zeros(n, np.int32)
+    for step in range(200):                               # 4 envs, a new t0 each step: 800 distinct keys in total
+        t0 = (np.arange(4) * 7919 + step * 4000) % (3 * SR)
+        ctx.plan(z(4), t0, z(4))
+    st = ctx.stats()
+    assert st["capacity"] <= 64 and st["resident"] <= st["capacity"] and st["evictions"] > 600
+    ctx.plan(z(4), (np.arange(4) * 7919 + 199 * 4000) % (3 * SR), z(4))          # the last step again: all hits
+    assert ctx.stats()["misses"] == st["misses"]
+    big = AudioContext(SR, max_window_sets=4)
+    for i in range(40):
+        big.add_source_len(f"s{i}", SR)
+    big.set_rir_cap_for_planning(SR)
+    desc, flags, wins = big.plan(np.arange(40), z(40), z(40))                     # 40 keys in ONE step, capacity 4
+    assert len(wins) == 40 and len(set(desc[:, 1])) == 40 and big.stats()["grows"] >= 4
+
+
+def test_planner_rejects_bad_input():
+    from ss_amd._lib import SsHipError
+    ctx = AudioContext(SR)
+    ctx.add_source_len("s", SR)
+    ctx.set_rir_cap_for_planning(SR)
+    with pytest.raises(SsHipError):
+        ctx.plan(np.array([3]), np.array([0]), np.array([0]))                     # unknown sound id
+    with pytest.raises(SsHipError):                                              # distractor AND previous RIR on one unit
+        ctx.plan(np.array([0]), np.array([0]), np.array([0]), dis_sound=np.array([0]), dis_rir=np.array([1]),
+                 last_rir=np.array([1]))
+
+
+# ---- GPU half ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_ctx_observe_matches_renderer_and_oracle():
+    """ss_ctx_observe (planner + cache + ring in the library) renders the same step as the Python-planned renderer,
+    bit for bit, over several steps with cache hits, evictions and a growing batch; spot-checked against the oracle."""
+    import torch
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank
+    dev = "cuda:0"
+    rng = np.random.default_rng(8)
+    src = [O.synth_sources(rng, SR, k=1, seconds=s)[0] for s in (1, 1, 1, 3, 5)]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=12)]
+    bank = RirBank.from_arrays(rirs, dev)
+    r = BatchedAudioRenderer(SR, device=dev)
+    ctx = AudioContext(SR, max_window_sets=8)
+    for i, s in enumerate(src):
+        r.add_source(f"s{i}", s)
+        ctx.add_source(f"s{i}", s)
+    r.set_rir_bank(bank)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    for step, n in enumerate((5, 33, 128, 7)):
+        sound = rng.integers(0, 5, n)
+        t0 = np.array([0 if len(src[s]) == SR else rng.integers(0, len(src[s]) // SR) * SR for s in sound])
+        rir = rng.integers(-1, 12, n)
+        sg = torch.empty((n, 65, 26, 2), device=dev)
+        ag = torch.empty((n, 2, SR), device=dev)
+        ctx.observe(sound, t0, rir, spectrogram_out=sg, audiogoal_out=ag)
+        ag2, sg2 = r.render(r.plan_arrays(sound, t0, rir), want_audiogoal=True)
+        assert torch.equal(sg, sg2) and torch.equal(ag, ag2)
+        sg3 = torch.empty_like(sg)
+        ctx.observe(sound, t0, rir, spectrogram_out=sg3)                          # spectrogram only (fused, no waveform)
+        assert float((sg3 - sg).abs().max()) <= 1e-5 * float(sg.abs().max())
+        k = int(np.flatnonzero(rir >= 0)[0])
+        ref = O.conv_window_fft(src[sound[k]], rirs[rir[k]], int(t0[k]), SR)
+        assert O.relerr(ag[k].cpu().numpy(), ref) <= 1e-4
+    assert ctx.stats()["hits"] > 0
+
+
+@pytest.mark.gpu
+def test_ctx_observe_distractor_crossfade_and_44k():
+    import torch
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank, UnitRequest
+    dev = "cuda:0"
+    rng = np.random.default_rng(9)
+    # distractors (SS1.0)
+    src = list(O.synth_sources(rng, SR, k=3))
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=6)]
+    bank = RirBank.from_arrays(rirs, dev)
+    ctx = AudioContext(SR)
+    for i, s in enumerate(src):
+        ctx.add_source(f"s{i}", s)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    n = 9
+    sound, rir = rng.integers(0, 3, n), rng.integers(0, 6, n)
+    ds, dr = rng.integers(0, 3, n), rng.integers(-1, 6, n)
+    ag = torch.empty((n, 2, SR), device=dev)
+    ctx.observe(sound, np.zeros(n), rir, audiogoal_out=ag, dis_sound=ds, dis_rir=dr)
+    for i in range(n):
+        ref = O.compute_audiogoal(src[sound[i]], rirs[rir[i]], SR, distractor=src[ds[i]] if dr[i] >= 0 else None,
+                                  distractor_rir=rirs[dr[i]] if dr[i] >= 0 else None)
+        assert O.relerr(ag[i].cpu().numpy(), ref) <= 1e-4
+    # SS2.0 cross-fade
+    src3 = O.tile_short_source(src[0], SR)
+    rl = [np.ascontiguousarray(O.synth_rir(rng, SR, length=L, n=1)[0].T) for L in (9000, 12000, 20000)]
+    bank2 = RirBank.from_arrays(rl, dev)
+    c2 = AudioContext(SR, step_time=0.25, wrap=True)
+    c2.add_source("s", src3)
+    c2.set_rir_bank(bank2.data, bank2.lengths)
+    idx = np.array([100, 15000, 30000, 46000, 47000])
+    cur, last = np.array([0, 1, 2, 0, 1]), np.array([1, 2, 0, -1, 2])
+    Ls = np.array([9000, 12000, 20000])
+    ag = torch.empty((5, 2, SR), device=dev)
+    sg = torch.empty((5, 65, 26, 2), device=dev)
+    c2.observe(np.zeros(5), idx, cur, spectrogram_out=sg, audiogoal_out=ag, last_rir=last,
+               wrap=(idx >= Ls[cur]).astype(np.uint8), last_wrap=(idx >= Ls[np.maximum(last, 0)]).astype(np.uint8))
+    for i in range(5):
+        ref = O.compute_audiogoal_continuous(src3, rl[cur[i]], SR, int(idx[i]), 0.25,
+                                             last_rir=rl[last[i]] if last[i] >= 0 else None, use_crossfade=True)
+        assert O.relerr(ag[i].cpu().numpy(), ref) <= 1e-4
+        assert O.relerr(sg[i].cpu().numpy(), O.compute_spectrogram(ref.astype(np.float32))) <= 1e-4
+    # 44.1 kHz, spectrogram only: the hand-over buffer is the context's own
+    sr = 44100
+    s44 = O.synth_sources(rng, sr, k=1)[0]
+    r44 = [np.ascontiguousarray(O.synth_rir(rng, sr, n=1)[0].T)]
+    b44 = RirBank.from_arrays(r44, dev)
+    c3 = AudioContext(sr)
+    c3.add_source("s", s44)
+    c3.set_rir_bank(b44.data, b44.lengths)
+    sg = torch.empty((2, 65, 69, 2), device=dev)
+    c3.observe(np.zeros(2), np.zeros(2), np.array([0, -1]), spectrogram_out=sg)
+    a = O.compute_audiogoal(s44, r44[0], sr)
+    assert O.relerr(sg[0].cpu().numpy(), O.compute_spectrogram(a)) <= 1e-4 and not sg[1].any()
