@@ -88,6 +88,111 @@ def synth_rir_bank_device(torch, n, sr, length, device, seed):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Plugin path: what a vector env pays per step when it goes through the Habitat-side boundary instead of handing the
+# kernels pre-planned descriptors -- simulator state -> units -> planning -> descriptor upload -> launch -> rollout
+# rows, ALL inside the timed region (the headline above pre-plans its descriptors).
+class SyntheticSim:
+    """Stand-in for SoundSpacesSim with the attributes its audio code reads (soundspaces/simulator.py:110-117,
+    303-305) and a `move()` that changes them the way `step()` does (:500-516: rotate by +-90 or hop to a neighbour)."""
+
+    def __init__(self, sounds, n_nodes, rng):
+        self._source_sound_dict = sounds
+        self._current_sound = "sound%d" % rng.integers(0, len(sounds))
+        self._current_distractor_sound = None
+        self._episode_step_count, self._duration = 0, 500
+        self._receiver_position_index = int(rng.integers(0, n_nodes))
+        self._source_position_index = int(rng.integers(0, n_nodes))
+        self._distractor_position_index = 0
+        self._rotation_angle = int(rng.integers(0, 4)) * 90
+        self._audio_index = 0
+
+    def move(self, action, node):
+        if action == 0:
+            self._receiver_position_index = node
+        elif action == 1:
+            self._rotation_angle = (self._rotation_angle + 90) % 360
+        else:
+            self._rotation_angle = (self._rotation_angle - 90) % 360
+        self._episode_step_count += 1
+
+
+def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, steps, warmup):
+    """-> dict for the JSON line.  One 'scene' of n_nodes x n_nodes (receiver, source) pairs whose 4 azimuths sit in 4
+    adjacent rows of `bank` (the same HBM-resident bank as the headline); n_envs stand-in simulators bound to a
+    VectorSimState; per step: agents move (attribute writes on the simulators), FastVectorAudioObserver.observe_into()
+    renders all envs into the rollout rows of the next insert()."""
+    import types
+    from ss_amd.context import AudioContext
+    from ss_amd.rollout import RolloutStorage
+    from ss_amd.vector import FastVectorAudioObserver, RirIndex, VectorSimState
+    from ss_amd import planning as P
+    R = bank.shape[0]
+    n_nodes = int(np.sqrt(R // 4))
+    rng = np.random.default_rng(5)
+    sounds = {"sound%d" % i: c for i, c in enumerate(sources)}
+    ctx = AudioContext(sr, max_window_sets=max(256, 2 * n_sounds))
+    ctx.set_rir_bank(bank, torch.full((R,), bank.shape[2], dtype=torch.int32, device=dev))
+    index = RirIndex(4)
+    sid = index.add_scene("synthetic", n_nodes)
+    rr, ss = np.meshgrid(np.arange(n_nodes), np.arange(n_nodes), indexing="ij")
+    index.set(sid, rr.reshape(-1), ss.reshape(-1), (4 * (rr * n_nodes + ss)).reshape(-1).astype(np.int32))
+    sims = [SyntheticSim(sounds, n_nodes, rng) for _ in range(n_envs)]
+    state = VectorSimState(n_envs)
+    for i, sim in enumerate(sims):
+        state.bind(sim, i)
+    state.scene[:] = sid
+    obs = FastVectorAudioObserver(ctx, state, index, sr)
+    T = 16
+    space = types.SimpleNamespace(spaces={"spectrogram": types.SimpleNamespace(shape=P.spectrogram_shape(sr))})
+
+    class ActionSpace:                      # RolloutStorage tests the class name, like the reference
+        pass
+    rollouts = RolloutStorage(T, n_envs, space, ActionSpace(), 8, device=dev)
+    total = warmup + steps
+    acts = rng.integers(0, 3, (total, n_envs))
+    nodes = rng.integers(0, n_nodes, (total, n_envs))
+
+    def run(k0, k1, move_sims, host_us=None):
+        for k in range(k0, k1):
+            if move_sims:                   # the simulators' own work: attribute writes land in the columns
+                a, nd = acts[k], nodes[k]
+                for i, sim in enumerate(sims):
+                    sim.move(a[i], int(nd[i]))
+            else:                           # the same motion applied to the columns directly (vectorised env)
+                a = acts[k]
+                state.recv[:] = np.where(a == 0, nodes[k], state.recv)
+                state.rot[:] = np.where(a == 1, (state.rot + 90) % 360, np.where(a == 2, (state.rot - 90) % 360, state.rot))
+                state.step_count += 1
+            t0 = time.perf_counter()
+            obs.observe_into(rollouts)
+            rollouts.step = (rollouts.step + 1) % T      # the other fields of insert() are the trainer's business
+            if host_us is not None:
+                host_us.append(1e6 * (time.perf_counter() - t0))
+
+    out = {}
+    for name, move_sims in (("columns", False), ("bound_sims", True)):
+        run(0, warmup, move_sims)
+        torch.cuda.synchronize()
+        host_us = []
+        t0 = time.perf_counter()
+        run(warmup, total, move_sims, host_us)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        h = np.sort(np.asarray(host_us))
+        out[name] = {"env_steps_per_s": round(n_envs * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 5),
+                     "observe_into_host_us": {"median": round(float(np.median(h)), 2),
+                                              "p10": round(float(h[len(h) // 10]), 2),
+                                              "p90": round(float(h[(9 * len(h)) // 10]), 2)}}
+    out["note"] = ("simulator state -> columns -> RIR table lookup -> ss_ctx_observe (C++ planner + window cache + pinned "
+                   "descriptor ring) -> spectrograms written into rollouts.observations['spectrogram'][step+1]; planning "
+                   "and descriptor upload inside the timed region.  'columns': agent motion applied to the state columns "
+                   "(vectorised env); 'bound_sims': motion applied through attribute writes on %d Python simulator objects "
+                   "bound to the columns (their Python loop is the simulators' cost, not the audio path's)" % n_envs)
+    out["cache"] = ctx.stats()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +216,7 @@ def main():
                          "rows may already start)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
     args = ap.parse_args()
 
@@ -292,6 +398,10 @@ def main():
             out["roofline_conv_only"] = {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel": "k_conv<FUSE=false>",
                                          "bytes_per_unit": b["conv"], "avg_launch_ms": round(conv_ms, 5)}
+        if world == 1 and not args.no_plugin_path and sr <= P.KB:
+            srcs = [r.sources._host[i] for i in range(len(r.sources))]
+            out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, N, bank, args.sounds, srcs,
+                                                     min(args.steps, 400), min(args.warmup, 50))
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)

