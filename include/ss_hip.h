@@ -91,6 +91,24 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
                      long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
                      int rir_cap, int n_valid, int out_len, int pad_mode, int flags, void* stream);
 
+/* ---- Spectral RIR bank ("store the RIR bank as half-spectra: x2 bytes, -50 % FLOPs") -----------------------
+ * SoundSpaces 1.0 RIRs are static files (simulator.py:615-618), so the forward FFT of the RIR that fftconvolve repeats
+ * on every step (:630) can be done ONCE when the bank is built.  ss_rir_spectra_f32 turns a planar time-domain bank
+ * (sample j of ear c of entry r at rir[r*rir_unit_stride + c*rir_chan_stride + j], rows zero beyond their length up to
+ * rir_cap) into hspec_out = n_entries * 2 * h_blocks * ss_spec_floats() floats, h_blocks = ceil(rir_cap / kB): the
+ * block spectra of every (entry, ear) in the kernels' register order (opaque).  Synchronous (one-off, at bank load).
+ * The *_spec_* entry points are ss_fftconv_binaural_f32 / ss_audio_obs_f32 reading that bank: same unit descriptors,
+ * same rir_len (it still says how many blocks of an entry are non-zero), same results to fp32 rounding, no forward
+ * FFT.  They read 2x the bytes per RIR; SS_FLAG_CROSSFADE is not supported (live SS2.0 RIRs have no static bank). */
+int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride,
+                       int rir_chan_stride, int rir_cap, void* stream);
+int ss_fftconv_binaural_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,
+                                 float* out, int n_units, int h_blocks, int n_valid, int out_len, int flags,
+                                 void* stream);
+int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,
+                          float* audiogoal, float* spectrogram, int n_units, int h_blocks, int n_valid, int out_len,
+                          int pad_mode, int flags, void* stream);
+
 /* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
  * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream);
@@ -159,6 +177,9 @@ int ss_ctx_add_source_len(ss_ctx* ctx, int len);   /* planner-only registration 
 /* RIR bank in device memory, addressing as for ss_fftconv_binaural_f32; the pointers are borrowed. */
 int ss_ctx_set_rir_bank(ss_ctx* ctx, const float* rir, const int* rir_len, long long rir_unit_stride,
                         int rir_chan_stride, int rir_elem_stride, int rir_cap);
+/* Optional spectral form (ss_rir_spectra_f32) of the bank given to ss_ctx_set_rir_bank: steps without a cross-fade then
+ * run the *_spec_* kernels.  hspec = NULL: back to the time-domain kernels.  Borrowed pointer. */
+int ss_ctx_set_rir_spectra(ss_ctx* ctx, const float* hspec, int h_blocks);
 /* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
  * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
 int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);

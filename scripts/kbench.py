@@ -16,6 +16,10 @@ ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--sizes", default="128,2048")
 ap.add_argument("--only", default="")
 ap.add_argument("--bank-mib", type=int, default=512)
+ap.add_argument("--spectral", action="store_true", help="spectral RIR bank (k_conv_spec) instead of the time-domain bank")
+ap.add_argument("--raw", action="store_true", help="launch through bound ctypes calls (host overhead ~3 us per launch)")
+ap.add_argument("--sort", action="store_true", help="units sorted by sound id modulo 8 (with SS_HIP_XCD_MAP=1: one group of sounds per XCD)")
+ap.add_argument("--distinct", type=int, default=8, help="pre-planned batches cycled (8 x 128 envs fit the Infinity Cache; bench.py streams)")
 ap.add_argument("--sounds", type=int, default=102, help="source clips (102 = bench.py: 13 MB of window spectra, more than one XCD's L2)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -26,6 +30,8 @@ for i, c in enumerate(O.synth_sources(rng, sr, k=a.sounds)):
     r.add_source(str(i), c)
 R = max(8, (a.bank_mib << 20) // (2 * sr * 4))
 r.set_rir_bank(RirBank(synth_rir_bank_device(torch, R, sr, sr, dev, 3), torch.full((R,), sr, dtype=torch.int32, device=dev)))
+if a.spectral:
+    r.rirs.build_spectra()
 
 def timeit(fn, reps):
     for _ in range(5): fn(0)
@@ -36,11 +42,53 @@ def timeit(fn, reps):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
+from ss_amd import _lib
+LIB = _lib.load()
+STREAM = torch.cuda.current_stream().cuda_stream
+
+
+def raw_conv(plan, out):
+    """bound ctypes call (no per-launch torch / Python checks: ~3 us of host time instead of ~11, so that kernels shorter
+    than the Python wrapper's overhead are still timed by the events)"""
+    if r.rirs.spectra is not None:
+        args = (r._spec.data_ptr(), r.rirs.spectra.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(), out.data_ptr(),
+                len(plan), r.rirs.spectra.shape[2], r.n_valid, r.out_len, plan.flags, STREAM)
+        fn = LIB.ss_fftconv_binaural_spec_f32
+    else:
+        cap = r.rirs.cap
+        args = (r._spec.data_ptr(), r.rirs.data.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(), out.data_ptr(),
+                len(plan), 2 * cap, cap, 1, cap, r.n_valid, r.out_len, plan.flags, STREAM)
+        fn = LIB.ss_fftconv_binaural_f32
+    return lambda: fn(*args)
+
+
+def raw_fused(plan, sg):
+    if r.rirs.spectra is not None:
+        args = (r._spec.data_ptr(), r.rirs.spectra.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(), None,
+                sg.data_ptr(), len(plan), r.rirs.spectra.shape[2], r.n_valid, r.out_len, 0, plan.flags, STREAM)
+        fn = LIB.ss_audio_obs_spec_f32
+    else:
+        cap = r.rirs.cap
+        args = (r._spec.data_ptr(), r.rirs.data.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(), None,
+                sg.data_ptr(), len(plan), 2 * cap, cap, 1, cap, r.n_valid, r.out_len, 0, plan.flags, STREAM)
+        fn = LIB.ss_audio_obs_f32
+    return lambda: fn(*args)
+
+
 for N in [int(x) for x in a.sizes.split(",")]:
-    descs = [r.plan_arrays(rng.integers(0, a.sounds, N), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(8)]
+    def snd():
+        s_ = rng.integers(0, a.sounds, N)
+        return s_[np.argsort(s_ % 8, kind="stable")] if a.sort else s_
+    descs = [r.plan_arrays(snd(), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(a.distinct)]
     ag = torch.empty((N, 2, sr), device=dev); sg = torch.empty((N,) + r.spectrogram_shape, device=dev)
     res = {}
-    if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % 8], spectrogram_out=sg, audiogoal_out=(ag if sr > 16384 else None)), a.reps)
-    if a.only in ("", "conv"): res["conv"] = timeit(lambda k: r.render_audiogoal(descs[k % 8], out=ag), a.reps)
+    if a.raw and sr <= 16384:
+        cf = [raw_fused(d, sg) for d in descs]; cc = [raw_conv(d, ag) for d in descs]
+        if a.only in ("", "fused"): res["fused"] = timeit(lambda k: cf[k % a.distinct](), a.reps)
+        if a.only in ("", "conv"): res["conv"] = timeit(lambda k: cc[k % a.distinct](), a.reps)
+        print(f"N={N} sr={sr} raw {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} dbg={os.environ.get('SS_HIP_DBG', '0')} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
+        continue
+    if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % a.distinct], spectrogram_out=sg, audiogoal_out=(ag if sr > 16384 else None)), a.reps)
+    if a.only in ("", "conv"): res["conv"] = timeit(lambda k: r.render_audiogoal(descs[k % a.distinct], out=ag), a.reps)
     if a.only in ("", "spec"): res["spec"] = timeit(lambda k: ops.spectrogram_into(ag, sg), a.reps)
-    print(f"N={N} sr={sr} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
+    print(f"N={N} sr={sr} {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)

@@ -67,6 +67,8 @@ struct Context {
     const int* rir_len = nullptr;
     long long rir_us = 0;
     int rir_cs = 0, rir_es = 1, rir_cap = 0;
+    const float* hspec = nullptr; // spectral form of the same bank (optional, borrowed)
+    int h_blocks = 0;
     // window-spectra cache
     int stride = 1;               // pool slots per entry = nbh_max + nby - 1
     int n_entries = 0;            // host bookkeeping (may run ahead of the device pool, see cache_grow)

@@ -122,8 +122,9 @@ static int launch_windows_scatter(const float* src, const int* win_desc5, float*
 }
 
 static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const float* rir, const int* rir_len,
-                     const int* unit_desc, long long us, int cs, int es, int cap, int n_valid, int out_len) {
-    if (!spec || !rir || !rir_len || !unit_desc) return SS_EINVAL;
+                     const int* unit_desc, long long us, int cs, int es, int cap, int n_valid, int out_len,
+                     bool need_rir = true) {
+    if (!spec || (need_rir && !rir) || !rir_len || !unit_desc) return SS_EINVAL;
     if (n_valid < 0 || out_len <= 0 || n_valid > out_len || n_valid > 3 * ssk::kB) return SS_EINVAL;
     if (es < 1 || cs < 0 || us < 0 || cap < 0) return SS_EINVAL;
     int rc = get_tables(&p.tb, n_cus);
@@ -144,6 +145,13 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.t4 = t4_of(out_len);
     p.pad_mode = 0;
     p.fade_len = static_cast<int>(0.05 * out_len);     // crossfade_samples = int(0.05 * sr), rows are 1 s (out_len == sr)
+    p.hspec = nullptr;
+    p.h_blocks = 0;
+    // default on: the two ears of a unit (same window spectrum) share an XCD's L2; SS_HIP_XCD_MAP=0 is the A/B switch
+    static const int xcd_map = getenv("SS_HIP_XCD_MAP") ? atoi(getenv("SS_HIP_XCD_MAP")) : 1;
+    p.xcd_map = xcd_map;
+    static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
+    p.dbg = dbg;
     return 0;
 }
 
@@ -278,6 +286,108 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
 }
 
 
+// ---- spectral RIR bank ---------------------------------------------------------------------------------------------
+int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride, int rir_chan_stride,
+                       int rir_cap, void* stream) {
+    if (n_entries == 0) return 0;
+    if (!rir || !hspec_out || n_entries < 0 || rir_cap <= 0 || rir_unit_stride < 0 || rir_chan_stride < 0) return SS_EINVAL;
+    const int hb = (rir_cap + ssk::kB - 1) / ssk::kB;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // window offsets are int32 words relative to a base pointer: walk the bank in chunks that keep them below 2^31
+    long long per = (rir_unit_stride > 0) ? ((1LL << 30) / rir_unit_stride) : n_entries;
+    if (per < 1) return SS_EINVAL;
+    if (per > 2048) per = 2048;
+    std::vector<int> host(static_cast<size_t>(per) * 2 * hb * 4);
+    int* dev_desc = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev_desc), host.size() * sizeof(int));
+    if (e != hipSuccess) return hip_err(e);
+    int rc = 0;
+    for (long long r0 = 0; r0 < n_entries && rc == 0; r0 += per) {
+        const int cnt = static_cast<int>(n_entries - r0 < per ? n_entries - r0 : per);
+        int w = 0;
+        for (int r = 0; r < cnt; ++r)
+            for (int c = 0; c < 2; ++c)
+                for (int i = 0; i < hb; ++i, ++w) {
+                    const int left = rir_cap - i * ssk::kB;
+                    host[4 * w + 0] = static_cast<int>(r * rir_unit_stride + (long long)c * rir_chan_stride + (long long)i * ssk::kB);
+                    host[4 * w + 1] = left < ssk::kB ? left : ssk::kB;       // the block's samples; zero padding beyond
+                    host[4 * w + 2] = 0;
+                    host[4 * w + 3] = 0;
+                }
+        e = hipMemcpyAsync(dev_desc, host.data(), sizeof(int) * 4 * static_cast<size_t>(w), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { rc = hip_err(e); break; }
+        ssk::SrcParams p;
+        rc = get_tables(&p.tb);
+        if (rc) break;
+        p.src = rir + r0 * rir_unit_stride;
+        p.desc = dev_desc;
+        p.spec = reinterpret_cast<ssk::f32x4*>(hspec_out) + static_cast<size_t>(r0) * 2 * hb * (ssk::kSpecComplex / 2);
+        p.desc_stride = 4;
+        p.scale = 1.0f;                                                   // H' = 2 * rFFT, unscaled (S' carries 1/(8M))
+        hipLaunchKernelGGL(ssk::k_source_windows, dim3(w), dim3(ssk::kT), 0, st, p);
+        rc = hip_err(hipGetLastError());
+        if (rc == 0) rc = hip_err(hipStreamSynchronize(st));             // host[] / dev_desc are reused by the next chunk
+    }
+    (void)hipFree(dev_desc);
+    return rc;
+}
+
+}  // extern "C"
+
+template <bool FUSE>
+static int launch_conv_spec(const ssk::ConvParams& p, int n_units, int nb_y, int flags, hipStream_t st) {
+    if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1) || (flags & SS_FLAG_CROSSFADE)) return SS_EINVAL;
+    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1;
+    const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
+    if (simple) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
+    return hip_err(hipGetLastError());
+}
+
+extern "C" {
+
+int ss_fftconv_binaural_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,
+                                 float* out, int n_units, int h_blocks, int n_valid, int out_len, int flags,
+                                 void* stream) {
+    if (n_units == 0) return 0;
+    if (!out || !hspec || n_units < 0 || h_blocks < 1) return SS_EINVAL;
+    ssk::ConvParams p;
+    int n_cus = 1;
+    int rc = fill_conv(p, &n_cus, spec, nullptr, rir_len, unit_desc, 0, 0, 1, 0, n_valid, out_len, false);
+    if (rc) return rc;
+    p.out = out;
+    p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
+    p.h_blocks = h_blocks;
+    const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
+    return launch_conv_spec<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream));
+}
+
+int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,
+                          float* audiogoal, float* spectrogram, int n_units, int h_blocks, int n_valid, int out_len,
+                          int pad_mode, int flags, void* stream) {
+    if (n_units == 0) return 0;
+    if (!spectrogram || !hspec || n_units < 0 || h_blocks < 1) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (out_len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    ssk::ConvParams p;
+    int n_cus = 1;
+    int rc = fill_conv(p, &n_cus, spec, nullptr, rir_len, unit_desc, 0, 0, 1, 0, n_valid, out_len, false);
+    if (rc) return rc;
+    p.pad_mode = pad_mode;
+    p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
+    p.h_blocks = h_blocks;
+    if (out_len <= ssk::kB && p.t4 <= 26) {
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_conv_spec<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
+    }
+    if (!audiogoal) return SS_EINVAL;
+    rc = ss_fftconv_binaural_spec_f32(spec, hspec, rir_len, unit_desc, audiogoal, n_units, h_blocks, n_valid, out_len,
+                                      flags, stream);
+    if (rc) return rc;
+    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+}
+
 // ---- context API (include/ss_hip.h): planner + window-spectra cache + descriptor ring inside the library --------------
 struct ss_ctx { ssctx::Context c; };
 
@@ -381,6 +491,17 @@ int ss_ctx_set_rir_bank(ss_ctx* h, const float* rir, const int* rir_len, long lo
     return 0;
 }
 
+// Spectral form of the bank set by ss_ctx_set_rir_bank (same entries, same rir_len): steps without a cross-fade then
+// run k_conv_spec.  hspec = NULL switches back to the time-domain kernels.
+int ss_ctx_set_rir_spectra(ss_ctx* h, const float* hspec, int h_blocks) {
+    if (!h || (hspec && h_blocks < 1)) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    if (hspec && h_blocks != (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1)) return SS_EINVAL;
+    c.hspec = hspec;
+    c.h_blocks = hspec ? h_blocks : 0;
+    return 0;
+}
+
 int ss_ctx_plan(ss_ctx* h, const ss_units* units, int n, int* unit_desc_out, int* flags_out, int* n_new_windows_out,
                 int* new_windows_out, int new_windows_cap) {
     if (!h || !unit_desc_out) return SS_EINVAL;
@@ -472,7 +593,7 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
     if (n == 0) return 0;
     ssctx::Context& c = h->c;
-    if (!c.rir || !c.rir_len || !c.src_dev) return SS_EINVAL;
+    if ((!c.rir && !c.hspec) || !c.rir_len || !c.src_dev) return SS_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = ctx_ensure_ring(c, n, 0, st);
     if (rc) return rc;
@@ -517,9 +638,16 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
         }
         audiogoal = c.ag_scratch;
     }
-    if (spectrogram)
+    const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);
+    if (spectrogram && spectral)
+        rc = ss_audio_obs_spec_f32(c.pool, c.hspec, c.rir_len, dd, audiogoal, spectrogram, n, c.h_blocks, c.n_valid,
+                                   c.out_len, c.pad_mode, res.flags, stream);
+    else if (spectrogram)
         rc = ss_audio_obs_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, spectrogram, n, c.rir_us, c.rir_cs, c.rir_es,
                               c.rir_cap, c.n_valid, c.out_len, c.pad_mode, res.flags, stream);
+    else if (spectral)
+        rc = ss_fftconv_binaural_spec_f32(c.pool, c.hspec, c.rir_len, dd, audiogoal, n, c.h_blocks, c.n_valid, c.out_len,
+                                          res.flags, stream);
     else
         rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
                                      c.n_valid, c.out_len, res.flags, stream);

@@ -42,6 +42,26 @@ __device__ __forceinline__ i32x4 uniform_load4(const int* ptr) {   // 4 consecut
 
 __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b; return r; }
 
+// Streamed-once global accesses (a RIR row is read by ONE workgroup once per step, an audiogoal row written once):
+// the nt policy keeps them from displacing the window spectra, which every step re-reads, from the XCD's 4 MiB L2
+// (MI355X_MICROARCH price list "nt-weights": -18 % issue-to-landed for data one CU reads once).
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
 constexpr int kNfft = 512, kHop = 160, kPool = 4, kBins4 = 65;   // 257 bins -> 65 pooled rows
 constexpr int kPrevPairs = 1104;          // XFADE: packed pairs of the cross-fade ramp kept per row (fade_len <= 2206)
@@ -778,7 +798,24 @@ struct ConvParams {
     int out_len;                 // row length
     int n_frames, t4, pad_mode;  // spectrogram geometry for the fused path
     int fade_len;                // XFADE kernels: cross-fade ramp covers samples 0..fade_len (continuous_simulator.py:47-53)
+    // spectral RIR bank (k_conv_spec): block spectra H' = 2*rFFT_{2kB}(rir[i*kB:(i+1)*kB]) in kernel order,
+    // [entry][ear][h_blocks][8192] f32x4; rir / rir_*_stride / rir_cap are unused by those kernels
+    const f32x4* hspec;
+    int h_blocks;
+    int xcd_map;                 // != 0: launch slots are dealt to the XCDs in contiguous ranges (row_slot)
+    int dbg;                     // timing experiments only (scripts/gpu_ladder.sh): early exit point, 0 = full kernel
 };
+
+// Workgroup b of a 1-D launch runs on XCD b % 8 (MI355X_MICROARCH: observed dispatch order, for speed only).  Dealing
+// the (unit, ear) rows out in that order puts the two ears of a unit - which read the SAME 128 KiB window spectrum -
+// on two different XCDs, i.e. in two different L2s, and scatters the units of one sound over all eight.  row_slot()
+// gives XCD x the contiguous slot range [x*G/8, (x+1)*G/8): both ears of a unit, and (with units sorted by sound by the
+// planner) all rows of a group of sounds, share one L2.
+__device__ __forceinline__ int row_slot(int b, int G, int on) {
+    if (!on) return b;
+    const int x = b & 7, q = G >> 3, r = G & 7;
+    return x * q + min(x, r) + (b >> 3);
+}
 
 // forward FFT of RIR block i of one ear + multiply by the window spectrum `slot` -> acc (= or +=)
 template <bool ACCUMULATE, bool PREFETCH>
@@ -796,7 +833,7 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const 
     if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
         const c32* h2 = reinterpret_cast<const c32*>(h + lo);
         const int m_end = (cap - lo) >> 1;
-        pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? h2[m] : mk2(0.f, 0.f); });
+        pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? ld_stream(h2 + m) : mk2(0.f, 0.f); });
     } else {
         pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
             const int n = lo + 2 * m;
@@ -894,7 +931,7 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
         c32* o2 = reinterpret_cast<c32*>(orow) + t;
         const int m_end = nv >> 1;
 #pragma unroll
-        for (int a = 0; a < 8; ++a) if (t + 1024 * a < m_end) o2[1024 * a] = y[a];
+        for (int a = 0; a < 8; ++a) if (t + 1024 * a < m_end) st_stream(o2 + 1024 * a, y[a]);
     } else {
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
@@ -963,7 +1000,8 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
-    const int unit = blockIdx.x >> 1, ch = blockIdx.x & 1, j = SIMPLE ? 0 : blockIdx.y;
+    const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
+    const int unit = slot >> 1, ch = slot & 1, j = SIMPLE ? 0 : blockIdx.y;
     const int* d = p.desc + 8 * unit;
     const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
     // fused path: the STFT's window and exp(-2 pi i k/512) tables are staged in the 21 KiB of LDS the FFT buffer
@@ -996,7 +1034,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                 const c32* h2 = reinterpret_cast<const c32*>(h);
                 const int m_end = cap >> 1;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) hraw[a] = (t + 1024 * a < m_end) ? h2[t + 1024 * a] : mk2(0.f, 0.f);
+                for (int a = 0; a < 8; ++a) hraw[a] = (t + 1024 * a < m_end) ? ld_stream(h2 + t + 1024 * a) : mk2(0.f, 0.f);
             }
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
@@ -1098,6 +1136,118 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
+        if (t < 256) s_tw512[posN(t)] = tw512_v;
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_conv_spec: the same convolution from a SPECTRAL RIR bank (SURVEY 7 "store the RIR bank as half-spectra":
+// twice the bytes, half the flops).  SoundSpaces 1.0 RIRs are static files (simulator.py:615-618), so their block
+// spectra H'_i = 2*rFFT_{2kB}(rir[i*kB:(i+1)*kB]) are computed ONCE when the bank is built (ss_rir_spectra_f32:
+// k_source_windows run over the bank rows with scale 1) and stored in the register order the item stage consumes,
+// exactly like the source-window spectra.  A row is then
+//     Y_j = sum_i H'_i * S'_{j-i}   (16 complex multiplies per thread and block pair, straight from two coalesced
+//                                    16-byte loads per lane, no LDS)  ->  Hermitian merge + inverse radix-4 -> LDS ->
+//     passes 3'-2'-1' -> the row's kB samples in registers  ->  store / fused STFT
+// i.e. the forward FFT (passes 1-3, half of the item stage, 4 of the 8 workgroup barriers) is gone.  Per (unit, ear)
+// and RIR block the kernel READS 128 KiB of H' (vs 64 KiB of time-domain RIR): the algorithmic bytes of SURVEY 8(d)
+// are defined on the time-domain bank, the actual traffic of this kernel is about twice that - reported as such.
+// Same unit descriptors as k_conv (term = {bank entry | -1, first window slot, m_min, count}); rir_len[entry] still
+// says how many blocks of the entry are non-zero.
+__device__ __forceinline__ void spec_block_product(const ConvParams& p, int t, const f32x4* hp, int slot, bool accumulate,
+                                                   c32 (&acc)[2][8]) {
+    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+    f32x4 hv[2][4], sv[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) { hv[s][hh] = ld_stream(hp + (s * 4 + hh) * 1024); sv[s][hh] = sp[(s * 4 + hh) * 1024]; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const c32 h = (e & 1) ? hv[s][e >> 1].zw : hv[s][e >> 1].xy;
+            const c32 w = (e & 1) ? sv[s][e >> 1].zw : sv[s][e >> 1].xy;
+            c32 pr = cmul(h, w);
+            if (s == 0 && e == 0 && t == 0) pr = mk2(h.x * w.x, h.y * w.y);      // (X[0], X[16384]) are real
+            if (accumulate) acc[s][e] += pr; else acc[s][e] = pr;
+        }
+}
+
+template <bool FUSE, bool SIMPLE>
+__global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
+    __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
+    const int t = threadIdx.x;
+    const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
+    const int unit = slot >> 1, ch = slot & 1, j = SIMPLE ? 0 : blockIdx.y;
+    const int* d = p.desc + 8 * unit;
+    __shared__ float s_win[FUSE ? kNfft : 1];
+    __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
+    c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
+    float win_v = 0.f;
+    c32 acc[2][8];
+    c32 y[8];
+    bool any = false;
+    const size_t row_f4 = (size_t)p.h_blocks * (kSpecComplex / 2);     // f32x4 per (entry, ear)
+    if (SIMPLE) {
+        const i32x4 dw = uniform_load4(d);
+        const int ridx = dw.x;
+        if (ridx >= 0) {
+            // the H' row needs only the bank index: its loads go out before the length word is waited for
+            const f32x4* hp = p.hspec + ((size_t)ridx * 2 + ch) * row_f4 + t;
+            const int L = uniform_load(p.rir_len + ridx);
+            if (L > 0 && dw.z <= 0 && dw.z + dw.w > 0) {
+                spec_block_product(p, t, hp, dw.y - dw.z, false, acc);
+                any = true;
+            }
+        }
+    } else {
+        for (int term = 0; term < 2; ++term) {
+            const i32x4 dw = uniform_load4(d + 4 * term);
+            const int ridx = dw.x;
+            if (ridx < 0) continue;
+            const int L = uniform_load(p.rir_len + ridx);
+            const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
+            const int nbh = min(p.h_blocks, (L + kB - 1) / kB);
+            for (int i = 0; i < nbh; ++i) {
+                const int m = j - i;
+                if (m < m_min || m >= m_min + m_cnt) continue;
+                int tl = t;
+                SSK_OPAQUE1(tl);
+                const f32x4* hp = p.hspec + ((size_t)ridx * 2 + ch) * row_f4 + (size_t)i * (kSpecComplex / 2) + tl;
+                spec_block_product(p, tl, hp, spec0 + (m - m_min), any, acc);
+                any = true;
+            }
+        }
+    }
+    const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    if (FUSE) {
+        if (t < kNfft) win_v = p.tb.win[t];
+        if (t < 256) tw512_v = p.tb.tw512[t];
+        wq = p.tb.twM[64 * (t & 15)];
+    }
+    if (p.dbg == 1) {                                   // exit after the loads + products
+        if (acc[0][0].x == 123.456f && any) p.out[0] = acc[1][7].y + tw.p1.x;
+        return;
+    }
+    if (p.dbg == 2) {                                   // exit after the item stage (Hermitian merge, radix-4, LDS store)
+        if (any) { item_store_inv(lds, tw.i0, t, acc[0]); item_store_inv(lds, tw.i1, t + 1024, acc[1]); }
+        return;
+    }
+    if (any) {
+        items_to_time(lds, tw, t, acc, y);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+    }
+    if (p.dbg == 3) {                                   // exit before the stores / STFT
+        if (y[0].x == 123.456f) p.out[0] = y[7].y;
+        return;
+    }
+    store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    if (FUSE) {
+        if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
         fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
     }

@@ -11,7 +11,8 @@ SO_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libss_hip.so"))
 EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source_windows_f32",
            "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32", "ss_gccphat_f32",
            "ss_ctx_create", "ss_ctx_destroy", "ss_ctx_add_source", "ss_ctx_add_source_len", "ss_ctx_set_rir_bank",
-           "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats")
+           "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
+           "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32")
 
 
 class SsUnits(ctypes.Structure):
@@ -56,6 +57,10 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp]
     lib.ss_ctx_plan.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp, vp, c_int]
     lib.ss_ctx_stats.argtypes = [vp, vp]
+    lib.ss_ctx_set_rir_spectra.argtypes = [vp, vp, c_int]
+    lib.ss_rir_spectra_f32.argtypes = [vp, vp, c_int, c_ll, c_int, c_int, vp]
+    lib.ss_fftconv_binaural_spec_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_audio_obs_spec_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib

@@ -97,6 +97,17 @@ class AudioContext:
                    "ss_ctx_set_rir_bank")
         self._bank = (data, lengths)
         self.rir_cap = int(cap)
+        self._spectra = None
+
+    def set_rir_spectra(self, hspec) -> None:
+        """Spectral form of the bank set by set_rir_bank() (ops.rir_spectra / RirBank.build_spectra): steps without a
+        cross-fade then run k_conv_spec.  None switches back to the time-domain kernels."""
+        if hspec is None:
+            _lib.check(self.lib.ss_ctx_set_rir_spectra(self._h, None, 0), "ss_ctx_set_rir_spectra")
+        else:
+            _lib.check(self.lib.ss_ctx_set_rir_spectra(self._h, hspec.data_ptr(), int(hspec.shape[2])),
+                       "ss_ctx_set_rir_spectra")
+        self._spectra = hspec
 
     def set_rir_cap_for_planning(self, cap: int) -> None:
         """plan()-only use without a GPU: the bank capacity decides how many partition blocks a key needs."""

@@ -10,6 +10,8 @@ Reference call sites replaced (facebookresearch/sound-spaces):
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -166,6 +168,58 @@ def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pa
     sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
     audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved, flags)
     return ag, sg
+
+
+# ---- spectral RIR bank ------------------------------------------------------------------------------------------
+def rir_spectra_into(rir_bank: torch.Tensor, hspec: torch.Tensor, first: int = 0, count: Optional[int] = None) -> None:
+    """Block spectra of bank entries [first, first+count) of a planar bank [R,2,cap] into hspec [R,2,hb,SPEC_FLOATS]
+    (ss_rir_spectra_f32; one-off work at bank load, synchronous)."""
+    _chk(rir_bank, torch.float32, "rir_bank"); _chk(hspec, torch.float32, "hspec")
+    R, two, cap = rir_bank.shape
+    hb = ceil_div(cap, KB)
+    assert two == 2 and tuple(hspec.shape) == (R, 2, hb, SPEC_FLOATS)
+    count = R - first if count is None else count
+    assert 0 <= first and first + count <= R
+    with torch.cuda.device(rir_bank.device):
+        _lib.check(_lib.load().ss_rir_spectra_f32(rir_bank[first:].data_ptr(), hspec[first:].data_ptr(), count, 2 * cap, cap,
+                                                  cap, _stream()), "ss_rir_spectra_f32")
+
+
+def rir_spectra(rir_bank: torch.Tensor) -> torch.Tensor:
+    R, _, cap = rir_bank.shape
+    hspec = torch.empty((R, 2, ceil_div(cap, KB), SPEC_FLOATS), dtype=torch.float32, device=rir_bank.device)
+    rir_spectra_into(rir_bank, hspec)
+    return hspec
+
+
+def fftconv_binaural_spec_into(spec, hspec, rir_len, unit_desc, out, n_valid: int, flags: int = 0) -> None:
+    _chk(spec, torch.float32, "spec"); _chk(hspec, torch.float32, "hspec"); _chk(rir_len, torch.int32, "rir_len")
+    _chk(unit_desc, torch.int32, "unit_desc"); _chk(out, torch.float32, "out")
+    N, two, out_len = out.shape
+    assert two == 2 and unit_desc.shape == (N, 8) and hspec.dim() == 4
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().ss_fftconv_binaural_spec_f32(spec.data_ptr(), hspec.data_ptr(), rir_len.data_ptr(),
+                                                            unit_desc.data_ptr(), out.data_ptr(), N, hspec.shape[2],
+                                                            n_valid, out_len, flags, _stream()),
+                   "ss_fftconv_binaural_spec_f32")
+
+
+def audio_obs_spec_into(spec, hspec, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
+                        pad_mode="reflect", flags: int = 0) -> None:
+    _chk(spec, torch.float32, "spec"); _chk(hspec, torch.float32, "hspec"); _chk(rir_len, torch.int32, "rir_len")
+    _chk(unit_desc, torch.int32, "unit_desc"); _chk(spectrogram_out, torch.float32, "spectrogram_out")
+    N = unit_desc.shape[0]
+    assert tuple(spectrogram_out.shape) == (N,) + spectrogram_shape(out_len) and hspec.dim() == 4
+    ag_ptr = None
+    if audiogoal is not None:
+        _chk(audiogoal, torch.float32, "audiogoal")
+        assert tuple(audiogoal.shape) == (N, 2, out_len)
+        ag_ptr = audiogoal.data_ptr()
+    with torch.cuda.device(spec.device):
+        _lib.check(_lib.load().ss_audio_obs_spec_f32(spec.data_ptr(), hspec.data_ptr(), rir_len.data_ptr(),
+                                                     unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N,
+                                                     hspec.shape[2], n_valid, out_len, _PAD[pad_mode], flags, _stream()),
+                   "ss_audio_obs_spec_f32")
 
 
 def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:

@@ -67,6 +67,15 @@ class RirBank:
         assert lengths.dtype == torch.int32 and lengths.shape == (data.shape[0],)
         self.data, self.lengths = data, lengths
         self.cap = int(data.shape[2])
+        self.spectra: Optional[torch.Tensor] = None      # [R, 2, ceil(cap/KB), SPEC_FLOATS]: see build_spectra()
+
+    def build_spectra(self) -> torch.Tensor:
+        """Spectral form of the bank (ss_rir_spectra_f32): the forward FFT of every RIR block, done once here instead
+        of once per step and unit (the reference redoes it inside every fftconvolve call, simulator.py:630).  With it
+        the renderer runs k_conv_spec (no forward FFT; 2x the bytes per RIR).  For banks whose entries change after
+        this call, call it again (or use RirStore(spectral=True), which keeps the two forms in step)."""
+        self.spectra = ops.rir_spectra(self.data)
+        return self.spectra
 
     @staticmethod
     def from_arrays(rirs: Sequence[Optional[np.ndarray]], device, cap: Optional[int] = None) -> "RirBank":
@@ -272,16 +281,24 @@ class BatchedAudioRenderer:
         sg = spectrogram_out
         if sg is None:
             sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
-        ops.audio_obs_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
-                           self.out_len, self.pad_mode, flags=plan.flags)
+        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+            ops.audio_obs_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
+                                    self.out_len, self.pad_mode, flags=plan.flags)
+        else:
+            ops.audio_obs_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
+                               self.out_len, self.pad_mode, flags=plan.flags)
         return (ag if (want_audiogoal or audiogoal_out is not None) else None), sg
 
     def render_audiogoal(self, plan: Plan, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """AudioGoalSensor-only configurations (soundspaces/tasks/nav.py:37-60)."""
         if out is None:
             out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
-        ops.fftconv_binaural_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, out, self.n_valid,
-                                  flags=plan.flags)
+        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+            ops.fftconv_binaural_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, out, self.n_valid,
+                                           flags=plan.flags)
+        else:
+            ops.fftconv_binaural_into(self._spec, self.rirs.data, self.rirs.lengths, plan.desc, out, self.n_valid,
+                                      flags=plan.flags)
         return out
 
     def render_crossfaded(self, units: Sequence[UnitRequest], want_audiogoal: bool = True):

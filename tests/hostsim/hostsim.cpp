@@ -131,6 +131,7 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.n_frames = 1 + out_len / ssk::kHop;
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
+    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.dbg = 0;
     p.fade_len = static_cast<int>(0.05 * out_len);
     const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
     if (xfade) simple = 0;
@@ -156,6 +157,61 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
                 if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
                 else if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
                 else { if (simple) ssk::k_conv<false, true>(p); else ssk::k_conv<false, false>(p); }
+            });
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+// spectral RIR bank: block spectra of every (entry, ear), like ss_rir_spectra_f32 (k_source_windows with scale 1)
+int hs_rir_spectra(const float* rir, float* hspec, int n_entries, long long us, int cs, int cap) {
+    const int hb = (cap + ssk::kB - 1) / ssk::kB;
+    std::vector<int> desc;
+    for (int r = 0; r < n_entries; ++r)
+        for (int c = 0; c < 2; ++c)
+            for (int i = 0; i < hb; ++i) {
+                const int left = cap - i * ssk::kB;
+                desc.push_back(static_cast<int>(r * us + (long long)c * cs + (long long)i * ssk::kB));
+                desc.push_back(left < ssk::kB ? left : ssk::kB);
+                desc.push_back(0);
+                desc.push_back(0);
+            }
+    ssk::SrcParams p;
+    p.src = rir; p.desc = desc.data(); p.spec = reinterpret_cast<ssk::f32x4*>(hspec); p.tb = host_tables();
+    p.desc_stride = 4; p.scale = 1.0f;
+    const int n_windows = static_cast<int>(desc.size() / 4);
+    gridDim = dim3{(unsigned)n_windows, 1, 1};
+    for (int w = 0; w < n_windows; ++w) {
+        blockIdx = dim3{(unsigned)w, 0, 0};
+        int rc = run_block(ssk::kT, [&] { ssk::k_source_windows(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, const int* rir_len, const int* desc,
+                 float* out, float* sgram, int n_units, int h_blocks, int n_valid, int out_len, int pad_mode) {
+    ssk::ConvParams p;
+    p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = nullptr; p.rir_len = rir_len; p.desc = desc;
+    p.out = out; p.sgram = sgram; p.tb = host_tables();
+    p.rir_unit_stride = 0; p.rir_chan_stride = 0; p.rir_elem_stride = 1; p.rir_cap = 0;
+    p.n_valid = n_valid; p.out_len = out_len;
+    p.n_frames = 1 + out_len / ssk::kHop;
+    p.t4 = (p.n_frames + 3) / 4;
+    p.pad_mode = pad_mode;
+    p.fade_len = 0;
+    p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
+    p.h_blocks = h_blocks; p.xcd_map = 0; p.dbg = 0;
+    const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
+    if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
+    if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
+    gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
+    for (int j = 0; j < nb_y; ++j)
+        for (int b = 0; b < 2 * n_units; ++b) {
+            blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
+            int rc = run_block(ssk::kT, [&] {
+                if (fuse) { if (simple) ssk::k_conv_spec<true, true>(p); else ssk::k_conv_spec<true, false>(p); }
+                else { if (simple) ssk::k_conv_spec<false, true>(p); else ssk::k_conv_spec<false, false>(p); }
             });
             if (rc) return rc;
         }

@@ -33,7 +33,7 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True, persist=0, crossfade=False):
+        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -87,6 +87,20 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     simple = int(simple and not any(u.get("dis_rir", -1) >= 0 for u in units) and cap <= P.KB and nby == 1)
     if crossfade:
         simple = 2
+    if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)
+        assert not crossfade and not interleaved
+        hb = P.ceil_div(cap, P.KB)
+        hspec = np.zeros((R, 2, hb, P.SPEC_FLOATS), np.float32)
+        rc = L.hs_rir_spectra(_p(rir_bank, ctypes.c_float), _p(hspec, ctypes.c_float), R, ctypes.c_longlong(2 * cap), cap, cap)
+        assert rc == 0, rc
+        rc = L.hs_conv_spec(int(fuse), simple, _p(spec, ctypes.c_float), _p(hspec, ctypes.c_float), _p(rl, ctypes.c_int),
+                            _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
+                            N, hb, n_valid, out_len, pad_mode)
+        assert rc == 0, rc
+        if want_spectrogram and not fuse:
+            rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
+            assert rc == 0, rc
+        return out, (sg if (fuse or want_spectrogram) else None)
     rc = L.hs_conv(int(fuse), simple, _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
                    _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
                    N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode, persist)

@@ -380,6 +380,73 @@ def test_baseline_config4_256_envs_distractor_multisecond_all_outputs():
             assert np.abs(gp[n] - ref_gp).max() <= 2e-3
 
 
+@pytest.mark.parametrize("sr,n_units,ragged", [(16000, 128, True), (44100, 24, False)])
+def test_spectral_rir_bank_vs_oracle_and_time_domain_bank(sr, n_units, ragged):
+    """RirBank.build_spectra() + k_conv_spec (no forward FFT per step): headline shape with ragged RIRs and the
+    44.1 kHz shape (3 x 3 partition blocks), every unit against the oracle and against the time-domain kernels."""
+    from ss_amd.renderer import UnitRequest
+    src, rirs, sel_s, sel_r = _random_batch(sr, n_units, 5, 16, seed=2, ragged=ragged)
+    r = make_renderer(sr, list(src), rirs)
+    units = [UnitRequest(int(s), 0, int(h), silent=(n % 29 == 3)) for n, (s, h) in enumerate(zip(sel_s, sel_r))]
+    plan = r.plan(units)
+    ag_t, sg_t = r.render(plan, want_audiogoal=True)
+    r.rirs.build_spectra()
+    assert tuple(r.rirs.spectra.shape) == (16, 2, P.ceil_div(r.rirs.cap, P.KB), P.SPEC_FLOATS)
+    ag, sg = r.render(plan, want_audiogoal=True)
+    ag_u = r.render_audiogoal(plan)
+    assert float((ag - ag_t).abs().max()) <= 2e-6 * float(ag_t.abs().max())
+    assert float((ag_u - ag_t).abs().max()) <= 2e-6 * float(ag_t.abs().max())
+    assert float((sg - sg_t).abs().max()) <= 1e-5 * float(sg_t.abs().max())
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    cache = {}
+    for n, u in enumerate(units):
+        if u.silent:
+            assert not ag[n].any() and not sg[n].any()
+            continue
+        key = (u.sound, u.rir)
+        if key not in cache:
+            a = O.compute_audiogoal(src[key[0]], rirs[key[1]], sr)
+            cache[key] = (a, O.compute_spectrogram(a))
+        check(ag[n], cache[key][0])
+        check(sg[n], cache[key][1])
+
+
+def test_spectral_rir_bank_distractor_multisecond_long_rir_and_context():
+    """Spectral bank through the loop kernel: distractor terms, multi-second windows, a 1.5-s RIR (2 blocks per entry),
+    via the renderer and via the context API (ss_ctx_set_rir_spectra)."""
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import UnitRequest
+    sr = 16000
+    rng = np.random.default_rng(77)
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in (1, 1, 4)]
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T) for L in (16000, 24000, 9000, 20000)]
+    r = make_renderer(sr, src, rirs)
+    r.rirs.build_spectra()
+    units, refs = [], []
+    for n in range(24):
+        s_, h_, d_, hd = n % 3, n % 4, (n + 1) % 2, (n + 2) % 4
+        idx = n % 4 if s_ == 2 else 0
+        dis = n % 5 != 0
+        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_, dis_sound=d_ if dis else -1,
+                                 dis_rir=hd if dis else -1))
+        refs.append(O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx, distractor=src[d_] if dis else None,
+                                        distractor_rir=rirs[hd] if dis else None))
+    ag, sg = r.render(r.plan(units), want_audiogoal=True)
+    ctx = AudioContext(sr)
+    for i, s_ in enumerate(src):
+        ctx.add_source(f"s{i}", s_)
+    ctx.set_rir_bank(r.rirs.data, r.rirs.lengths)
+    ctx.set_rir_spectra(r.rirs.spectra)
+    ag2, sg2 = torch.empty_like(ag), torch.empty_like(sg)
+    ctx.observe([u.sound for u in units], [u.t0 for u in units], [u.rir for u in units], spectrogram_out=sg2,
+                audiogoal_out=ag2, dis_sound=[u.dis_sound for u in units], dis_rir=[u.dis_rir for u in units])
+    assert torch.equal(ag, ag2) and torch.equal(sg, sg2)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    for n in range(24):
+        check(ag[n], refs[n])
+        check(sg[n], O.compute_spectrogram(refs[n].astype(np.float32)))
+
+
 def test_persistent_row_kernel_large_batches():
     """More (unit, ear) rows than CUs: the AudioGoal-only path switches to the persistent k_conv_rows (next row's RIR
     prefetched under the inverse passes).  300 units with ragged RIRs, silent units and an empty RIR in the walk;

@@ -178,6 +178,34 @@ def test_continuous_crossfade_branches_differ_between_the_two_rirs():
     check(sg[0], ref_s)
 
 
+@pytest.mark.parametrize("name", ["clip1s", "clip1s_ragged", "multi_L1.0_i2", "multi_L1.5_i2", "distractor", "clip1s_44k"])
+def test_spectral_rir_bank_equals_time_domain_bank(name):
+    """k_conv_spec (RIR block spectra precomputed by the bank builder, no forward FFT per step) against the
+    reference-run vectors and against k_conv on the same inputs: loop-free and loop kernel, fused and unfused,
+    a 1.5-s RIR (2 blocks), a distractor term, 44.1 kHz (3 x 3 blocks)."""
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
+    srcs, banks, lens = [d["source"]], [d["rir"]], [d["rir"].shape[0]]
+    u = dict(sound=0, t0=t0, rir=0)
+    if "distractor" in d:
+        srcs.append(d["distractor"]); banks.append(d["distractor_rir"]); lens.append(d["distractor_rir"].shape[0])
+        u.update(dis_sound=1, dis_t0=0, dis_rir=1)
+    cap = max(lens) + (max(lens) & 1)
+    bank = np.concatenate([planar(b, cap) for b in banks])
+    fuse = sr <= P.KB
+    a_s, s_s = hs.run(srcs, bank, lens, [u, dict(rir=-1)], sr, sr, fuse=fuse, want_spectrogram=True, spectral=True)
+    a_t, s_t = hs.run(srcs, bank, lens, [u, dict(rir=-1)], sr, sr, fuse=fuse, want_spectrogram=True)
+    check(a_s[0][:, ::stride], ref_a)
+    check(s_s[0], ref_s)
+    assert not a_s[1].any() and not s_s[1].any()                                # silent unit: exact zeros
+    assert np.abs(a_s - a_t).max() <= 2e-6 * np.abs(a_t).max()
+    if fuse:                                                                     # and the unfused spectral kernel
+        a_u, _ = hs.run(srcs, bank, lens, [u], sr, sr, fuse=False, spectral=True)
+        assert np.abs(a_u[0] - a_s[0]).max() <= 2e-6 * np.abs(a_t).max()
+
+
 def test_44k_three_output_blocks_three_rir_blocks():
     d = case_inputs("clip1s_44k")
     sr = d["sr"]
