@@ -92,3 +92,80 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                            str(src), "-o", str(exe), "-L", so_dir, "-lss_hip", "-Wl,-rpath," + so_dir])
     assert subprocess.run([str(exe)]).returncode == 0
+
+
+def _build_client(tmp_path, with_hip):
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "ctx_client"
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    cmd = [gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "ctx_client.c"),
+           "-o", str(exe), "-L", so_dir, "-lss_hip", "-Wl,-rpath," + so_dir]
+    if with_hip:
+        cmd += ["-DWITH_HIP", "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
+                "-Wno-error=unused-function", "-Wno-error=unused-parameter"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_context_api_from_a_c_program_planning(tmp_path):
+    """the self-contained entry used from C.  Host half (no GPU): a C99 client creates a context,
+    registers two clips by length, plans two steps; the descriptors it prints equal the Python planner's, and the
+    second step is all cache hits."""
+    import subprocess
+    exe = _build_client(tmp_path, with_hip=False)
+    out = subprocess.run([str(exe), "plan"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "step 0 flags 0 new_windows 2"                # keys (sound 0, t0 0) [also the distractor's] and (1, 32000)
+    assert lines[4] == "step 1 flags 0 new_windows 0"
+    d = [[int(v) for v in l.replace("|", " ").split()[2:]] for l in lines[1:4]]
+    ws0 = planning.plan_window_set(16000, 0, 1, 1)
+    ws1 = planning.plan_window_set(80000, 32000, 1, 1)
+    assert d[0][0] == 5 and d[0][2:4] == [ws0.m_min, ws0.count] and d[0][4] == -1
+    assert d[1][0] == 6 and d[1][2:4] == [ws1.m_min, ws1.count] and d[1][4] == 9 and d[1][5] == d[0][1]   # distractor = key of unit 0
+    assert d[2][0] == -1 and d[2][4] == -1
+    assert lines[-1] == "hits 2 misses 2 resident 2"
+
+
+@pytest.mark.gpu
+def test_context_api_from_a_c_program_on_gpu(tmp_path):
+    """GPU half: the same C client uploads a bank with the HIP C API, calls ss_ctx_observe once and its outputs match the
+    reference-run vectors / the oracle."""
+    import subprocess
+    import numpy as np
+    from golden_util import case_inputs, case_outputs
+    from oracle import ss_oracle as O
+    exe = _build_client(tmp_path, with_hip=True)
+    d = case_inputs("clip1s")
+    m = case_inputs("multi_L1.0_i2")
+    sr = d["sr"]
+    srcs = [d["source"], m["source"]]
+    rirs = [d["rir"], m["rir"]]
+    cap = sr
+    bank = np.zeros((2, 2, cap), np.float32)
+    for i, r in enumerate(rirs):
+        bank[i, :, :r.shape[0]] = r.T
+    sound, t0, ridx = np.array([0, 1, 0], np.int32), np.array([0, 2 * sr, 0], np.int32), np.array([0, 1, -1], np.int32)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([sr, 2], np.int32).tobytes())
+        f.write(np.array([len(s) for s in srcs], np.int32).tobytes())
+        for s in srcs:
+            f.write(np.ascontiguousarray(s, np.float32).tobytes())
+        f.write(np.array([2, cap], np.int32).tobytes())
+        f.write(np.array([r.shape[0] for r in rirs], np.int32).tobytes())
+        f.write(bank.tobytes())
+        f.write(np.array([3], np.int32).tobytes())
+        f.write(sound.tobytes()); f.write(t0.tobytes()); f.write(ridx.tobytes())
+    out = subprocess.run([str(exe), "observe", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    raw = np.fromfile(tmp_path / "out.bin", np.float32)
+    ag = raw[:3 * 2 * sr].reshape(3, 2, sr)
+    sg = raw[3 * 2 * sr:].reshape(3, 65, 26, 2)
+    for n, name in enumerate(("clip1s", "multi_L1.0_i2")):
+        ref_a, ref_s, stride = case_outputs(name)
+        assert O.relerr(ag[n][:, ::stride], ref_a) <= 1e-4 and O.relerr(sg[n], ref_s) <= 1e-4
+    assert not ag[2].any() and not sg[2].any()

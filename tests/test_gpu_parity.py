@@ -587,6 +587,58 @@ def test_audiogoal_batcher_savi_semantics():
     assert idx.min() >= 0 and idx.max() <= len(d0["source"]) // sr - 2          # random.randint(0, n - 2), inclusive
 
 
+def test_fast_vector_observer_on_gpu():
+    """Column-based observer (ss_amd/vector.py) on the real context + store: bound stand-in simulators, RIR groups of 4
+    azimuths in adjacent bank rows, spectral bank on and off; against the per-env oracle."""
+    from fakes import FakeSim
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import RirStore
+    from ss_amd.vector import FastVectorAudioObserver, RirIndex, VectorSimState
+    from ss_amd import ops
+    sr, n = 16000, 6
+    rng = np.random.default_rng(12)
+    sounds = {f"snd{k}": O.synth_sources(rng, sr, k=1, seconds=s_)[0] for k, s_ in enumerate((1, 3))}
+    store = RirStore(slots=4 * 16, cap=sr, device=DEV, group=4)
+    index = RirIndex(4)
+    sid = index.add_scene("apartment_0", 4)
+    groups = {}
+    for r in range(4):
+        for s_ in range(4):
+            groups[(r, s_)] = [np.ascontiguousarray(O.synth_rir(rng, sr, length=int(rng.integers(2000, 9000)), n=1)[0].T)
+                               for _ in range(4)]
+    bases = store.slot_many(list(groups), [(lambda g=g: g) for g in groups.values()])
+    for (r, s_), b in zip(groups, bases):
+        index.set(sid, r, s_, b)
+    ctx = AudioContext(sr)
+    ctx.set_rir_bank(store.bank.data, store.bank.lengths)
+    sims = [FakeSim(sr, sounds, {}) for _ in range(n)]
+    state = VectorSimState(n)
+    for i, sim in enumerate(sims):
+        state.bind(sim, i)
+    obs = FastVectorAudioObserver(ctx, state, index, sr)
+    sg = torch.empty((n, 65, 26, 2), device=DEV)
+    ag = torch.empty((n, 2, sr), device=DEV)
+    for step in range(4):
+        if step == 2:
+            ctx.set_rir_spectra(ops.rir_spectra(store.bank.data))
+        for i, sim in enumerate(sims):
+            sim._receiver_position_index, sim._source_position_index = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            sim._rotation_angle = int(rng.integers(0, 4)) * 90
+            sim._current_sound = f"snd{(i + step) % 2}"
+            sim._episode_step_count = 600 if (i == 1 and step == 3) else step
+        idx_before = [s_._audio_index for s_ in sims]
+        obs.observe(spectrogram_out=sg, audiogoal_out=ag)
+        a, s_out = ag.cpu().numpy(), sg.cpu().numpy()
+        for i, sim in enumerate(sims):
+            if sim._episode_step_count > sim._duration:
+                assert not a[i].any()
+                continue
+            rir = groups[(sim._receiver_position_index, sim._source_position_index)][sim.azimuth_angle // 90]
+            ref = O.compute_audiogoal(sim.current_source_sound, rir, sr, audio_index=idx_before[i])
+            check(a[i], ref)
+            check(s_out[i], O.compute_spectrogram(ref.astype(np.float32)))
+
+
 def test_plugin_boundary_end_to_end_on_gpu():
     """The reference-shaped call chain sensor -> sim.get_current_spectrogram_observation -> HIP engine, with the real
     AudioEngine (RIR store + renderer) behind a stand-in simulator object."""
@@ -613,6 +665,59 @@ def test_plugin_boundary_end_to_end_on_gpu():
     assert not sg_sensor.get_observation(observations=None, episode=None).any()
     obs = sim_audio.VectorAudioObserver(eng, [sim._ss_hip_audio] * 3, want_audiogoal=True).observe()
     assert tuple(obs["spectrogram"].shape) == (3, 65, 26, 2) and obs["spectrogram"].is_cuda
+
+
+def test_deferred_requests_resolved_on_gpu():
+    """Deferred mode (multi-process vector envs): AudioRequests produced by worker-side adapters (pickled, as through
+    habitat.VectorEnv's pipe) resolved by the trainer-side DeferredResolver on the real engine, straight into rollout
+    rows; SS1.0 with a distractor and SS2.0 with cross-fade."""
+    import pickle
+    import types
+    from fakes import FakeContinuousSim, FakeSim, NS
+    from ss_amd import sensors
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.renderer import AudioEngine
+    from ss_amd.rollout import RolloutStorage
+    d = case_inputs("distractor")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("distractor")
+    files = {"rirs/replica/apartment_0/90/3_7.wav": d["rir"], "rirs/replica/apartment_0/90/3_11.wav": d["distractor_rir"]}
+    sims = [FakeSim(sr, {"telephone.wav": d["source"], "d.wav": d["distractor"]}, files, has_distractor=True) for _ in range(3)]
+    for i, sim in enumerate(sims):
+        sim._current_distractor_sound = "d.wav"
+        attach_deferred(sim, env_rank=i)
+    sims[2]._episode_step_count = 999
+    sg_sensors = [sensors.SpectrogramSensor(sim=s_, config=NS()) for s_ in sims]
+    observations = [pickle.loads(pickle.dumps({"spectrogram": g.get_observation(observations=None, episode=None)}))
+                    for g in sg_sensors]
+    eng = AudioEngine(sr, device=DEV, rir_slots=16)
+    space = types.SimpleNamespace(spaces={"spectrogram": types.SimpleNamespace(shape=(65, 26, 2))})
+
+    class ActionSpace:
+        pass
+    rollouts = RolloutStorage(4, 3, space, ActionSpace(), 8, device=DEV)
+    batch = DeferredResolver(eng, rir_reader=files.get).resolve_observations(observations, rollouts)
+    assert batch["spectrogram"].data_ptr() == rollouts.observations["spectrogram"][1].data_ptr()
+    sg = batch["spectrogram"].cpu().numpy()
+    check(sg[0], ref_s)
+    check(sg[1], ref_s)
+    assert not sg[2].any()
+    # SS2.0: live RIRs + cross-fade through the same resolver
+    rng = np.random.default_rng(6)
+    bank = O.synth_rir(rng, sr, length=9000, n=6)
+    csims = [FakeContinuousSim(sr, {"telephone": d["source"]}, lambda k, o=o: bank[(k + o) % 6].astype(np.float64).tolist(),
+                               start_index=700 * o) for o in range(2)]
+    for i, c in enumerate(csims):
+        attach_deferred(c, env_rank=i, continuous=True)
+    ceng = AudioEngine(sr, device=DEV, rir_slots=8, step_time=0.25, wrap=True)
+    res = DeferredResolver(ceng)
+    for step in range(4):
+        reqs = [pickle.loads(pickle.dumps(c.get_current_audiogoal_observation())) for c in csims]
+        out = res.resolve(reqs, want_audiogoal=True)
+        for i, c in enumerate(csims):
+            check(out["audiogoal"][i].cpu().numpy(), c.reference_audiogoal())
+        for c in csims:
+            c.step()
 
 
 def test_vectorised_planner_equals_per_unit_planner():
