@@ -9,9 +9,15 @@ Workload = BASELINE.json's metric shape: 128 envs, 16 kHz, 1-s clips, 2-channel 
 
   python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-N>1: every rank renders its own 128 envs (weak scaling, units are independent) and the per-rank spectrogram slabs
-are all-gathered over RCCL on a side stream (the exchange step BASELINE.json names); --exchange none times the
-collective-free DD-PPO arrangement instead.  Rank 0 prints ONE JSON line.
+N>1: every rank renders its own 128 envs (weak scaling, units are independent; --scaling strong splits 128 envs over the
+ranks, BASELINE configs[3]) and the per-rank spectrogram slabs are all-gathered over RCCL on a side stream (the exchange
+step BASELINE.json names) in chunks of --gather-every steps; the same run also times the per-step gather and the
+collective-free DD-PPO arrangement and reports them beside the headline.  Rank 0 prints ONE JSON line.
+
+The line also carries, measured in the same run: per-step GPU time distribution (HIP events per step), the convolution
+kernel alone (`roofline_conv_only`, the figure BASELINE's >= 40 % target is defined on), the spectral-RIR-bank variant,
+two-stream launch, the PLUGIN PATH (simulator state -> planning -> descriptor upload -> launch -> rollout rows, all
+inside the timed region) and the CPU oracle on the host cores this process may use.
 """
 import argparse
 import json
@@ -46,24 +52,57 @@ def _cpu_worker(args):
     rng = np.random.default_rng(seed)
     src = O.synth_sources(rng, sr, k=4)
     rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=8)]
-    n, t_end = 0, time.perf_counter() + seconds
+    n, t_conv, t_spec = 0, 0.0, 0.0
     t0 = time.perf_counter()
+    t_end = t0 + seconds
     while time.perf_counter() < t_end:
+        ta = time.perf_counter()
         a = O.compute_audiogoal(src[n % 4], rirs[n % 8], sr)
+        tb = time.perf_counter()
         O.compute_spectrogram(a)
+        tc = time.perf_counter()
+        t_conv += tb - ta
+        t_spec += tc - tb
         n += 1
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, t_conv, t_spec
+
+
+def usable_cores():
+    """Cores this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU quota
+    (os.cpu_count() reports the machine, not the container: r1's '256 cores' scaled only 20x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(sr, seconds):
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     one = _cpu_worker((0, sr, min(4.0, seconds)))
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, [(100 + i, sr, seconds) for i in range(cores)])
-    total = sum(n / dt for n, dt in res)
+    total = sum(r[0] / r[1] for r in res)
+    one_rate = one[0] / one[1]
+    n_all = sum(r[0] for r in res)
     return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (scipy fftconvolve x2 + numpy STFT/pool/log1p), {cores} processes x {seconds:.0f} s, "
-                      f"sr={sr}, 1-s clip, 1-s RIR, caches off; 1 core: {one[0] / one[1]:.1f} env-steps/s"}
+            "one_core": round(one_rate, 1), "scaling_efficiency": round(total / (one_rate * cores), 3),
+            "stage_ms_one_core": {"fftconvolve_x2": round(1e3 * one[2] / one[0], 3),
+                                  "spectrogram": round(1e3 * one[3] / one[0], 3)},
+            "stage_ms_all_cores": {"fftconvolve_x2": round(1e3 * sum(r[2] for r in res) / n_all, 3),
+                                   "spectrogram": round(1e3 * sum(r[3] for r in res) / n_all, 3)},
+            "sample": f"oracle (scipy fftconvolve x2 + numpy STFT/pool/log1p), {cores} processes (sched affinity / cgroup "
+                      f"quota; os.cpu_count() = {os.cpu_count()}) x {seconds:.0f} s, sr={sr}, 1-s clip, 1-s RIR, caches "
+                      f"off; 1 core alone: {one_rate:.1f} env-steps/s"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -193,37 +232,72 @@ def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, ste
     return out
 
 
+def dist_of(ms):
+    """median / p10 / p90 of per-step durations (ms)."""
+    import numpy as np
+    v = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"median": round(float(np.median(v)), 5), "p10": round(float(v[len(v) // 10]), 5),
+            "p90": round(float(v[(9 * len(v)) // 10]), 5)}
+
+
+def measured_traffic(units, sr, kernel):
+    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r2/traffic.json written by
+    scripts/gpu_profile_r2.sh with the hash of the kernel sources): null when the sources have changed since."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
+        have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.srchash")).read().strip()
+        e = tj["kernels"][kernel]
+        if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
+            return {"bytes": int(e["fetch_bytes"] + e["write_bytes"]), "fetch_bytes": int(e["fetch_bytes"]),
+                    "write_bytes": int(e["write_bytes"]), "note": e.get("note", "")}
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=128, help="envs (units) per GPU per step")
+    ap.add_argument("--envs", type=int, default=128, help="envs per GPU per step (weak scaling) / in total (--scaling strong)")
+    ap.add_argument("--rotations", type=int, default=1, help="agent rotations rendered per env and step (BASELINE configs[2]: "
+                                                             "4; the azimuths of a pair sit in adjacent bank rows)")
     ap.add_argument("--sr", type=int, default=16000)
     ap.add_argument("--bank-mib", type=int, default=512, help="RIR bank size per GPU (> 256 MiB Infinity Cache)")
     ap.add_argument("--sounds", type=int, default=102)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --envs per GPU (default); strong: --envs in total, split over the ranks (BASELINE configs[3]: "
+                         "128 envs = 16 per GPU on 8 GPUs)")
     ap.add_argument("--exchange", choices=["allgather", "none"], default="allgather")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="steps per all-gather: the learner consumes rollouts, so per-rank slabs are exchanged in chunks of "
-                         "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); 1 = every step")
+                         "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); the per-step "
+                         "gather (1) is timed as well and reported beside it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank flow on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams that consecutive steps alternate between; 0 = auto: 1 on one GPU (per-launch durations "
-                         "stay comparable with the rocprofv3 kernel trace), 2 when the all-gather overlaps the kernels "
-                         "(RCCL's workgroups cannot share a CU with the 148 KB / 512-VGPR workgroups of k_conv, so a "
-                         "256-row launch on fewer than 256 free CUs needs a second wave of rows unless the next step's "
-                         "rows may already start)")
+                         "stay comparable with the rocprofv3 kernel trace), 2 when the all-gather overlaps the kernels")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the conv-only / spectral-bank / 2-stream side measurements")
+    ap.add_argument("--spectral", action="store_true", help="headline loop on the spectral RIR bank (k_conv_spec) instead of "
+                                                           "the time-domain bank")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    sr, N = args.sr, args.envs
+    sr = args.sr
+    if args.scaling == "strong":
+        assert args.envs % world == 0, "--scaling strong: --envs must divide by the number of ranks"
+        n_env = args.envs // world
+    else:
+        n_env = args.envs
+    N = n_env * args.rotations                               # units per GPU per step
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -234,7 +308,7 @@ def main():
     import torch.distributed as dist
     from oracle import ss_oracle as O
     from ss_amd import planning as P
-    from ss_amd.dist import SlabExchange
+    from ss_amd.dist import ChunkedSlabExchange
     from ss_amd.renderer import BatchedAudioRenderer, RirBank
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
@@ -252,138 +326,173 @@ def main():
     rng = np.random.default_rng(1000 + rank)
     L = sr                                                   # RIR length = fallback shape (simulator.py:621)
     R = max(64, (args.bank_mib << 20) // (2 * L * 4))
+    R -= R % 4                                               # whole azimuth groups
     r = BatchedAudioRenderer(sr, device=dev)
     for i, clip in enumerate(O.synth_sources(rng, sr, k=args.sounds)):
         r.add_source(f"sound{i}", clip)
     bank = synth_rir_bank_device(torch, R, sr, L, dev, seed=7 + rank)
     r.set_rir_bank(RirBank(bank, torch.full((R,), L, dtype=torch.int32, device=dev)))
     total = args.warmup + args.steps
-    descs = [r.plan_arrays(rng.integers(0, args.sounds, N), np.zeros(N, np.int64), rng.integers(0, R, N))
+    rot = args.rotations
+
+    def draw_rir():                                          # rotations > 1: first row of an azimuth group of `rot` rows
+        return rng.integers(0, R // rot, n_env) * rot if rot > 1 else rng.integers(0, R, n_env)
+    descs = [r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
              for _ in range(total)]
     t4 = r.spectrogram_shape[1]
-    G = max(1, args.gather_every)
-    ex = SlabExchange((G * N,) + r.spectrogram_shape, device=dev) if (world > 1 and args.exchange == "allgather") else None
-    chunk = {"buf": None, "n": 0}
-    sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(2)]
-    ag_buf = torch.empty((N, 2, sr), dtype=torch.float32, device=dev) if (args.with_audiogoal or sr > P.KB) else None
+    fused = sr <= P.KB
+    want_ag = args.with_audiogoal or not fused
 
-    S = args.streams if args.streams > 0 else (2 if ex is not None else 1)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
-    sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
-    ag_bufs = [ag_buf] + [torch.empty_like(ag_buf) for _ in range(S - 1)] if ag_buf is not None else [None] * S
+    def run_loop(S, gather_every, spectral, per_step_events=False):
+        """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms: average over
+        the region from two HIP events on the launch stream, or the per-step list with per_step_events, note).
+        Per-step event records put a marker packet between consecutive launches (measured: +2-3 us per step), so the
+        headline loop records only the two ends and the distribution comes from a separate pass."""
+        r.rirs.spectra = spectra if spectral else None
+        cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev) if (world > 1 and gather_every > 0) else None
+        ex = cx.exchange if cx is not None else None
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
+        sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
+        ag_bufs = [torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(S)] if want_ag else [None] * S
 
-    def step(k):
-        st = streams[k % S]
-        with torch.cuda.stream(st):
-            if ex is not None:
-                if chunk["n"] == 0:
-                    chunk["buf"] = ex.next_local(streams)      # [G*N, 65, T4, 2]: G consecutive steps of this rank
-                i = chunk["n"]
-                r.render(descs[k], spectrogram_out=chunk["buf"][i * N:(i + 1) * N], audiogoal_out=ag_bufs[k % S])
-                chunk["n"] += 1
-                if chunk["n"] == G:
-                    ex.gather(streams)
-                    chunk["n"] = 0
-            else:
-                r.render(descs[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
+        def step(k):
+            st = streams[k % S]
+            with torch.cuda.stream(st):
+                if cx is not None and not state["no_exchange"]:
+                    r.render(descs[k], spectrogram_out=cx.step_rows(streams), audiogoal_out=ag_bufs[k % S])
+                    cx.step_done(streams)                          # all-gather of the chunk once it is full
+                else:
+                    r.render(descs[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def flush():
-        if ex is not None:
-            if chunk["n"]:                                     # partial last chunk
-                ex.gather(streams)
-                chunk["n"] = 0
-            ex.wait(streams)
-
-    exchange_note = None
-    if ex is not None:                                         # RCCL communicator / channel set-up (seconds, lazy on
-        try:                                                   # the first collective) must not land in the timed region
-            for _ in range(2):                                 # whatever --warmup is; both buffers, full-size gathers
-                ex.next_local(streams)
-                ex.gather(streams)
-            ex.wait(streams)
+        def fence():
+            if world > 1:
+                dist.barrier()
             torch.cuda.synchronize()
-        except Exception as e:                                 # keep the run alive: the shards do not depend on the
-            exchange_note = f"all-gather unavailable ({type(e).__name__}: {e}); ran without exchange"   # collective
-            print("[bench] " + exchange_note, file=sys.stderr, flush=True)
-            ex = None
-    torch.cuda.synchronize()                                   # banks / spectra were built on the default stream
-    for k in range(args.warmup):
-        step(k)
-    flush()
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_start = time.perf_counter()
-    ev0.record(streams[0])
-    for k in range(args.warmup, total):
-        step(k)
-    if S > 1:
-        for st in streams[1:]:
-            streams[0].wait_stream(st)
-    ev1.record(streams[0])
-    flush()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    # avg launch duration on the launch stream (S > 1: launches overlap, this is the issue-to-issue average)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+
+        def flush():
+            if cx is not None and not state["no_exchange"]:
+                cx.flush(streams)                                  # partial last chunk + wait
+
+        note = None
+        state = {"no_exchange": False}
+        if ex is not None:                                         # RCCL communicator / channel set-up (seconds, lazy on
+            try:                                                   # the first collective) must not land in the timed region
+                for _ in range(2):
+                    ex.next_local(streams)
+                    ex.gather(streams)
+                ex.wait(streams)
+                torch.cuda.synchronize()
+            except Exception as e:                                 # keep the run alive: the shards do not depend on it
+                note = f"all-gather unavailable ({type(e).__name__}: {e}); ran without exchange"
+                print("[bench] " + note, file=sys.stderr, flush=True)
+                state["no_exchange"] = True
+        torch.cuda.synchronize()
+        for k in range(args.warmup):
+            step(k)
+        flush()
+        fence()
+        n_ev = args.steps + 1 if per_step_events else 2
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] if S == 1 else None
+        t_start = time.perf_counter()
+        if evs:
+            evs[0].record(streams[0])
+        for k in range(args.warmup, total):
+            step(k)
+            if evs and per_step_events:
+                evs[k - args.warmup + 1].record(streams[0])
+        if evs and not per_step_events:
+            evs[1].record(streams[0])
+        flush()
+        fence()
+        elapsed = time.perf_counter() - t_start
+        per_step = None
+        if evs:
+            per_step = ([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if per_step_events
+                        else [evs[0].elapsed_time(evs[1]) / args.steps])
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, per_step, note
+
+    spectra = None
+    if (args.spectral or not args.no_secondary) and fused:
+        r.rirs.build_spectra()
+        spectra = r.rirs.spectra
+    S_auto = args.streams if args.streams > 0 else (2 if (world > 1 and args.exchange == "allgather") else 1)
+    G_head = args.gather_every if (world > 1 and args.exchange == "allgather") else 0
+    elapsed, per_step, exchange_note = run_loop(S_auto, G_head, args.spectral)
+    side = {}
+    step_dist = None
+    if world == 1 and S_auto == 1 and not args.no_secondary:
+        _, ps, _ = run_loop(1, 0, args.spectral, per_step_events=True)
+        step_dist = dist_of(ps)
+        step_dist["note"] = "separate pass with one HIP event record per step (the records themselves add 2-3 us per step)"
+    if world > 1 and args.exchange == "allgather" and not args.no_secondary:
+        e1, _, _ = run_loop(S_auto, 1, args.spectral)             # per-step gather, same run
+        side["exchange_per_step_gather"] = {"value": round(world * N * args.steps / e1, 1), "ms_per_step": round(1e3 * e1 / args.steps, 5)}
+        e0, _, _ = run_loop(S_auto, 0, args.spectral)             # no collective (the reference's DD-PPO arrangement)
+        side["exchange_none"] = {"value": round(world * N * args.steps / e0, 1), "ms_per_step": round(1e3 * e0 / args.steps, 5)}
+    if world == 1 and not args.no_secondary and fused:
+        e2, _, _ = run_loop(2, 0, args.spectral)                  # consecutive steps on two streams
+        side["two_streams"] = {"value": round(N * args.steps / e2, 1), "ms_per_step": round(1e3 * e2 / args.steps, 5)}
+        eo, ps_o, _ = run_loop(1, 0, not args.spectral)           # the other RIR bank format
+        side["spectral_bank" if not args.spectral else "time_domain_bank"] = {
+            "value": round(N * args.steps / eo, 1), "ms_per_step": round(1e3 * eo / args.steps, 5),
+            "avg_launch_ms": round(float(np.mean(ps_o)), 5),
+            "note": "RIR bank stored as block spectra (ss_rir_spectra_f32): no forward FFT per step, 2x the bytes per RIR "
+                    "(actual reads per unit: 2*2*L*4 + window spectrum from L2)" if not args.spectral else "time-domain bank"}
+    r.rirs.spectra = spectra if args.spectral else None
 
     # ---- secondary measurement: the convolution kernel alone (audiogoal written), same inputs -------------
     conv_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_secondary:
         ag = torch.empty((N, 2, sr), dtype=torch.float32, device=dev)
         for k in range(min(10, total)):
             r.render_audiogoal(descs[k], out=ag)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = min(100, args.steps)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for k in range(reps):
             r.render_audiogoal(descs[args.warmup + k], out=ag)
         e1.record()
         torch.cuda.synchronize()
-        conv_ms = e0.elapsed_time(e1) / reps
+        conv_ms = [e0.elapsed_time(e1) / reps]
 
     if rank == 0:
-        traffic = None                      # HBM bytes per launch from the committed PMC pass of this same command
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))["k_conv<FUSE=true>"]
-            if tj["units_per_launch"] == N and tj["sampling_rate"] == sr:
-                traffic = int((tj["fetch_kib"] + tj["write_kib"]) * 1024)
-        except Exception:
-            pass
+        kernel_ms = float(np.mean(per_step)) if per_step else 1e3 * elapsed / args.steps
         b = bytes_per_unit(sr, L, t4)
-        fused = sr <= P.KB
-        dom_bytes = (b["fused"] if fused else b["conv"]) * N
-        ach = dom_bytes / (kernel_ms * 1e-3) / 1e9
+        kname = ("k_conv_spec<FUSE=true>" if args.spectral else "k_conv<FUSE=true>") if fused else "k_conv<FUSE=false>+k_spectrogram"
+        bpu = b["fused"] if fused else b["conv"] + b["spec"]
+        ach = bpu * N / (kernel_ms * 1e-3) / 1e9
+        workload = (f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, 1-s source clips ({args.sounds} sounds), "
+                    f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident"
+                    f"{', stored as block spectra: ' + str(R * 2 * 2 * P.SPEC_FLOATS * 4 >> 20) + ' MiB' if args.spectral else ''}), "
+                    "cache-miss path, spectrogram [65,%d,2] f32 out" % t4)
         out = {
             "metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
             "value": round(world * N * args.steps / elapsed, 1),
             "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{N} envs/GPU x 1 rotation, sr={sr}, 1-s source clips ({args.sounds} sounds), "
-                                   f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident), "
-                                   "cache-miss path, spectrogram [65,%d,2] f32 out" % t4,
-                       "envs_per_gpu": N, "sampling_rate": sr, "rir_len": L,
-                       "exchange": (exchange_note or ((args.exchange + f" every {G} steps") if (world > 1 and args.exchange == "allgather") else "none")),
-                       "streams": S, "kernel": "k_conv<fused>" if fused else
-                       "k_conv + k_spectrogram"},
+            "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
+                       "sampling_rate": sr, "rir_len": L, "rir_bank": "spectral" if args.spectral else "time-domain",
+                       "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps")
+                                                      if (world > 1 and args.exchange == "allgather") else "none")),
+                       "streams": S_auto, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_conv<FUSE=true>" if fused else "k_conv<FUSE=false>+k_spectrogram",
-                         "bytes_per_unit": b["fused"] if fused else b["conv"], "units_per_launch": N,
-                         "avg_launch_ms": round(kernel_ms, 5)},
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
+                         "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5)},
         }
+        tr = measured_traffic(N, sr, kname)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["bytes"]
+            out["roofline"]["traffic_detail"] = tr
+        if step_dist:
+            out["gpu_ms_per_step"] = step_dist
         if fused:
             # SURVEY 8(d): FFT convolution sits at the FP32 ridge (~20 FLOP/B), so the vector-FP32 roofline is reported
             # beside the declared HBM one.  Algorithmic FLOPs per env-step (radix-2 real-FFT count 2.5 N log2 N):
@@ -394,13 +503,16 @@ def main():
                                     "frac": round(tf / 157.3, 4), "flops_per_unit": 7.4e6,
                                     "note": "FFT butterflies are adds (no FMA pairing): the add-rate ceiling is 78.6"}
         if conv_ms is not None:
-            a2 = b["conv"] * N / (conv_ms * 1e-3) / 1e9
+            cm = float(np.mean(conv_ms))
+            a2 = b["conv"] * N / (cm * 1e-3) / 1e9
             out["roofline_conv_only"] = {"bound": "hbm", "achieved": round(a2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(a2 / HBM_PEAK_GBS, 4), "kernel": "k_conv<FUSE=false>",
-                                         "bytes_per_unit": b["conv"], "avg_launch_ms": round(conv_ms, 5)}
-        if world == 1 and not args.no_plugin_path and sr <= P.KB:
+                                         "frac": round(a2 / HBM_PEAK_GBS, 4),
+                                         "kernel": "k_conv_spec<FUSE=false>" if args.spectral else "k_conv<FUSE=false>",
+                                         "bytes_per_unit": b["conv"], "avg_launch_ms": round(cm, 5)}
+        out.update(side)
+        if world == 1 and not args.no_plugin_path and fused and rot == 1:
             srcs = [r.sources._host[i] for i in range(len(r.sources))]
-            out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, N, bank, args.sounds, srcs,
+            out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, n_env, bank, args.sounds, srcs,
                                                      min(args.steps, 400), min(args.warmup, 50))
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -90,3 +90,50 @@ class SlabExchange:
         if self._cuda and self.world > 1 and self._k > 0:
             for st in self._producers(streams):
                 st.wait_event(self.ready[(self._k - 1) % self.depth])
+
+
+class ChunkedSlabExchange:
+    """The exchange schedule of bench.py / a rollout learner: every rank renders `units` rows per step; the rows of
+    `gather_every` consecutive steps form one slab that is all-gathered at once (a learner consumes rollouts, not single
+    steps; fewer, larger collectives suit the point-to-point xGMI fabric).  gather_every = 1 is the per-step gather.
+
+        buf = cx.step_rows(streams)        # [units, ...] view the renderer writes this step's rows into
+        ... launch the kernels ...
+        cx.step_done(streams)              # issues the all-gather when the chunk is full
+        cx.flush(streams)                  # end of the run: gather a partial last chunk, wait for everything
+
+    `gathered` is called with (full slab [world * gather_every * units, ...], number of valid steps in it) on the host
+    right after a gather was ISSUED (consume it on a stream after `exchange.wait()`)."""
+
+    def __init__(self, units: int, row_shape, gather_every: int, dtype=torch.float32, device="cuda",
+                 group: Optional[dist.ProcessGroup] = None, exchange_cls=None, gathered=None):
+        self.units, self.G = int(units), max(1, int(gather_every))
+        cls = exchange_cls or SlabExchange
+        self.exchange = cls((self.G * self.units,) + tuple(row_shape), dtype=dtype, device=device, group=group)
+        self._buf = None
+        self._n = 0
+        self.gathered = gathered
+        self.gathers = 0
+
+    def step_rows(self, streams=None) -> torch.Tensor:
+        if self._n == 0:
+            self._buf = self.exchange.next_local(streams)
+        i = self._n
+        return self._buf[i * self.units:(i + 1) * self.units]
+
+    def step_done(self, streams=None) -> None:
+        self._n += 1
+        if self._n == self.G:
+            self._gather(streams)
+
+    def _gather(self, streams):
+        full = self.exchange.gather(streams)
+        self.gathers += 1
+        if self.gathered is not None:
+            self.gathered(full, self._n)
+        self._n = 0
+
+    def flush(self, streams=None) -> None:
+        if self._n:
+            self._gather(streams)
+        self.exchange.wait(streams)

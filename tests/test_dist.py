@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ss_amd.dist import SlabExchange, owner_of, shard_range
+from ss_amd.dist import ChunkedSlabExchange, SlabExchange, owner_of, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -73,3 +73,51 @@ def test_single_process_exchange_is_identity():
     s = ex.next_local()
     s.copy_(torch.randn(3, 65, 26, 2))
     assert torch.equal(ex.gather(), s)
+
+
+def _bench_flow_worker(rank, world, port, units, gather_every, steps, q):
+    """The exchange flow of bench.py (ChunkedSlabExchange): per-step rows, a gather per full chunk, a partial last chunk."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen = []
+
+        def gathered(full, n_steps):
+            seen.append((full.clone(), n_steps))
+        cx = ChunkedSlabExchange(units, (5, 3, 2), gather_every, device="cpu", gathered=gathered)
+        for k in range(steps):
+            rows = cx.step_rows()
+            assert tuple(rows.shape) == (units, 5, 3, 2)
+            rows.fill_(float(1000 * rank + k))                       # stands in for the kernels' output of step k
+            cx.step_done()
+        cx.flush()
+        ok = cx.gathers == -(-steps // gather_every) == len(seen)
+        k0 = 0
+        for full, n_steps in seen:
+            ok &= tuple(full.shape) == (world * gather_every * units, 5, 3, 2)
+            for r in range(world):
+                blk = full[r * gather_every * units:(r + 1) * gather_every * units]
+                for i in range(n_steps):                             # rows of step k0 + i of rank r
+                    ok &= bool((blk[i * units:(i + 1) * units] == 1000 * r + k0 + i).all())
+            k0 += n_steps
+        ok &= k0 == steps
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gather_every,steps", [(1, 5), (3, 7), (8, 8)])
+def test_bench_exchange_flow_two_ranks_gloo(gather_every, steps):
+    """the multi-rank flow of bench.py (per-step gather, chunked gather, partial last chunk) under
+    world_size 2 on gloo, not only in a gpurun script."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_flow_worker, args=(r, 2, port, 4, gather_every, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
