@@ -109,31 +109,6 @@ int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_
                           float* audiogoal, float* spectrogram, int n_units, int h_blocks, int n_valid, int out_len,
                           int pad_mode, int flags, void* stream);
 
-/* ---- Half-row kernels: the SoundSpaces 1.0 @16 kHz shape (the headline) with TWO workgroups resident per CU --------------
- * Scope: out_len = n_valid = 16000, planar RIR bank with rows of <= 16000 taps (rir_cap even, 8-byte aligned rows), no
- * distractor, no cross-fade.  Same results as ss_audio_obs_f32 to fp32 rounding.  The (unit, ear) row is produced by two
- * 512-thread workgroups (output samples [0, 8385) and [7615, 16000), STFT frames 0..51 and 52..100: no hand-off), each an
- * 8192-point FFT over 8000-tap RIR partitions; see csrc/ss_kernels8.hpp.
- * Source windows are 16384 samples, spectra ss_half_spec_floats() floats each (opaque order):
- *   win_desc[w] = {src_offset, src_len, start, wrap} as for ss_source_windows_f32;
- *   for out[t] = sum_k h[k] x[t0 + t - k] the window of (half j, RIR partition i) starts at
- *   start = t0 + E_j - 8000*i - 16384,  E_0 = 8385, E_1 = 16000.
- * unit_desc[n] = 8 x int32: [0] RIR bank index or -1 (silent unit -> exact zeros); [1..4] spectrum slot of the windows
- *   (j,i) = (0,0), (0,1), (1,0), (1,1), or -1 for a window that holds no sample of the clip; [5..7] 0.
- * audiogoal [n,2,16000] and spectrogram [n,65,26,2]: either may be NULL (not both). */
-int ss_half_spec_floats(void);
-int ss_source_windows8_f32(const float* src, const int* win_desc, float* spec_out, int n_windows, void* stream);
-int ss_audio_obs_half_f32(const float* spec8, const float* rir, const int* rir_len, const int* unit_desc,
-                          float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
-                          int rir_chan_stride, int rir_cap, int out_len, int pad_mode, void* stream);
-/* Spectral form of the same: ss_rir_spectra8_f32 turns a planar bank (rows <= 16000 taps) into hspec_out = n_entries * 2
- * ears * 2 partitions * ss_half_spec_floats() floats (the 8000-tap partition spectra, opaque order; synchronous, one-off);
- * ss_audio_obs_half_spec_f32 then needs no forward FFT (same descriptors / rir_len / results to fp32 rounding). */
-int ss_rir_spectra8_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride, int rir_chan_stride,
-                        int rir_cap, void* stream);
-int ss_audio_obs_half_spec_f32(const float* spec8, const float* hspec8, const int* rir_len, const int* unit_desc,
-                               float* audiogoal, float* spectrogram, int n_units, int out_len, int pad_mode, void* stream);
-
 /* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
  * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream);

@@ -17,7 +17,6 @@ ap.add_argument("--sizes", default="128,2048")
 ap.add_argument("--only", default="")
 ap.add_argument("--bank-mib", type=int, default=512)
 ap.add_argument("--spectral", action="store_true", help="spectral RIR bank (k_conv_spec) instead of the time-domain bank")
-ap.add_argument("--halfspec", action="store_true", help="half-row kernels reading the partition-spectra bank (ss_audio_obs_half_spec_f32)")
 ap.add_argument("--raw", action="store_true", help="launch through bound ctypes calls (host overhead ~3 us per launch)")
 ap.add_argument("--sort", action="store_true", help="units sorted by sound id modulo 8 (with SS_HIP_XCD_MAP=1: one group of sounds per XCD)")
 ap.add_argument("--distinct", type=int, default=8, help="pre-planned batches cycled (8 x 128 envs fit the Infinity Cache; bench.py streams)")
@@ -48,30 +47,7 @@ LIB = _lib.load()
 STREAM = torch.cuda.current_stream().cuda_stream
 
 
-HSPEC8 = None
-if a.halfspec:
-    HSPEC8 = torch.empty((R, 2, 2, 16384), dtype=torch.float32, device=dev)
-    rc = LIB.ss_rir_spectra8_f32(r.rirs.data.data_ptr(), HSPEC8.data_ptr(), R, 2 * r.rirs.cap, r.rirs.cap, r.rirs.cap, STREAM)
-    assert rc == 0, rc
-    torch.cuda.synchronize()
-
-
-def raw_half(plan, ag, sg):
-    if HSPEC8 is not None:
-        args = (r._spec8.data_ptr(), HSPEC8.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(),
-                None if ag is None else ag.data_ptr(), None if sg is None else sg.data_ptr(), len(plan), 16000, 0, STREAM)
-        fn = LIB.ss_audio_obs_half_spec_f32
-        return lambda: fn(*args)
-    cap = r.rirs.cap
-    args = (r._spec8.data_ptr(), r.rirs.data.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(),
-            None if ag is None else ag.data_ptr(), None if sg is None else sg.data_ptr(), len(plan), 2 * cap, cap, cap, 16000, 0, STREAM)
-    fn = LIB.ss_audio_obs_half_f32
-    return lambda: fn(*args)
-
-
 def raw_conv(plan, out):
-    if plan.kind == "half":
-        return raw_half(plan, out, None)
     """bound ctypes call (no per-launch torch / Python checks: ~3 us of host time instead of ~11, so that kernels shorter
     than the Python wrapper's overhead are still timed by the events)"""
     if r.rirs.spectra is not None:
@@ -87,8 +63,6 @@ def raw_conv(plan, out):
 
 
 def raw_fused(plan, sg):
-    if plan.kind == "half":
-        return raw_half(plan, None, sg)
     if r.rirs.spectra is not None:
         args = (r._spec.data_ptr(), r.rirs.spectra.data_ptr(), r.rirs.lengths.data_ptr(), plan.desc.data_ptr(), None,
                 sg.data_ptr(), len(plan), r.rirs.spectra.shape[2], r.n_valid, r.out_len, 0, plan.flags, STREAM)
@@ -108,22 +82,13 @@ for N in [int(x) for x in a.sizes.split(",")]:
     descs = [r.plan_arrays(snd(), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(a.distinct)]
     ag = torch.empty((N, 2, sr), device=dev); sg = torch.empty((N,) + r.spectrogram_shape, device=dev)
     res = {}
-    if a.halfspec:
-        d0 = descs[0]
-        a1 = torch.empty_like(ag); s1 = torch.empty_like(sg); a2 = torch.empty_like(ag); s2 = torch.empty_like(sg)
-        raw_half(d0, a1, s1)()
-        hs_, HSPEC8 = HSPEC8, None
-        raw_half(d0, a2, s2)()
-        HSPEC8 = hs_
-        torch.cuda.synchronize()
-        print("halfspec vs half: audiogoal %.2e spectrogram %.2e" % (float((a1 - a2).abs().max() / a2.abs().max()), float((s1 - s2).abs().max() / s2.abs().max())))
     if a.raw and sr <= 16384:
         cf = [raw_fused(d, sg) for d in descs]; cc = [raw_conv(d, ag) for d in descs]
         if a.only in ("", "fused"): res["fused"] = timeit(lambda k: cf[k % a.distinct](), a.reps)
         if a.only in ("", "conv"): res["conv"] = timeit(lambda k: cc[k % a.distinct](), a.reps)
-        print(f"N={N} sr={sr} raw {'spectral' if a.spectral else ('time' if os.environ.get('SS_HIP_NO_HALF') else ('halfspec' if a.halfspec else 'half'))} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} dbg={os.environ.get('SS_HIP_DBG', '0')} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
+        print(f"N={N} sr={sr} raw {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} dbg={os.environ.get('SS_HIP_DBG', '0')} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
         continue
     if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % a.distinct], spectrogram_out=sg, audiogoal_out=(ag if sr > 16384 else None)), a.reps)
     if a.only in ("", "conv"): res["conv"] = timeit(lambda k: r.render_audiogoal(descs[k % a.distinct], out=ag), a.reps)
     if a.only in ("", "spec"): res["spec"] = timeit(lambda k: ops.spectrogram_into(ag, sg), a.reps)
-    print(f"N={N} sr={sr} {'spectral' if a.spectral else ('time' if os.environ.get('SS_HIP_NO_HALF') else ('halfspec' if a.halfspec else 'half'))} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
+    print(f"N={N} sr={sr} {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)

@@ -9,7 +9,6 @@
 #include "../../include/ss_hip.h"
 #include "ss_context.hpp"
 #include "ss_kernels.hpp"
-#include "ss_kernels8.hpp"
 #include "ss_tables.hpp"
 
 namespace {
@@ -43,7 +42,6 @@ int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
         d.tb.twItem = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwItemOff);
         d.tb.tw512 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTw512Off);
         d.tb.win = dev_buf + ssk_host::kWinOff;
-        d.tb.twItem8 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwItem8Off);
         int cus = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);   // slow call: once per device
         if (e != hipSuccess) { (void)hipFree(dev_buf); return hip_err(e); }
@@ -287,130 +285,6 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
     return hip_err(hipGetLastError());
 }
 
-
-// ---- half-row kernels (ss_kernels8.hpp): 16 kHz, RIR rows <= 16000 taps, no distractor / cross-fade --------------------
-static int launch_windows8(const float* src, const int* win_desc, int desc_stride, float* spec, int n_windows, hipStream_t st) {
-    ssk8::SrcParams8 p;
-    int rc = get_tables(&p.tb);
-    if (rc) return rc;
-    p.src = src;
-    p.desc = win_desc;
-    p.spec = reinterpret_cast<ssk::f32x4*>(spec);
-    p.desc_stride = desc_stride;
-    p.scale = ssk8::kWindowScale8;
-    hipLaunchKernelGGL(ssk8::k_source_windows8, dim3(n_windows), dim3(ssk8::kT8), 0, st, p);
-    return hip_err(hipGetLastError());
-}
-
-int ss_half_spec_floats(void) { return 2 * ssk8::kSpec8; }
-
-int ss_source_windows8_f32(const float* src, const int* win_desc, float* spec_out, int n_windows, void* stream) {
-    if (n_windows == 0) return 0;
-    if (!src || !win_desc || !spec_out || n_windows < 0) return SS_EINVAL;
-    return launch_windows8(src, win_desc, 4, spec_out, n_windows, static_cast<hipStream_t>(stream));
-}
-
-static int audio_obs_half(const float* spec8, const float* rir, const float* hspec8, const int* rir_len, const int* unit_desc,
-                          float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
-                          int rir_chan_stride, int rir_cap, int out_len, int pad_mode, void* stream);
-
-int ss_audio_obs_half_f32(const float* spec8, const float* rir, const int* rir_len, const int* unit_desc,
-                          float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
-                          int rir_chan_stride, int rir_cap, int out_len, int pad_mode, void* stream) {
-    if (!rir) return n_units == 0 ? 0 : SS_EINVAL;
-    return audio_obs_half(spec8, rir, nullptr, rir_len, unit_desc, audiogoal, spectrogram, n_units, rir_unit_stride,
-                          rir_chan_stride, rir_cap, out_len, pad_mode, stream);
-}
-
-// spectral form: hspec8 from ss_rir_spectra8_f32 (entries x 2 ears x 2 partitions x ss_half_spec_floats())
-int ss_audio_obs_half_spec_f32(const float* spec8, const float* hspec8, const int* rir_len, const int* unit_desc,
-                               float* audiogoal, float* spectrogram, int n_units, int out_len, int pad_mode, void* stream) {
-    if (!hspec8) return n_units == 0 ? 0 : SS_EINVAL;
-    return audio_obs_half(spec8, reinterpret_cast<const float*>(16), hspec8, rir_len, unit_desc, audiogoal, spectrogram, n_units,
-                          32000, 16000, 16000, out_len, pad_mode, stream);
-}
-
-int ss_rir_spectra8_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride, int rir_chan_stride,
-                        int rir_cap, void* stream) {
-    if (n_entries == 0) return 0;
-    if (!rir || !hspec_out || n_entries < 0 || rir_cap <= 0 || rir_cap > 2 * ssk8::kP || rir_unit_stride < 0 ||
-        rir_chan_stride < 0)
-        return SS_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    long long per = (rir_unit_stride > 0) ? ((1LL << 30) / rir_unit_stride) : n_entries;
-    if (per < 1) return SS_EINVAL;
-    if (per > 2048) per = 2048;
-    std::vector<int> host(static_cast<size_t>(per) * 2 * 2 * 4);
-    int* dev_desc = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dev_desc), host.size() * sizeof(int));
-    if (e != hipSuccess) return hip_err(e);
-    int rc = 0;
-    for (long long r0 = 0; r0 < n_entries && rc == 0; r0 += per) {
-        const int cnt = static_cast<int>(n_entries - r0 < per ? n_entries - r0 : per);
-        int w = 0;
-        for (int r = 0; r < cnt; ++r)
-            for (int c = 0; c < 2; ++c)
-                for (int i = 0; i < 2; ++i, ++w) {
-                    const int left = rir_cap - i * ssk8::kP;
-                    host[4 * w + 0] = static_cast<int>(r * rir_unit_stride + (long long)c * rir_chan_stride + (long long)i * ssk8::kP);
-                    host[4 * w + 1] = left < 0 ? 0 : (left < ssk8::kP ? left : ssk8::kP);
-                    host[4 * w + 2] = 0;
-                    host[4 * w + 3] = 0;
-                }
-        e = hipMemcpyAsync(dev_desc, host.data(), sizeof(int) * 4 * static_cast<size_t>(w), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { rc = hip_err(e); break; }
-        ssk8::SrcParams8 p;
-        rc = get_tables(&p.tb);
-        if (rc) break;
-        p.src = rir + r0 * rir_unit_stride;
-        p.desc = dev_desc;
-        p.spec = reinterpret_cast<ssk::f32x4*>(hspec_out) + static_cast<size_t>(r0) * 4 * (ssk8::kSpec8 / 2);
-        p.desc_stride = 4;
-        p.scale = 1.0f;
-        hipLaunchKernelGGL(ssk8::k_source_windows8, dim3(w), dim3(ssk8::kT8), 0, st, p);
-        rc = hip_err(hipGetLastError());
-        if (rc == 0) rc = hip_err(hipStreamSynchronize(st));
-    }
-    (void)hipFree(dev_desc);
-    return rc;
-}
-
-static int audio_obs_half(const float* spec8, const float* rir, const float* hspec8, const int* rir_len, const int* unit_desc,
-                          float* audiogoal, float* spectrogram, int n_units, long long rir_unit_stride,
-                          int rir_chan_stride, int rir_cap, int out_len, int pad_mode, void* stream) {
-    if (n_units == 0) return 0;
-    if (!spec8 || !rir || !rir_len || !unit_desc || (!audiogoal && !spectrogram) || n_units < 0) return SS_EINVAL;
-    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
-    if (out_len != 16000 || rir_cap < 2 || rir_cap > 2 * ssk8::kP || (rir_cap & 1)) return SS_EINVAL;
-    if ((reinterpret_cast<size_t>(rir) & 7) || (rir_unit_stride & 1) || (rir_chan_stride & 1) || rir_unit_stride < 0 ||
-        rir_chan_stride < 0)
-        return SS_EINVAL;                                       // 8-byte aligned planar rows
-    ssk8::HalfParams p;
-    int rc = get_tables(&p.tb);
-    if (rc) return rc;
-    p.spec = reinterpret_cast<const ssk::f32x4*>(spec8);
-    p.rir = rir; p.rir_len = rir_len; p.desc = unit_desc;
-    p.out = audiogoal; p.sgram = spectrogram;
-    p.rir_unit_stride = rir_unit_stride; p.rir_chan_stride = rir_chan_stride; p.rir_cap = rir_cap;
-    p.out_len = out_len;
-    p.n_frames = n_frames_of(out_len); p.t4 = t4_of(out_len); p.pad_mode = pad_mode;
-    p.n_rows = 2 * n_units;
-    static const int xcd_map = getenv("SS_HIP_XCD_MAP") ? atoi(getenv("SS_HIP_XCD_MAP")) : 1;
-    p.xcd_map = xcd_map;
-    static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
-    p.dbg = dbg;
-    p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec8);
-    const dim3 grid(4 * n_units), block(ssk8::kT8);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hspec8) {
-        if (spectrogram) hipLaunchKernelGGL((ssk8::k_conv_half<true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((ssk8::k_conv_half<false, true>), grid, block, 0, st, p);
-    } else {
-        if (spectrogram) hipLaunchKernelGGL((ssk8::k_conv_half<true, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((ssk8::k_conv_half<false, false>), grid, block, 0, st, p);
-    }
-    return hip_err(hipGetLastError());
-}
 
 // ---- spectral RIR bank ---------------------------------------------------------------------------------------------
 int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride, int rir_chan_stride,

@@ -84,7 +84,6 @@ struct Tables {
     const c32* twItem;   // [2048]  exp(-2 pi i gA(q) / 32768)
     const c32* tw512;    // [256]   exp(-2 pi i k / 512)
     const float*  win;      // [512]   hann(400, periodic) centred in 512
-    const c32* twItem8;  // [2048]  exp(-2 pi i gA(q) / 16384)   (8192-point core, ss_fft8k.hpp)
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // ss_tables.hpp — host-side construction of the constant tables the kernels read (double precision -> f32).
-// Layout of the returned buffer (floats): twM[2*1024] | twItem[2*2048] | tw512[2*256] | win[512] | twItem8[2*2048].
+// Layout of the returned buffer (floats): twM[2*1024] | twItem[2*2048] | tw512[2*256] | win[512].
 #pragma once
 #include <cmath>
 #include <vector>
@@ -10,8 +10,7 @@ constexpr int kTwMOff = 0;
 constexpr int kTwItemOff = 2 * 1024;
 constexpr int kTw512Off = kTwItemOff + 2 * 2048;
 constexpr int kWinOff = kTw512Off + 2 * 256;
-constexpr int kTwItem8Off = kWinOff + 512;              // exp(-2 pi i gA(q) / 16384): Hermitian stage of the 8192-point core
-constexpr int kTableFloats = kTwItem8Off + 2 * 2048;
+constexpr int kTableFloats = kWinOff + 512;
 
 inline std::vector<float> build_tables() {
     const double two_pi = 6.283185307179586476925286766559;
@@ -31,14 +30,6 @@ inline std::vector<float> build_tables() {
         const double a = -two_pi * g / 32768.0;
         twItem[2 * q] = static_cast<float>(std::cos(a));
         twItem[2 * q + 1] = static_cast<float>(std::sin(a));
-    }
-    float* twItem8 = host.data() + kTwItem8Off;
-    for (int q = 0; q < 2048; ++q) {                       // same item -> group map, half the transform length
-        const int c = q & 15, lo = q >> 4;
-        const int g = lo != 0 ? lo + 256 * c : (c < 8 ? 256 * c : 128 + 256 * (c - 8));
-        const double a = -two_pi * g / 16384.0;
-        twItem8[2 * q] = static_cast<float>(std::cos(a));
-        twItem8[2 * q + 1] = static_cast<float>(std::sin(a));
     }
     for (int k = 0; k < 256; ++k) {                        // exp(-2 pi i k / 512)
         const double a = -two_pi * k / 512.0;

@@ -222,41 +222,6 @@ def audio_obs_spec_into(spec, hspec, rir_len, unit_desc, audiogoal, spectrogram_
                    "ss_audio_obs_spec_f32")
 
 
-# ---- half-row kernels (16 kHz, RIR <= 16000 taps; two workgroups per CU) -------------------------------------------
-HALF_SPEC_FLOATS = 2 * 8192
-
-
-def source_windows8_into(src: torch.Tensor, win_desc: torch.Tensor, spec_out: torch.Tensor) -> None:
-    _chk(src, torch.float32, "src"); _chk(win_desc, torch.int32, "win_desc"); _chk(spec_out, torch.float32, "spec_out")
-    W = win_desc.shape[0]
-    assert win_desc.shape == (W, 4) and spec_out.numel() >= W * HALF_SPEC_FLOATS
-    with torch.cuda.device(src.device):
-        _lib.check(_lib.load().ss_source_windows8_f32(src.data_ptr(), win_desc.data_ptr(), spec_out.data_ptr(), W, _stream()),
-                   "ss_source_windows8_f32")
-
-
-def audio_obs_half_into(spec8, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, pad_mode="reflect") -> None:
-    """ss_audio_obs_half_f32: planar bank [R,2,cap<=16000]; audiogoal / spectrogram_out may be None (not both)."""
-    _chk(spec8, torch.float32, "spec8"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
-    _chk(unit_desc, torch.int32, "unit_desc")
-    N = unit_desc.shape[0]
-    R, two, cap = rir_bank.shape
-    assert two == 2 and unit_desc.shape == (N, 8)
-    ag_ptr = sg_ptr = None
-    if audiogoal is not None:
-        _chk(audiogoal, torch.float32, "audiogoal")
-        assert tuple(audiogoal.shape) == (N, 2, 16000)
-        ag_ptr = audiogoal.data_ptr()
-    if spectrogram_out is not None:
-        _chk(spectrogram_out, torch.float32, "spectrogram_out")
-        assert tuple(spectrogram_out.shape) == (N, 65, 26, 2)
-        sg_ptr = spectrogram_out.data_ptr()
-    with torch.cuda.device(spec8.device):
-        _lib.check(_lib.load().ss_audio_obs_half_f32(spec8.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
-                                                     unit_desc.data_ptr(), ag_ptr, sg_ptr, N, 2 * cap, cap, cap, 16000,
-                                                     _PAD[pad_mode], _stream()), "ss_audio_obs_half_f32")
-
-
 def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:
     """av_wan Intensity (ss_baselines/av_wan/avwan_sensors.py:91-100): [N,2,T] -> [N] mean-square of the 150 samples
     after the onset."""

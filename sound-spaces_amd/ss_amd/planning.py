@@ -150,31 +150,3 @@ def mel_filterbank_sparse(sr: int, n_mels: int = 64, n_fft: int = 512, fmin: flo
 
 def logmel_shape(n_samples: int, n_mels: int):
     return (n_mels, 1 + n_samples // 160, 2)
-
-
-# ---- half-row kernels (csrc/ss_kernels8.hpp): 16 kHz, RIR <= 16000 taps --------------------------------------------------
-HALF_SEG = 16384            # samples per window (one 8192-point complex FFT)
-HALF_P = 8000               # RIR partition length = hop between the windows of consecutive partitions
-HALF_VALID = HALF_SEG - HALF_P + 1      # 8385 alias-free samples per block
-HALF_SPEC_FLOATS = 2 * 8192
-HALF_SR = 16000
-
-
-def half_block_ends(out_len: int = HALF_SR):
-    """E_j: half j produces output samples (E_j - 8385, E_j]-ish: [0, 8385) and [7615, 16000)."""
-    return (HALF_VALID, out_len)
-
-
-def half_window_starts(t0: int, out_len: int = HALF_SR):
-    """Start sample of the source window S_{j,i} (half j, RIR partition i), in the order the unit descriptor lists the
-    slots: (0,0), (0,1), (1,0), (1,1).  start = t0 + E_j - 8000 i - 16384."""
-    return tuple(t0 + e - HALF_P * i - HALF_SEG for e in half_block_ends(out_len) for i in (0, 1))
-
-
-def half_window_live(start: int, source_len: int) -> bool:
-    """False when the window x[start : start + 16384] holds no sample of the clip (its spectrum is zero: slot -1)."""
-    return start + HALF_SEG > 0 and start < source_len
-
-
-def half_eligible(sr: int, n_valid: int, rir_cap: int, wrap: bool) -> bool:
-    return sr == HALF_SR and n_valid == sr and rir_cap <= 2 * HALF_P and not (rir_cap & 1) and not wrap

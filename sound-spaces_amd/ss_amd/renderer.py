@@ -129,7 +129,6 @@ class Plan:
     """Device-side unit descriptors of one batch + what the host knows about them."""
     desc: torch.Tensor            # int32 [N, 8]
     flags: int = 0                # ops.FLAG_* promises (e.g. no unit carries a distractor term)
-    kind: str = "full"            # "half": descriptors of the half-row kernels (ss_audio_obs_half_f32)
 
     def __len__(self):
         return int(self.desc.shape[0])
@@ -156,12 +155,6 @@ class BatchedAudioRenderer:
         self._n_slots = 0
         self._windows: Dict[Tuple[int, int, bool], Tuple[int, P.WindowSet]] = {}
         self.spectrogram_shape = P.spectrogram_shape(self.out_len)
-        # half-row kernels (16 kHz, RIR <= 16000 taps, no distractor / cross-fade): two workgroups per CU
-        import os
-        self.use_half = os.environ.get("SS_HIP_NO_HALF") is None
-        self._spec8 = torch.empty((4 * spec_capacity, P.HALF_SPEC_FLOATS), dtype=torch.float32, device=self.device)
-        self._n_slots8 = 0
-        self._windows8: Dict[Tuple[int, int], int] = {}
 
     # ---- banks ---------------------------------------------------------------------------------------
     def add_source(self, name: str, clip: np.ndarray) -> int:
@@ -175,55 +168,6 @@ class BatchedAudioRenderer:
     def clear_window_cache(self) -> None:
         self._windows.clear()
         self._n_slots = 0
-        self._windows8.clear()
-        self._n_slots8 = 0
-
-    # ---- half-row planning ---------------------------------------------------------------------------------------
-    def half_ok(self) -> bool:
-        return (self.use_half and self.rirs is not None and self.rirs.spectra is None
-                and P.half_eligible(self.sr, self.n_valid, self.rirs.cap, self.wrap))
-
-    def _half_slots(self, pairs) -> Dict[Tuple[int, int], Tuple[int, int, int, int]]:
-        """(sound, t0) -> the 4 window slots (j,i) = (0,0), (0,1), (1,0), (1,1) of the half-row kernels (-1: the window
-        holds no sample of the clip); missing spectra are computed (k_source_windows8)."""
-        out, rows, first = {}, [], self._n_slots8
-        for (sid, t0) in pairs:
-            slots = []
-            for start in P.half_window_starts(t0):
-                if not P.half_window_live(start, self.sources.lengths[sid]):
-                    slots.append(-1)
-                    continue
-                key = (sid, start)
-                if key not in self._windows8:
-                    self._windows8[key] = self._n_slots8
-                    self._n_slots8 += 1
-                    rows.append((self.sources.offsets[sid], self.sources.lengths[sid], start, 0))
-                slots.append(self._windows8[key])
-            out[(sid, t0)] = tuple(slots)
-        if rows:
-            if self._n_slots8 > self._spec8.shape[0]:
-                grown = torch.empty((max(self._n_slots8, 2 * self._spec8.shape[0]), P.HALF_SPEC_FLOATS),
-                                    dtype=torch.float32, device=self.device)
-                grown[:first] = self._spec8[:first]
-                self._spec8 = grown
-            wd = torch.from_numpy(np.asarray(rows, np.int32).reshape(-1, 4)).to(self.device)
-            ops.source_windows8_into(self.sources.flat(), wd, self._spec8[first:first + len(rows)])
-        return out
-
-    def _plan_half(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray) -> Plan:
-        desc = np.zeros((sound.shape[0], 8), np.int32)
-        desc[:, 0] = -1
-        active = rir >= 0
-        if active.any():
-            keys, inv = np.unique(np.stack([sound[active], t0[active]], axis=1), axis=0, return_inverse=True)
-            table = self._half_slots([(int(s), int(t)) for s, t in keys])
-            tab = np.array([table[(int(s), int(t))] for s, t in keys], np.int32).reshape(-1, 4)
-            rows = tab[inv.reshape(-1)]
-            ok = (rows >= 0).any(axis=1)                            # no live window: nothing to convolve -> silent
-            idx = np.flatnonzero(active)[ok]
-            desc[idx, 0] = rir[active][ok]
-            desc[idx, 1:5] = rows[ok]
-        return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), ops.FLAG_NO_DISTRACTOR, kind="half")
 
     # ---- planning --------------------------------------------------------------------------------------
     def _ensure_windows(self, keys) -> None:
@@ -254,16 +198,9 @@ class BatchedAudioRenderer:
             return False
         return t0 + self.n_valid > self.sources.lengths[sound]
 
-    def plan(self, units: Sequence[UnitRequest], allow_half: bool = True) -> Plan:
-        """-> unit descriptors (int32 [N, 8]) on the device; computes any missing source-window spectra.
-        Batches the half-row kernels can serve (16 kHz, RIR rows <= 16000 taps, no distractor / cross-fade; see
-        csrc/ss_kernels8.hpp) are planned for them unless allow_half is False."""
+    def plan(self, units: Sequence[UnitRequest]) -> Plan:
+        """-> unit descriptors (int32 [N, 8]) on the device; computes any missing source-window spectra."""
         assert self.rirs is not None, "set_rir_bank() first"
-        if allow_half and self.half_ok() and not any((u.dis_rir >= 0 or u.last_rir >= 0) and not u.silent and u.rir >= 0 for u in units):
-            n = len(units)
-            return self._plan_half(np.fromiter((u.sound for u in units), np.int64, n),
-                                   np.fromiter((u.t0 for u in units), np.int64, n),
-                                   np.fromiter((-1 if u.silent else u.rir for u in units), np.int64, n))
         keys, ukeys = [], []
         for u in units:
             k0 = k1 = None
@@ -299,8 +236,7 @@ class BatchedAudioRenderer:
             flags = ops.FLAG_CROSSFADE
         return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), flags)
 
-    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray, rotations: int = 1,
-                    allow_half: bool = True) -> Plan:
+    def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray, rotations: int = 1) -> Plan:
         """Vectorised plan() for the common no-distractor case (rir < 0 = silent): the per-step host cost is a handful
         of numpy operations on the N-vectors plus one dict lookup per *distinct* (sound, t0) pair.
         ``rotations`` = R > 1: every env yields R units (unit n*R + k) that hear the same clip window through the R
@@ -315,8 +251,6 @@ class BatchedAudioRenderer:
             k = np.arange(rotations, dtype=np.int64)
             sound, t0 = np.repeat(sound, rotations), np.repeat(t0, rotations)
             rir = np.where(rir[:, None] >= 0, rir[:, None] + k[None, :], -1).reshape(-1)
-        if allow_half and self.half_ok():
-            return self._plan_half(sound, t0, rir)
         active = rir >= 0
         desc = np.zeros((sound.shape[0], 8), np.int32)
         desc[:, 0] = -1
@@ -347,9 +281,7 @@ class BatchedAudioRenderer:
         sg = spectrogram_out
         if sg is None:
             sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
-        if plan.kind == "half":
-            ops.audio_obs_half_into(self._spec8, self.rirs.data, self.rirs.lengths, plan.desc, ag, sg, self.pad_mode)
-        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
             ops.audio_obs_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
                                     self.out_len, self.pad_mode, flags=plan.flags)
         else:
@@ -361,9 +293,7 @@ class BatchedAudioRenderer:
         """AudioGoalSensor-only configurations (soundspaces/tasks/nav.py:37-60)."""
         if out is None:
             out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
-        if plan.kind == "half":
-            ops.audio_obs_half_into(self._spec8, self.rirs.data, self.rirs.lengths, plan.desc, out, None, self.pad_mode)
-        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
             ops.fftconv_binaural_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, out, self.n_valid,
                                            flags=plan.flags)
         else:

@@ -9,7 +9,6 @@
 
 #include "hip_shim.h"
 #include "../../sound-spaces_amd/csrc/ss_kernels.hpp"
-#include "../../sound-spaces_amd/csrc/ss_kernels8.hpp"
 #include "../../sound-spaces_amd/csrc/ss_tables.hpp"
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -90,7 +89,6 @@ ssk::Tables host_tables() {
     tb.twItem = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwItemOff);
     tb.tw512 = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTw512Off);
     tb.win = tab.data() + ssk_host::kWinOff;
-    tb.twItem8 = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwItem8Off);
     return tb;
 }
 }  // namespace
@@ -217,38 +215,6 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
             });
             if (rc) return rc;
         }
-    return 0;
-}
-
-// ---- half-row kernels (ss_kernels8.hpp) ------------------------------------------------------------------------------
-int hs_source_windows8(const float* src, const int* desc, float* spec, int n_windows) {
-    ssk8::SrcParams8 p;
-    p.src = src; p.desc = desc; p.spec = reinterpret_cast<ssk::f32x4*>(spec); p.tb = host_tables();
-    p.desc_stride = 4; p.scale = ssk8::kWindowScale8;
-    gridDim = dim3{(unsigned)n_windows, 1, 1};
-    for (int w = 0; w < n_windows; ++w) {
-        blockIdx = dim3{(unsigned)w, 0, 0};
-        int rc = run_block(ssk8::kT8, [&] { ssk8::k_source_windows8(p); });
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-int hs_conv_half(int fuse, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
-                 float* sgram, int n_units, long long us, int cs, int cap, int out_len, int pad_mode, int xcd_map) {
-    ssk8::HalfParams p;
-    p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
-    p.out = out; p.sgram = sgram; p.tb = host_tables();
-    p.rir_unit_stride = us; p.rir_chan_stride = cs; p.rir_cap = cap; p.out_len = out_len;
-    p.n_frames = 1 + out_len / ssk::kHop; p.t4 = (p.n_frames + 3) / 4; p.pad_mode = pad_mode;
-    p.n_rows = 2 * n_units; p.xcd_map = xcd_map; p.dbg = 0; p.hspec = nullptr;
-    if (out_len != 16000 || cap > 16000 || (cap & 1)) return -1;
-    gridDim = dim3{(unsigned)(4 * n_units), 1, 1};
-    for (int b = 0; b < 4 * n_units; ++b) {
-        blockIdx = dim3{(unsigned)b, 0, 0};
-        int rc = run_block(ssk8::kT8, [&] { if (fuse) ssk8::k_conv_half<true>(p); else ssk8::k_conv_half<false>(p); });
-        if (rc) return rc;
-    }
     return 0;
 }
 

@@ -19,8 +19,7 @@ def lib():
         so = os.path.join(HERE, "libss_hostsim.so")
         srcs = [os.path.join(HERE, f) for f in ("hostsim.cpp", "hip_shim.h")]
         csrc = os.path.join(HERE, "..", "..", "sound-spaces_amd", "csrc")
-        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp", "ss_kernels8.hpp",
-                                                 "ss_fft8k.hpp")]
+        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             cxx = os.environ.get("SS_HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")   # needs ext_vector_type
             subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
@@ -152,49 +151,3 @@ def gccphat(x, max_lag=32, eps=1e-8, pad_mode=0, gpw=1):
     rc = L.hs_gccphat(_p(x, ctypes.c_float), _p(out, ctypes.c_float), N, n, pad_mode, max_lag, ctypes.c_float(eps), gpw)
     assert rc == 0, rc
     return out
-
-
-def run_half(sources, rir_bank, rir_len, units, fuse=True, pad_mode=0, xcd_map=0):
-    """Half-row kernels (k_source_windows8 + k_conv_half): sr = 16000, units = dicts {sound, t0, rir} (rir < 0 silent).
-    Returns (audiogoal [N,2,16000], spectrogram [N,65,26,2] or None)."""
-    L = lib()
-    sr = P.HALF_SR
-    rir_bank = np.ascontiguousarray(rir_bank, dtype=np.float32)
-    R, _, cap = rir_bank.shape
-    assert P.half_eligible(sr, sr, cap, False)
-    offs = np.cumsum([0] + [len(s) for s in sources])
-    flat = np.concatenate([np.asarray(s, np.float32) for s in sources]).astype(np.float32)
-    cache, rows = {}, []
-
-    def slot_of(sound, start):
-        if not P.half_window_live(start, len(sources[sound])):
-            return -1
-        key = (sound, start)
-        if key not in cache:
-            cache[key] = len(rows)
-            rows.append((int(offs[sound]), len(sources[sound]), start, 0))
-        return cache[key]
-
-    desc = np.zeros((len(units), 8), np.int32)
-    desc[:, 0] = -1
-    for n, u in enumerate(units):
-        if u.get("rir", -1) < 0:
-            continue
-        slots = [slot_of(u["sound"], st) for st in P.half_window_starts(u["t0"])]
-        if all(s_ < 0 for s_ in slots):
-            continue
-        desc[n, 0] = u["rir"]
-        desc[n, 1:5] = slots
-    wd = np.ascontiguousarray(np.asarray(rows, np.int32).reshape(-1, 4))
-    spec = np.zeros((max(1, len(wd)), P.HALF_SPEC_FLOATS), np.float32)
-    rc = L.hs_source_windows8(_p(flat, ctypes.c_float), _p(wd, ctypes.c_int), _p(spec, ctypes.c_float), len(wd))
-    assert rc == 0, rc
-    N = len(units)
-    out = np.full((N, 2, sr), np.nan, np.float32)
-    sg = np.full((N, 65, 26, 2), np.nan, np.float32)
-    rl = np.ascontiguousarray(rir_len, np.int32)
-    rc = L.hs_conv_half(int(fuse), _p(spec, ctypes.c_float), _p(rir_bank, ctypes.c_float), _p(rl, ctypes.c_int),
-                        _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
-                        N, ctypes.c_longlong(2 * cap), cap, cap, sr, pad_mode, xcd_map)
-    assert rc == 0, rc
-    return out, (sg if fuse else None)

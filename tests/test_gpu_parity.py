@@ -57,9 +57,6 @@ def test_sim_branches_vs_reference_vectors(name):
     ag2 = r.render_audiogoal(r.plan([UnitRequest(0, t0, 0)]))
     scale = float(ag.abs().max())
     assert float((ag - ag2).abs().max()) <= 2e-6 * scale
-    # the same unit through the 16384-point kernels (the half-row kernels serve the eligible batches by default)
-    ag3, sg3 = r.render(r.plan([UnitRequest(0, t0, 0)], allow_half=False), want_audiogoal=True)
-    assert float((ag - ag3).abs().max()) <= 4e-6 * scale and float((sg - sg3).abs().max()) <= 2e-5 * float(sg.abs().max())
     sg2 = torch.ops.ss_hip.spectrogram(ag2, 0)
     assert float((sg - sg2).abs().max()) <= 1e-5 * float(sg.abs().max())
 
@@ -219,7 +216,7 @@ def test_interleaved_wav_layout_matches_planar():
     d = case_inputs("clip1s_ragged")
     sr = d["sr"]
     r = make_renderer(sr, [d["source"]], [d["rir"]])
-    desc = r.plan([UnitRequest(0, 0, 0)], allow_half=False)
+    desc = r.plan([UnitRequest(0, 0, 0)])
     a1 = r.render_audiogoal(desc)
     wav = r.rirs.data.transpose(1, 2).contiguous()             # [R, cap, 2]
     a2 = ops.fftconv_binaural(r._spec, wav, r.rirs.lengths, desc.desc, sr, sr, interleaved=True, flags=desc.flags)
@@ -391,7 +388,7 @@ def test_spectral_rir_bank_vs_oracle_and_time_domain_bank(sr, n_units, ragged):
     src, rirs, sel_s, sel_r = _random_batch(sr, n_units, 5, 16, seed=2, ragged=ragged)
     r = make_renderer(sr, list(src), rirs)
     units = [UnitRequest(int(s), 0, int(h), silent=(n % 29 == 3)) for n, (s, h) in enumerate(zip(sel_s, sel_r))]
-    plan = r.plan(units, allow_half=False)
+    plan = r.plan(units)
     ag_t, sg_t = r.render(plan, want_audiogoal=True)
     r.rirs.build_spectra()
     assert tuple(r.rirs.spectra.shape) == (16, 2, P.ceil_div(r.rirs.cap, P.KB), P.SPEC_FLOATS)
@@ -450,42 +447,6 @@ def test_spectral_rir_bank_distractor_multisecond_long_rir_and_context():
         check(sg[n], O.compute_spectrogram(refs[n].astype(np.float32)))
 
 
-def test_half_row_kernels_headline_shape_vs_oracle():
-    """k_conv_half at the headline shape: 128 envs @16 kHz, ragged RIRs (one and two 8000-tap partitions), 1-s and
-    multi-second clips, silent units, an empty RIR; fused and AudioGoal-only; every unit against the oracle and the whole
-    batch against the 16384-point kernels."""
-    from ss_amd.renderer import UnitRequest
-    sr, n_units = 16000, 128
-    rng = np.random.default_rng(81)
-    src = list(O.synth_sources(rng, sr, k=4)) + [O.synth_sources(rng, sr, k=1, seconds=4)[0]]
-    lens = [16000, 7000, 8000, 8001, 12346, 15999, 3000, 16000]
-    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T) for L in lens] + [None]
-    r = make_renderer(sr, src, rirs)
-    units, refs = [], []
-    for n in range(n_units):
-        s_, h_ = int(rng.integers(0, 5)), int(rng.integers(0, 9))
-        idx = int(rng.integers(0, 4)) if s_ == 4 else 0
-        silent = n % 43 == 5
-        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_, silent=silent))
-        refs.append(None if (silent or h_ == 8) else O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx))
-    plan = r.plan(units)
-    assert plan.kind == "half"
-    ag, sg = r.render(plan, want_audiogoal=True)
-    sg_only = r.render(plan)[1]
-    ag_only = r.render_audiogoal(plan)
-    ag_f, sg_f = r.render(r.plan(units, allow_half=False), want_audiogoal=True)
-    assert torch.equal(sg, sg_only) and torch.equal(ag, ag_only)
-    assert float((ag - ag_f).abs().max()) <= 4e-6 * float(ag_f.abs().max())
-    assert float((sg - sg_f).abs().max()) <= 2e-5 * float(sg_f.abs().max())
-    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
-    for n in range(n_units):
-        if refs[n] is None:
-            assert not ag[n].any() and not sg[n].any()
-            continue
-        check(ag[n], refs[n])
-        check(sg[n], O.compute_spectrogram(refs[n].astype(np.float32)))
-
-
 def test_persistent_row_kernel_large_batches():
     """More (unit, ear) rows than CUs: the AudioGoal-only path switches to the persistent k_conv_rows (next row's RIR
     prefetched under the inverse passes).  300 units with ragged RIRs, silent units and an empty RIR in the walk;
@@ -503,7 +464,7 @@ def test_persistent_row_kernel_large_batches():
             units.append(UnitRequest(int(s_), 0, len(rirs) - 1))
         else:
             units.append(UnitRequest(int(s_), 0, int(h_)))
-    plan = r.plan(units, allow_half=False)                          # k_conv_rows belongs to the 16384-point kernels
+    plan = r.plan(units)
     ag = r.render_audiogoal(plan).cpu().numpy()
     ag_f, _ = r.render(plan, want_audiogoal=True)
     scale = float(ag_f.abs().max())
@@ -772,10 +733,6 @@ def test_vectorised_planner_equals_per_unit_planner():
     rir = rng.integers(-1, 6, n)                                        # -1 = silent
     a = r.plan_arrays(sound, t0, rir)
     b = r.plan([UnitRequest(int(s), int(t), int(h)) for s, t, h in zip(sound, t0, rir)])
-    assert torch.equal(a.desc, b.desc) and a.flags == b.flags and a.kind == b.kind == "half"
-    a2 = r.plan_arrays(sound, t0, rir, allow_half=False)
-    b2 = r.plan([UnitRequest(int(s), int(t), int(h)) for s, t, h in zip(sound, t0, rir)], allow_half=False)
-    assert torch.equal(a2.desc, b2.desc) and a2.flags == b2.flags and a2.kind == "full"
-    assert float((r.render(a)[1] - r.render(a2)[1]).abs().max()) <= 2e-5 * float(r.render(a2)[1].abs().max())
+    assert torch.equal(a.desc, b.desc) and a.flags == b.flags
     sg = r.render(a)[1].cpu().numpy()
     assert not sg[rir < 0].any()

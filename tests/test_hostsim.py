@@ -206,49 +206,6 @@ def test_spectral_rir_bank_equals_time_domain_bank(name):
         assert np.abs(a_u[0] - a_s[0]).max() <= 2e-6 * np.abs(a_t).max()
 
 
-HALF_CASES = ["clip1s", "clip1s_ragged", "clip1s_singing", "multi_L1.0_i0", "multi_L1.0_i2", "multi_L1.0_i4"]
-
-
-@pytest.mark.parametrize("name", HALF_CASES)
-def test_half_row_kernels_vs_reference_vectors(name):
-    """k_source_windows8 + k_conv_half (two 512-thread workgroups per row, 8192-point FFT, 8000-tap RIR partitions, 13 + 13
-    pooled STFT blocks with no hand-off between the halves) against the vectors produced by running the reference:
-    1-s clips, a ragged RIR (one partition), the real clip, multi-second windows (early and steady branch)."""
-    d = case_inputs(name)
-    sr = d["sr"]
-    ref_a, ref_s, stride = case_outputs(name)
-    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
-    bank = planar(d["rir"], 16000)
-    units = [dict(sound=0, t0=t0, rir=0), dict(rir=-1)]
-    out, sg = hs.run_half([d["source"]], bank, [d["rir"].shape[0]], units, fuse=True)
-    check(out[0][:, ::stride], ref_a)
-    check(sg[0], ref_s)
-    assert not out[1].any() and not sg[1].any()
-    out2, _ = hs.run_half([d["source"]], bank, [d["rir"].shape[0]], units, fuse=False, xcd_map=1)
-    np.testing.assert_array_equal(out2, out)
-
-
-@pytest.mark.parametrize("pad_mode", [0, 1])
-def test_half_row_kernels_batch_and_padding_modes(pad_mode):
-    rng = np.random.default_rng(3)
-    sr = 16000
-    srcs = list(O.synth_sources(rng, sr, k=2)) + [O.synth_sources(rng, sr, k=1, seconds=3)[0]]
-    lens = [16000, 7000, 8000, 8001, 12346, 0]
-    bank = np.zeros((len(lens), 2, 16000), np.float32)
-    for i, L in enumerate(lens):
-        if L:
-            bank[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
-    units = [dict(sound=n % 3, t0=(n % 3 == 2) * sr * (n % 2 + 1), rir=n % 6) for n in range(9)]
-    out, sg = hs.run_half(srcs, bank, lens, units, fuse=True, pad_mode=pad_mode, xcd_map=1)
-    for n, u in enumerate(units):
-        if lens[u["rir"]] == 0:
-            assert not out[n].any() and not sg[n].any()
-            continue
-        ref = O.conv_window_fft(srcs[u["sound"]], np.ascontiguousarray(bank[u["rir"], :, :lens[u["rir"]]].T), u["t0"], sr)
-        check(out[n], ref)
-        check(sg[n], O.compute_spectrogram(ref.astype(np.float32), pad_mode="reflect" if pad_mode == 0 else "constant"))
-
-
 def test_44k_three_output_blocks_three_rir_blocks():
     d = case_inputs("clip1s_44k")
     sr = d["sr"]
