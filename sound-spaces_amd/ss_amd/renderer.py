@@ -335,7 +335,7 @@ class RirStore:
     pair: SURVEY 8(f)2), loaded and evicted together; ``slot()`` then returns the first slot of the group."""
 
     def __init__(self, slots: int, cap: int, device, truncate_to: Optional[int] = None, max_cap: int = 1 << 18,
-                 on_grow=None, group: int = 1):
+                 on_grow=None, group: int = 1, spectral: bool = False):
         cap += cap & 1
         assert slots % group == 0
         self.device = torch.device(device)
@@ -350,6 +350,13 @@ class RirStore:
         self._batch_of = np.full((slots,), -1, np.int64)      # batch in which the slot was last handed out
         self.hits = self.misses = self.grown = 0
         self._clipped = np.zeros((slots,), bool)              # the stored row is shorter than its RIR (truncate_to)
+        # spectral=True keeps the block spectra of every row next to it (RirBank.spectra, ss_rir_spectra_f32): rows
+        # (re)loaded since the last sync_spectra() are transformed there, once, instead of once per step and unit
+        self.spectral = spectral
+        self._stale = np.zeros((slots,), bool)
+        if spectral and self.device.type == "cuda":
+            self.bank.spectra = torch.zeros((slots, 2, P.ceil_div(cap, P.KB), P.SPEC_FLOATS), dtype=torch.float32,
+                                            device=self.device)
         # pinned staging ring for single-row uploads (a pageable torch copy blocks the host for the whole transfer)
         self._stage = None
         self._stage_ev: List = []
@@ -383,6 +390,10 @@ class RirStore:
         data = torch.zeros((self.slots, 2, new_cap), dtype=torch.float32, device=self.device)
         data[:, :, :self.cap] = self.bank.data
         self.bank = RirBank(data, self.bank.lengths)
+        if self.spectral and self.device.type == "cuda":        # more blocks per row: every spectrum is rebuilt
+            self.bank.spectra = torch.zeros((self.slots, 2, P.ceil_div(new_cap, P.KB), P.SPEC_FLOATS),
+                                            dtype=torch.float32, device=self.device)
+            self._stale[:] = self.host_len > 0
         self.cap = new_cap
         self._stage = None
         self.grown += 1
@@ -419,6 +430,24 @@ class RirStore:
             self._stage_ev[k] = ev
         self.bank.lengths[slot:slot + 1].fill_(n)
         self.host_len[slot] = n
+        self._stale[slot] = True
+
+    def sync_spectra(self) -> int:
+        """spectral stores: transform the rows loaded since the last call (contiguous runs, one ss_rir_spectra_f32 each;
+        synchronous - this is bank-load work, steady-state steps find nothing to do).  Returns the rows transformed."""
+        if not self.spectral or self.bank.spectra is None or not self._stale.any():
+            return 0
+        idx = np.flatnonzero(self._stale)
+        run_start = prev = int(idx[0])
+        for i in list(idx[1:]) + [None]:
+            if i is not None and int(i) == prev + 1:
+                prev = int(i)
+                continue
+            ops.rir_spectra_into(self.bank.data, self.bank.spectra, run_start, prev - run_start + 1)
+            if i is not None:
+                run_start = prev = int(i)
+        self._stale[:] = False
+        return int(idx.shape[0])
 
     def _take_slot(self) -> int:
         if self._free:
@@ -514,6 +543,7 @@ class RirStore:
             self.bank.data.index_copy_(0, idx, stage.to(self.device, non_blocking=True))
             self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
             self.host_len[np.asarray(slots)] = lens
+            self._stale[np.asarray(slots)] = True
             self._clipped[np.asarray(slots)] = [n < r.shape[1] for n, r in zip(kept, rows)]
             if self.device.type == "cuda":
                 torch.cuda.current_stream(self.device).synchronize()   # the pinned block dies with this scope
@@ -553,12 +583,15 @@ class AudioEngine:
     use, longer RIRs grow the bank (RirStore)."""
 
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
-                 rir_max_cap: int = 1 << 18, rir_group: int = 1, **renderer_kwargs):
+                 rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: bool = False, **renderer_kwargs):
+        """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec (no
+        forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change every step and stay
+        on the time-domain kernels."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
         self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device,
                               truncate_to=None if full else int(sampling_rate), max_cap=rir_max_cap,
-                              on_grow=self.renderer.set_rir_bank, group=rir_group)
+                              on_grow=self.renderer.set_rir_bank, group=rir_group, spectral=rir_spectral and not full)
         self.renderer.set_rir_bank(self.store.bank)
 
     def source_id(self, name: str, clip: np.ndarray) -> int:
@@ -577,6 +610,7 @@ class AudioEngine:
 
     def observe(self, units: Sequence[UnitRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None) -> Dict[str, torch.Tensor]:
+        self.store.sync_spectra()
         plan = self.renderer.plan(units)
         if not want_spectrogram:
             return {"audiogoal": self.renderer.render_audiogoal(plan, out=audiogoal_out)}

@@ -411,6 +411,34 @@ def test_spectral_rir_bank_vs_oracle_and_time_domain_bank(sr, n_units, ragged):
         check(sg[n], cache[key][1])
 
 
+def test_spectral_store_keeps_spectra_in_step_with_the_rows():
+    """AudioEngine(rir_spectral=True): rows loaded on demand (misses, LRU eviction, bank growth for a 1.5-s RIR with a
+    multi-second clip) get their block spectra at the next observe(); every result against the oracle."""
+    from fakes import FakeSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    sr = 16000
+    rng = np.random.default_rng(5)
+    sounds = {"a.wav": O.synth_sources(rng, sr, k=1)[0], "long.wav": O.synth_sources(rng, sr, k=1, seconds=3)[0]}
+    files = {f"rirs/replica/apartment_0/{az}/{r}_7.wav": np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T)
+             for az in (0, 90, 180, 270) for r, L in ((1, 9000), (2, 16000), (3, 24000))}
+    sim = FakeSim(sr, sounds, files)
+    eng = AudioEngine(sr, device=DEV, rir_slots=4, rir_spectral=True)              # 12 files through 4 slots: evictions
+    sim_audio.attach(sim, eng, rir_reader=files.get)
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    for step in range(14):
+        sim._receiver_position_index = 1 + step % 3
+        sim._rotation_angle = (step * 90) % 360
+        sim._current_sound = "long.wav" if step >= 7 else "a.wav"
+        sim._audiogoal_cache, sim._spectrogram_cache = {}, {}
+        idx = sim._audio_index
+        a = ag_sensor.get_observation(observations=None, episode=None)
+        path = f"rirs/replica/apartment_0/{sim.azimuth_angle}/{sim._receiver_position_index}_7.wav"
+        check(a, O.compute_audiogoal(sim.current_source_sound, files[path], sr, audio_index=idx))
+    assert eng.store.bank.spectra is not None and eng.store.grown == 1 and eng.store.bank.spectra.shape[2] == 2
+    assert eng.renderer.rirs.spectra is eng.store.bank.spectra and not eng.store._stale.any()
+
+
 def test_spectral_rir_bank_distractor_multisecond_long_rir_and_context():
     """Spectral bank through the loop kernel: distractor terms, multi-second windows, a 1.5-s RIR (2 blocks per entry),
     via the renderer and via the context API (ss_ctx_set_rir_spectra)."""
