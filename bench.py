@@ -156,7 +156,7 @@ class SyntheticSim:
         self._episode_step_count += 1
 
 
-def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, steps, warmup):
+def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, steps, warmup, spectra=None):
     """-> dict for the JSON line.  One 'scene' of n_nodes x n_nodes (receiver, source) pairs whose 4 azimuths sit in 4
     adjacent rows of `bank` (the same HBM-resident bank as the headline); n_envs stand-in simulators bound to a
     VectorSimState; per step: agents move (attribute writes on the simulators), FastVectorAudioObserver.observe_into()
@@ -172,6 +172,8 @@ def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, ste
     sounds = {"sound%d" % i: c for i, c in enumerate(sources)}
     ctx = AudioContext(sr, max_window_sets=max(256, 2 * n_sounds))
     ctx.set_rir_bank(bank, torch.full((R,), bank.shape[2], dtype=torch.int32, device=dev))
+    if spectra is not None:
+        ctx.set_rir_spectra(spectra)                      # same bank format as the headline loop
     index = RirIndex(4)
     sid = index.add_scene("synthetic", n_nodes)
     rr, ss = np.meshgrid(np.arange(n_nodes), np.arange(n_nodes), indexing="ij")
@@ -269,7 +271,10 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --envs per GPU (default); strong: --envs in total, split over the ranks (BASELINE configs[3]: "
                          "128 envs = 16 per GPU on 8 GPUs)")
-    ap.add_argument("--exchange", choices=["allgather", "none"], default="allgather")
+    ap.add_argument("--exchange", choices=["allgather", "peercopy", "none"], default="allgather",
+                    help="allgather: RCCL all_gather_into_tensor on a side stream; peercopy: every rank copies its slab into the "
+                         "peers' buffers over xGMI (HIP IPC mappings, SDMA / blit path: no CUs taken from the kernels), RCCL "
+                         "only for the 4-byte completion barrier; none: no exchange (DD-PPO: each rank consumes its own slab)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="steps per all-gather: the learner consumes rollouts, so per-rank slabs are exchanged in chunks of "
                          "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); the per-step "
@@ -283,10 +288,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the conv-only / spectral-bank / 2-stream side measurements")
-    ap.add_argument("--spectral", action="store_true", help="headline loop on the spectral RIR bank (k_conv_spec) instead of "
-                                                           "the time-domain bank")
+    ap.add_argument("--rir-bank", choices=["spectral", "time"], default="spectral",
+                    help="format of the HBM-resident RIR bank the headline loop reads: 'spectral' = block spectra computed "
+                         "once at bank load (ss_rir_spectra_f32; SoundSpaces 1.0 RIRs are static files), no forward FFT per "
+                         "step, 2x the bytes per RIR; 'time' = the reference's time-domain samples.  The other format is "
+                         "timed in the same run and reported beside it (16 kHz)")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
     args = ap.parse_args()
+    args.spectral = args.rir_bank == "spectral" and args.sr <= 16384      # 44.1 kHz rows: time-domain kernels
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -308,7 +317,7 @@ def main():
     import torch.distributed as dist
     from oracle import ss_oracle as O
     from ss_amd import planning as P
-    from ss_amd.dist import ChunkedSlabExchange
+    from ss_amd.dist import ChunkedSlabExchange, PeerCopyExchange
     from ss_amd.renderer import BatchedAudioRenderer, RirBank
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
@@ -349,7 +358,10 @@ def main():
         Per-step event records put a marker packet between consecutive launches (measured: +2-3 us per step), so the
         headline loop records only the two ends and the distribution comes from a separate pass."""
         r.rirs.spectra = spectra if spectral else None
-        cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev) if (world > 1 and gather_every > 0) else None
+        cx = None
+        if world > 1 and gather_every > 0:
+            cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev,
+                                     exchange_cls=PeerCopyExchange if args.exchange == "peercopy" else None)
         ex = cx.exchange if cx is not None else None
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
         sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
@@ -419,8 +431,9 @@ def main():
     if (args.spectral or not args.no_secondary) and fused:
         r.rirs.build_spectra()
         spectra = r.rirs.spectra
-    S_auto = args.streams if args.streams > 0 else (2 if (world > 1 and args.exchange == "allgather") else 1)
-    G_head = args.gather_every if (world > 1 and args.exchange == "allgather") else 0
+    exchanging = world > 1 and args.exchange != "none"
+    S_auto = args.streams if args.streams > 0 else (2 if exchanging else 1)
+    G_head = args.gather_every if exchanging else 0
     elapsed, per_step, exchange_note = run_loop(S_auto, G_head, args.spectral)
     side = {}
     step_dist = None
@@ -428,7 +441,7 @@ def main():
         _, ps, _ = run_loop(1, 0, args.spectral, per_step_events=True)
         step_dist = dist_of(ps)
         step_dist["note"] = "separate pass with one HIP event record per step (the records themselves add 2-3 us per step)"
-    if world > 1 and args.exchange == "allgather" and not args.no_secondary:
+    if exchanging and not args.no_secondary:
         e1, _, _ = run_loop(S_auto, 1, args.spectral)             # per-step gather, same run
         side["exchange_per_step_gather"] = {"value": round(world * N * args.steps / e1, 1), "ms_per_step": round(1e3 * e1 / args.steps, 5)}
         e0, _, _ = run_loop(S_auto, 0, args.spectral)             # no collective (the reference's DD-PPO arrangement)
@@ -480,8 +493,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
                        "sampling_rate": sr, "rir_len": L, "rir_bank": "spectral" if args.spectral else "time-domain",
-                       "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps")
-                                                      if (world > 1 and args.exchange == "allgather") else "none")),
+                       "actual_bytes_per_unit": ((2 * 2 * L * 4 if args.spectral else 2 * L * 4) + 65 * t4 * 2 * 4) if fused else None,
+                       "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
                        "streams": S_auto, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
@@ -513,7 +526,9 @@ def main():
         if world == 1 and not args.no_plugin_path and fused and rot == 1:
             srcs = [r.sources._host[i] for i in range(len(r.sources))]
             out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, n_env, bank, args.sounds, srcs,
-                                                     min(args.steps, 400), min(args.warmup, 50))
+                                                     min(args.steps, 400), min(args.warmup, 50),
+                                                     spectra if args.spectral else None)
+            out["plugin_path"]["rir_bank"] = "spectral" if args.spectral else "time-domain"
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)

@@ -1370,44 +1370,67 @@ __global__ __launch_bounds__(1024) void k_conv_rows(ConvParams p, int n_rows) {
 // k_intensity: av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on the audiogoal:
 //   thr = 0.1 * max(x);  onset = min over ears of the first index with x > thr (0 if none);
 //   out = mean( x[:, onset : onset+num_frame] ** 2 )      (mean over the samples that exist)
-// One 256-thread workgroup per unit; two block reductions (max, then min index) and one sum.
+// One 256-thread workgroup per unit; block reductions (max, min index per ear, sum) = wave butterflies + 4 partials.
 struct IntensityParams {
     const float* x;    // [N][2][len]
     float* out;        // [N]
     int len, num_frame;
 };
 
+// value of `v` held by lane (lane ^ mask) of the same wave
+__device__ __forceinline__ float lane_xor(float v, int lane, int mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __shfl_xor(v, mask, 64);
+#elif defined(SSK_HOSTSIM)
+    return hostsim_lane_read(v, lane ^ mask);
+#else
+    return v;
+#endif
+}
+// wave-level butterfly reductions (6 exchange steps, every lane ends with the result); OP in {0 max, 1 min, 2 sum}
+template <int OP>
+__device__ __forceinline__ float wave_reduce(float v, int lane) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float o = lane_xor(v, lane, m);
+        v = OP == 0 ? fmaxf(v, o) : OP == 1 ? fminf(v, o) : v + o;
+    }
+    return v;
+}
+// block reduction for 256 threads = 4 waves: one wave-level reduction + 4 partials through LDS (two barriers instead of
+// the eight of a shared-memory tree)
+template <int OP>
+__device__ __forceinline__ float block_reduce256(float v, int t, float* part) {
+    v = wave_reduce<OP>(v, t & 63);
+    __syncthreads();                       // `part` may still be read from the previous reduction
+    if ((t & 63) == 0) part[t >> 6] = v;
+    __syncthreads();
+    const float a = part[0], b = part[1], c = part[2], d = part[3];
+    return OP == 0 ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : OP == 1 ? fminf(fminf(a, b), fminf(c, d)) : (a + b) + (c + d);
+}
+
 __global__ __launch_bounds__(256) void k_intensity(IntensityParams p) {
-    __shared__ float red[256];
-    __shared__ int redi[256];
+    __shared__ float part[4];
     const int t = threadIdx.x;
     const float* x = p.x + (size_t)blockIdx.x * 2 * p.len;
     float m = -3.402823466e38f;
     for (int i = t; i < 2 * p.len; i += 256) m = fmaxf(m, x[i]);
-    red[t] = m;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] = fmaxf(red[t], red[t + s]); __syncthreads(); }
-    const float thr = 0.1f * red[0];
-    __syncthreads();
-    int first[2] = {p.len, p.len};                       // first index above the threshold, per ear
-    for (int c = 0; c < 2; ++c)
-        for (int i = t; i < p.len; i += 256)
-            if (x[c * p.len + i] > thr) { first[c] = i; break; }
+    const float thr = 0.1f * block_reduce256<0>(m, t, part);
+    int first[2];                                        // first index above the threshold, per ear (len = none)
     for (int c = 0; c < 2; ++c) {
-        redi[t] = first[c];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (t < s) redi[t] = min(redi[t], redi[t + s]); __syncthreads(); }
-        first[c] = redi[0] == p.len ? 0 : redi[0];       // np.argmax of an all-False row is 0
-        __syncthreads();
+        int f = p.len;
+        for (int i = t; i < p.len; i += 256)
+            if (x[c * p.len + i] > thr) { f = i; break; }
+        // indices < 2^24 are exact in float: the min reduction runs on the same float butterfly
+        const int g = (int)block_reduce256<1>((float)f, t, part);
+        first[c] = g == p.len ? 0 : g;                   // np.argmax of an all-False row is 0
     }
     const int onset = min(first[0], first[1]);
     const int n = min(p.num_frame, p.len - onset);
     float acc = 0.f;
     for (int i = t; i < 2 * n; i += 256) { const float v = x[(i / n) * p.len + onset + (i % n)]; acc += v * v; }
-    red[t] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
-    if (t == 0) p.out[blockIdx.x] = n > 0 ? red[0] / (2.f * n) : 0.f;
+    const float tot = block_reduce256<2>(acc, t, part);
+    if (t == 0) p.out[blockIdx.x] = n > 0 ? tot / (2.f * n) : 0.f;
 }
 
 }  // namespace ssk

@@ -137,3 +137,66 @@ class ChunkedSlabExchange:
         if self._n:
             self._gather(streams)
         self.exchange.wait(streams)
+
+
+class PeerCopyExchange(SlabExchange):
+    """Same interface as ``SlabExchange``, different transport: every rank WRITES its slab straight into the other
+    ranks' gathered buffers with device-to-device copies over xGMI (peer memory mapped through HIP IPC), and only the
+    completion barrier is a collective.
+
+    Why: RCCL's all-gather runs as kernels that need CUs with ~20 KB of LDS and ~270 registers per thread; they can
+    never share a CU with a ``k_conv`` workgroup (148 KB of LDS, all of the register file), so while a gather is in
+    flight a 256-row launch finds fewer than 256 free CUs.  Peer copies are executed by the
+    SDMA engines / blit path: no CUs, no LDS.  The slabs are small (1.7 MB per rank and step at 128 envs), every GPU
+    has a direct xGMI link to every other one, so each rank issues world-1 independent copies, one per link.
+
+    Set-up (once): each rank exports the IPC handle of its ``full`` buffers (``torch`` shares CUDA/HIP storages with
+    ``_share_cuda_``; the dmabuf IPC mode needs ``HSA_ENABLE_IPC_MODE_LEGACY=0``, already exported on these boxes) through
+    ``all_gather_object`` on the process group, and opens its peers'.  Per gather: wait for the producer streams, copy
+    the local slab into slot ``rank`` of EVERY rank's buffer on the side stream, then a 4-byte all-reduce on that stream
+    as the completion barrier (with the ``gloo`` control plane used in the single-GPU test: stream sync + host barrier)."""
+
+    def __init__(self, slab_shape, dtype=torch.float32, device="cuda", group: Optional[dist.ProcessGroup] = None,
+                 depth: int = 2):
+        super().__init__(slab_shape, dtype=dtype, device=device, group=group, depth=depth)
+        assert self._cuda, "peer copies need device memory"
+        self._peers = [[None] * self.world for _ in range(depth)]     # [buffer][rank] -> that rank's `full` tensor
+        if self.world > 1:
+            from torch.multiprocessing.reductions import rebuild_cuda_tensor, reduce_tensor
+            for i in range(depth):
+                fn, args = reduce_tensor(self.full[i])                # IPC handle + metadata (picklable)
+                assert fn is rebuild_cuda_tensor
+                handles = [None] * self.world
+                dist.all_gather_object(handles, args, group=self.group)
+                for r in range(self.world):
+                    if r == self.rank:
+                        self._peers[i][r] = self.full[i]
+                    else:
+                        # storage_device in the handle is the EXPORTING rank's device index: every process of the node sees
+                        # all GPUs under the same numbering (one process per GPU, no *_VISIBLE_DEVICES masking)
+                        self._peers[i][r] = rebuild_cuda_tensor(*handles[r])   # maps the peer's allocation into this process
+        else:
+            for i in range(depth):
+                self._peers[i][0] = self.full[i]
+        self._flag = torch.zeros((1,), dtype=torch.float32, device=self.device)
+        self._device_barrier = self.world > 1 and dist.get_backend(self.group) == "nccl"
+
+    def gather(self, streams=None) -> torch.Tensor:
+        i = self._k % self.depth
+        self._k += 1
+        n = self.slab_shape[0]
+        for st in self._producers(streams):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            for r in range(self.world):                               # one copy per peer link (and the local one)
+                self._peers[i][r][self.rank * n:(self.rank + 1) * n].copy_(self.local[i], non_blocking=True)
+            if self.world > 1:
+                if self._device_barrier:
+                    dist.all_reduce(self._flag, group=self.group)     # every rank's copies are ordered before it
+                else:
+                    self.stream.synchronize()
+                    dist.barrier(group=self.group)
+            self.ready[i].record(self.stream)
+        return self.full[i]

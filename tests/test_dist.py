@@ -121,3 +121,55 @@ def test_bench_exchange_flow_two_ranks_gloo(gather_every, steps):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _peer_worker(rank, world, port, q):
+    """Two processes sharing ONE GPU (the test box has one): peer memory through HIP IPC, gloo as the control plane."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ss_amd.dist import ChunkedSlabExchange, PeerCopyExchange
+        seen = []
+        cx = ChunkedSlabExchange(4, (65, 26, 2), 3, device="cuda:0", exchange_cls=PeerCopyExchange,
+                                 gathered=lambda full, n: seen.append((full, n)))
+        ok = True
+        for k in range(7):
+            rows = cx.step_rows()
+            rows.fill_(float(1000 * rank + k))
+            cx.step_done()
+            if seen:
+                full, n_steps = seen.pop()
+                cx.exchange.wait()
+                torch.cuda.synchronize()
+                for r in range(world):
+                    blk = full[r * 12:(r + 1) * 12]
+                    for i in range(n_steps):
+                        ok &= bool((blk[i * 4:(i + 1) * 4] == 1000 * r + (k - n_steps + 1) + i).all())
+                dist.barrier()                    # nobody refills a buffer a peer is still checking
+        cx.flush()
+        torch.cuda.synchronize()
+        full, n_steps = seen.pop()
+        for r in range(world):
+            ok &= bool((full[r * 12:r * 12 + 4] == 1000 * r + 6).all()) and n_steps == 1
+        q.put((rank, bool(ok)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_peer_copy_exchange_two_processes_one_gpu():
+    """the peer-write exchange behind the SlabExchange interface (device-to-device copies into the
+    peers' buffers through HIP IPC instead of RCCL kernels), exercised with two processes on the one GPU of the box."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
