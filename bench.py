@@ -295,7 +295,7 @@ def main():
                          "timed in the same run and reported beside it (16 kHz)")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
     args = ap.parse_args()
-    args.spectral = args.rir_bank == "spectral" and args.sr <= 16384      # 44.1 kHz rows: time-domain kernels
+    args.spectral = args.rir_bank == "spectral"
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -428,7 +428,7 @@ def main():
         return elapsed, per_step, note
 
     spectra = None
-    if (args.spectral or not args.no_secondary) and fused:
+    if args.spectral or not args.no_secondary:
         r.rirs.build_spectra()
         spectra = r.rirs.spectra
     exchanging = world > 1 and args.exchange != "none"
@@ -446,7 +446,7 @@ def main():
         side["exchange_per_step_gather"] = {"value": round(world * N * args.steps / e1, 1), "ms_per_step": round(1e3 * e1 / args.steps, 5)}
         e0, _, _ = run_loop(S_auto, 0, args.spectral)             # no collective (the reference's DD-PPO arrangement)
         side["exchange_none"] = {"value": round(world * N * args.steps / e0, 1), "ms_per_step": round(1e3 * e0 / args.steps, 5)}
-    if world == 1 and not args.no_secondary and fused:
+    if world == 1 and not args.no_secondary:
         e2, _, _ = run_loop(2, 0, args.spectral)                  # consecutive steps on two streams
         side["two_streams"] = {"value": round(N * args.steps / e2, 1), "ms_per_step": round(1e3 * e2 / args.steps, 5)}
         eo, ps_o, _ = run_loop(1, 0, not args.spectral)           # the other RIR bank format
@@ -476,7 +476,8 @@ def main():
     if rank == 0:
         kernel_ms = float(np.mean(per_step)) if per_step else 1e3 * elapsed / args.steps
         b = bytes_per_unit(sr, L, t4)
-        kname = ("k_conv_spec<FUSE=true>" if args.spectral else "k_conv<FUSE=true>") if fused else "k_conv<FUSE=false>+k_spectrogram"
+        kk = "k_conv_spec" if args.spectral else "k_conv"
+        kname = f"{kk}<FUSE=true>" if fused else f"{kk}<FUSE=false>+k_spectrogram"
         bpu = b["fused"] if fused else b["conv"] + b["spec"]
         ach = bpu * N / (kernel_ms * 1e-3) / 1e9
         workload = (f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, 1-s source clips ({args.sounds} sounds), "
@@ -493,7 +494,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
                        "sampling_rate": sr, "rir_len": L, "rir_bank": "spectral" if args.spectral else "time-domain",
-                       "actual_bytes_per_unit": ((2 * 2 * L * 4 if args.spectral else 2 * L * 4) + 65 * t4 * 2 * 4) if fused else None,
+                       "actual_bytes_per_unit": ((2 * P.ceil_div(L, P.KB) * P.SPEC_FLOATS * 4 if args.spectral else 2 * L * 4)
+                                                 + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)),
                        "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
                        "streams": S_auto, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

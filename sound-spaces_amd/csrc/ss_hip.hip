@@ -57,8 +57,9 @@ inline int n_frames_of(int len) { return 1 + len / ssk::kHop; }
 inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kPool; }
 
 template <bool FUSE>
-int launch_conv(const ssk::ConvParams& p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
+int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
+    p.nb_y = nb_y;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && !(flags & SS_FLAG_CROSSFADE) && nb_y == 1 && p.rir_cap <= ssk::kB;
     if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
     const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
@@ -335,10 +336,11 @@ int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long l
 }  // extern "C"
 
 template <bool FUSE>
-static int launch_conv_spec(const ssk::ConvParams& p, int n_units, int nb_y, int flags, hipStream_t st) {
+static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1) || (flags & SS_FLAG_CROSSFADE)) return SS_EINVAL;
+    p.nb_y = nb_y;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1;
-    const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
+    const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
     if (simple) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());

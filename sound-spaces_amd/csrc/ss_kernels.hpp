@@ -794,7 +794,7 @@ struct ConvParams {
     int rir_chan_stride;         // floats between ears      (planar [R,2,L]: L ; wav [R,L,2]: 1)
     int rir_elem_stride;         // floats between samples   (planar: 1 ; wav: 2)
     int rir_cap;                 // samples readable per (entry, ear); rows are ZERO beyond rir_len[r] up to rir_cap
-    int n_valid;                 // samples computed per row (<= gridDim.y*kB); [n_valid, out_len) is zero-filled
+    int n_valid;                 // samples computed per row (<= nb_y*kB); [n_valid, out_len) is zero-filled
     int out_len;                 // row length
     int n_frames, t4, pad_mode;  // spectrogram geometry for the fused path
     int fade_len;                // XFADE kernels: cross-fade ramp covers samples 0..fade_len (continuous_simulator.py:47-53)
@@ -803,6 +803,7 @@ struct ConvParams {
     const f32x4* hspec;
     int h_blocks;
     int xcd_map;                 // != 0: launch slots are dealt to the XCDs in contiguous ranges (row_slot)
+    int nb_y;                    // output blocks per row; k_conv_spec: grid = 2N * nb_y, slot = (row, j), j fastest
     int dbg;                     // timing experiments only (scripts/gpu_ladder.sh): early exit point, 0 = full kernel
 };
 
@@ -988,7 +989,7 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     }
 }
 
-// SIMPLE: the caller guarantees one output block (gridDim.y == 1), RIR capacity <= kB and no distractor term,
+// SIMPLE: the caller guarantees one output block (nb_y == 1), RIR capacity <= kB and no distractor term,
 // so a unit is at most ONE forward FFT: straight-line code, no accumulator carried across passes, no scratch.
 // XFADE (SoundSpaces 2.0 CROSSFADE, continuous_simulator.py:47-53, 422-424): term 1 of the descriptor is not a
 // distractor to be added but the PREVIOUS step's RIR: the row is convolved with it first, the first fade_len+1 samples
@@ -1000,6 +1001,8 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
+    // grid (2N rows, nb_y output blocks).  (Putting the blocks of a row next to each other in slot order, as k_conv_spec
+    // does, was measured 10 % SLOWER here at 44.1 kHz: 91 vs 82 us per 128 units.)
     const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
     const int unit = slot >> 1, ch = slot & 1, j = SIMPLE ? 0 : blockIdx.y;
     const int* d = p.desc + 8 * unit;
@@ -1179,8 +1182,14 @@ template <bool FUSE, bool SIMPLE>
 __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
+    // 1-D grid of 2N * nb_y workgroups.  With several output blocks per row (44.1 kHz: 3) the blocks of one row sit NEXT
+    // to each other in slot order, i.e. on one XCD at about the same time, so the block spectra H'_i that block j re-reads
+    // after block j-1 (i <= j: 6 block reads per row, 3 distinct) come out of that XCD's L2 instead of HBM
+    // (44.1 kHz, 128 units: 77.7 -> 67.8 us).
     const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
-    const int unit = slot >> 1, ch = slot & 1, j = SIMPLE ? 0 : blockIdx.y;
+    // (the division of two uniform values is done on the vector unit: bring the quotient back to a scalar register)
+    const int row = SIMPLE ? slot : __builtin_amdgcn_readfirstlane(slot / p.nb_y), j = SIMPLE ? 0 : slot - row * p.nb_y;
+    const int unit = row >> 1, ch = row & 1;
     const int* d = p.desc + 8 * unit;
     __shared__ float s_win[FUSE ? kNfft : 1];
     __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];

@@ -149,10 +149,11 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
         }
         return 0;
     }
+    p.nb_y = nb_y;
     gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
-    for (int j = 0; j < nb_y; ++j)
-        for (int b = 0; b < 2 * n_units; ++b) {
-            blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
+    for (int b = 0; b < 2 * n_units * nb_y; ++b) {
+        {
+            blockIdx = dim3{(unsigned)(b % (2 * n_units)), (unsigned)(b / (2 * n_units)), 0};
             int rc = run_block(ssk::kT, [&] {
                 if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
                 else if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
@@ -160,6 +161,7 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
             });
             if (rc) return rc;
         }
+    }
     return 0;
 }
 
@@ -205,16 +207,18 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
-    gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
-    for (int j = 0; j < nb_y; ++j)
-        for (int b = 0; b < 2 * n_units; ++b) {
-            blockIdx = dim3{(unsigned)b, (unsigned)j, 0};
+    p.nb_y = nb_y;
+    gridDim = dim3{(unsigned)(2 * n_units * nb_y), 1, 1};
+    for (int b = 0; b < 2 * n_units * nb_y; ++b) {
+        {
+            blockIdx = dim3{(unsigned)b, 0, 0};
             int rc = run_block(ssk::kT, [&] {
                 if (fuse) { if (simple) ssk::k_conv_spec<true, true>(p); else ssk::k_conv_spec<true, false>(p); }
                 else { if (simple) ssk::k_conv_spec<false, true>(p); else ssk::k_conv_spec<false, false>(p); }
             });
             if (rc) return rc;
         }
+    }
     return 0;
 }
 
