@@ -294,6 +294,10 @@ def main():
                          "step, 2x the bytes per RIR; 'time' = the reference's time-domain samples.  The other format is "
                          "timed in the same run and reported beside it (16 kHz)")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
+    ap.add_argument("--workload", choices=["audiogoal", "savi"], default="audiogoal",
+                    help="audiogoal: the headline shape (1-s clips, no distractor).  savi: BASELINE configs[4] (semantic_audionav): "
+                         "21 sounds of 1-20 s (all windowing branches of simulator.py:629-647), a distractor on every env "
+                         "(two convolutions + add), audiogoal AND spectrogram written; use with --envs 256")
     args = ap.parse_args()
     args.spectral = args.rir_bank == "spectral"
 
@@ -337,8 +341,16 @@ def main():
     R = max(64, (args.bank_mib << 20) // (2 * L * 4))
     R -= R % 4                                               # whole azimuth groups
     r = BatchedAudioRenderer(sr, device=dev)
-    for i, clip in enumerate(O.synth_sources(rng, sr, k=args.sounds)):
-        r.add_source(f"sound{i}", clip)
+    savi = args.workload == "savi"
+    if savi:
+        args.sounds = 21
+        secs = [1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20]
+        for i, sec in enumerate(secs):
+            r.add_source(f"sound{i}", O.synth_sources(rng, sr, k=1, seconds=sec)[0])
+        args.with_audiogoal = True
+    else:
+        for i, clip in enumerate(O.synth_sources(rng, sr, k=args.sounds)):
+            r.add_source(f"sound{i}", clip)
     bank = synth_rir_bank_device(torch, R, sr, L, dev, seed=7 + rank)
     r.set_rir_bank(RirBank(bank, torch.full((R,), L, dtype=torch.int32, device=dev)))
     total = args.warmup + args.steps
@@ -346,8 +358,18 @@ def main():
 
     def draw_rir():                                          # rotations > 1: first row of an azimuth group of `rot` rows
         return rng.integers(0, R // rot, n_env) * rot if rot > 1 else rng.integers(0, R, n_env)
-    descs = [r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
-             for _ in range(total)]
+    if savi:
+        from ss_amd.renderer import UnitRequest
+
+        def savi_units():
+            snd = rng.integers(0, 21, n_env)
+            idx = np.array([rng.integers(0, secs[s]) for s in snd])
+            return [UnitRequest(int(s), 0 if secs[s] == 1 else int(i) * sr, int(h), dis_sound=int(d), dis_rir=int(hd))
+                    for s, i, h, d, hd in zip(snd, idx, rng.integers(0, R, n_env), rng.integers(0, 3, n_env), rng.integers(0, R, n_env))]
+        descs = [r.plan(savi_units()) for _ in range(total)]
+    else:
+        descs = [r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
+                 for _ in range(total)]
     t4 = r.spectrogram_shape[1]
     fused = sr <= P.KB
     want_ag = args.with_audiogoal or not fused
@@ -479,8 +501,13 @@ def main():
         kk = "k_conv_spec" if args.spectral else "k_conv"
         kname = f"{kk}<FUSE=true>" if fused else f"{kk}<FUSE=false>+k_spectrogram"
         bpu = b["fused"] if fused else b["conv"] + b["spec"]
+        if savi:
+            bpu = 2 * (2 * L * 4) + 2 * sr * 4 + 65 * t4 * 2 * 4        # two RIRs read, waveform and spectrogram written
         ach = bpu * N / (kernel_ms * 1e-3) / 1e9
-        workload = (f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, 1-s source clips ({args.sounds} sounds), "
+        workload = (("savi semantic_audionav shape: 21 sounds of 1-20 s, a distractor on every env (2 convolutions + add), "
+                     "audiogoal AND spectrogram written; " if savi else "") +
+                    f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, " +
+                    ("" if savi else f"1-s source clips ({args.sounds} sounds), ") +
                     f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident"
                     f"{', stored as block spectra: ' + str(R * 2 * 2 * P.SPEC_FLOATS * 4 >> 20) + ' MiB' if args.spectral else ''}), "
                     "cache-miss path, spectrogram [65,%d,2] f32 out" % t4)
@@ -525,7 +552,7 @@ def main():
                                          "kernel": "k_conv_spec<FUSE=false>" if args.spectral else "k_conv<FUSE=false>",
                                          "bytes_per_unit": b["conv"], "avg_launch_ms": round(cm, 5)}
         out.update(side)
-        if world == 1 and not args.no_plugin_path and fused and rot == 1:
+        if world == 1 and not args.no_plugin_path and fused and rot == 1 and not savi:
             srcs = [r.sources._host[i] for i in range(len(r.sources))]
             out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, n_env, bank, args.sounds, srcs,
                                                      min(args.steps, 400), min(args.warmup, 50),
