@@ -250,8 +250,10 @@ def measured_traffic(units, sr, kernel):
         have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.srchash")).read().strip()
         e = tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
-            return {"bytes": int(e["fetch_bytes"] + e["write_bytes"]), "fetch_bytes": int(e["fetch_bytes"]),
-                    "write_bytes": int(e["write_bytes"]), "note": e.get("note", "")}
+            corr = float(e.get("fetch_correction", 1.0))
+            return {"bytes": int(corr * e["fetch_bytes"] + e["write_bytes"]), "fetch_bytes_raw": int(e["fetch_bytes"]),
+                    "fetch_correction": corr, "write_bytes": int(e["write_bytes"]), "tcc_hit_rate": e.get("tcc_hit_rate"),
+                    "note": e.get("note", "") + "; " + e.get("correction_note", "")}
     except Exception:
         pass
     return None

@@ -1,49 +1,66 @@
 #!/bin/bash
-# Round-2 profile pass: kernel trace (+stats) and PMC passes (separate runs, no tracing domains mixed in) of the bench
-# command, summary + traffic.json (stamped with the kernel-source hash) for profiles/r2/.
-# usage: gpu_profile_r2.sh TAG [extra bench args]
+# Round-2 profile pass (run through gpurun).  For the default bench command (spectral RIR bank) and for --rir-bank time:
+# rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group (separate runs, no tracing domains mixed in).
+# Writes gpurun_out/prof_<TAG>/{summary_*.txt, traffic.json}; copy them to profiles/r2/.
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=${1:-r2}; shift || true
-EXTRA="$*"
+TAG=${1:-r2}
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG"
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-plugin-path --no-secondary --steps 200 $EXTRA"
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- $CMD > "$OUT.bench.json" 2>/dev/null
-i=0
-for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-  i=$((i+1))
-  timeout 600 rocprofv3 --pmc $PMC --output-format csv -d "$OUT" -o pmc$i -- $CMD > /dev/null 2>&1 || echo "pmc pass $i failed"
+mkdir -p "$OUT"
+for BANK in spectral time; do
+  CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-plugin-path --no-secondary --steps 200 --rir-bank $BANK"
+  D="$OUT/$BANK"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o trace -- $CMD > "$D.bench.json" 2>/dev/null )
+  i=0
+  for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+             "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $PMC --output-format csv -d "$D" -o pmc$i -- $CMD > /dev/null 2>&1 ) || echo "pmc pass $i failed"
+  done
+  python scripts/prof_summary.py "$D" > /dev/null 2>&1
+  cp "$D/summary.txt" "$OUT/summary_$BANK.txt"
 done
-cd "$GRAFT_REPO_ROOT"
-python scripts/prof_summary.py "$OUT" > /dev/null 2>&1
-python - "$OUT" "$TAG" <<'PY'
+# secondary shapes: kernel traces only
+for ARGS in "--sr 44100 --rotations 4 --bank-mib 1024 --steps 40 --warmup 5" "--workload savi --envs 256 --steps 100" "--envs 32" "--envs 2048 --steps 40 --warmup 5"; do
+  NAME=$(echo $ARGS | tr -d ' -' | cut -c1-40)
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sec_$NAME" -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-plugin-path $ARGS > "$OUT/sec_$NAME.bench.json" 2>/dev/null )
+  echo "## bench.py $ARGS" >> "$OUT/secondary_kernels.txt"
+  python - "$OUT/sec_$NAME" >> "$OUT/secondary_kernels.txt" <<'PY'
+import csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "ssk::" in row.get("Name", ""):
+            print("   %-64s calls=%s avg=%.2fus min=%.2fus max=%.2fus" % (row["Name"][:64], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
+PY
+done
+python - "$OUT" <<'PY'
 import csv, glob, json, os, sys
 from collections import defaultdict
-d, tag = sys.argv[1], sys.argv[2]
-agg = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "ssk::" in row.get("Kernel_Name", ""):
-            agg[row["Kernel_Name"].split("(")[0]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-bench = json.loads(open(d + ".bench.json").read().strip().splitlines()[-1])
-units, sr = bench["config"]["units_per_gpu"], bench["config"]["sampling_rate"]
+out = sys.argv[1]
+names = {"k_conv_spec<true, true>": "k_conv_spec<FUSE=true>", "k_conv<true, true, false>": "k_conv<FUSE=true>"}
 kernels = {}
-for k, cs in agg.items():
-    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide
-        # (16 B/lane) streaming read -> raw value kept, the x2 rule of MI355X_MICROARCH applied in `fetch_bytes_x2`
-        f_kib = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]); w_kib = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
-        name = k.replace("void ssk::", "").replace("ssk::", "")
-        kernels[name] = {"units_per_launch": units, "sampling_rate": sr, "fetch_bytes": f_kib * 1024, "write_bytes": w_kib * 1024,
-                         "fetch_bytes_x2": 2 * f_kib * 1024,
-                         "note": "per-dispatch means of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE raw "
-                                 "(gfx950 counts 64 B per 128-B request of 16-B/lane streaming loads: see fetch_bytes_x2)"}
+for bank in ("spectral", "time"):
+    d = os.path.join(out, bank)
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "ssk::" in row.get("Kernel_Name", ""):
+                agg[row["Kernel_Name"].split("(")[0].replace("void ssk::", "").replace("ssk::", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    bench = json.loads(open(d + ".bench.json").read().strip().splitlines()[-1])
+    for k, cs in agg.items():
+        if k in names and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            f_kib = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]); w_kib = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+            kernels[names[k]] = {
+                "units_per_launch": bench["config"]["units_per_gpu"], "sampling_rate": bench["config"]["sampling_rate"],
+                "fetch_bytes": f_kib * 1024, "write_bytes": w_kib * 1024,
+                "tcc_hit_rate": round(sum(cs["TCC_HIT_sum"]) / (sum(cs["TCC_HIT_sum"]) + sum(cs["TCC_MISS_sum"])), 3) if "TCC_HIT_sum" in cs else None,
+                "note": "per-dispatch means of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB x 1024; separate passes).  FETCH_SIZE is the raw "
+                        "counter: on gfx950 it tallies 64 B per 128-B request of a wide (16 B/lane) streaming read (MI355X_MICROARCH: x2 for "
+                        "such streams) - the block-spectra / window-spectra loads are 16 B/lane, the time-domain RIR loads 8 B/lane"}
 src_hash = open("sound-spaces_amd/csrc/.libss_hip.srchash").read().strip()
-json.dump({"source_hash": src_hash, "command": "bench.py --no-cpu-baseline --no-plugin-path --no-secondary --steps 200", "kernels_raw": kernels},
-          open(os.path.join(d, "traffic_raw.json"), "w"), indent=1)
-print(json.dumps(kernels, indent=1)[:1500])
+json.dump({"source_hash": src_hash, "command": "bench.py --no-cpu-baseline --no-plugin-path --no-secondary --steps 200 --rir-bank {spectral,time}",
+           "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print(json.dumps(kernels, indent=1))
 PY
-tail -40 "$OUT/summary.txt"
+head -3 "$OUT/summary_spectral.txt" | cut -c1-220; head -3 "$OUT/summary_time.txt" | cut -c1-220; cat "$OUT/secondary_kernels.txt"
