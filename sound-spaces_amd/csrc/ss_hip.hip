@@ -336,10 +336,17 @@ int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long l
 }  // extern "C"
 
 template <bool FUSE>
-static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags, hipStream_t st) {
+static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags, hipStream_t st, int n_cus = 0) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1) || (flags & SS_FLAG_CROSSFADE)) return SS_EINVAL;
     p.nb_y = nb_y;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1;
+    static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
+    if constexpr (!FUSE) {              // more rows than CUs: persistent workgroups prefetching the next row's H'
+        if (simple && !no_rows && n_cus > 0 && n_units > n_cus && !(reinterpret_cast<size_t>(p.hspec) & 15)) {
+            hipLaunchKernelGGL(ssk::k_conv_spec_rows, dim3(n_cus), dim3(ssk::kT), 0, st, p, 2 * n_units);
+            return hip_err(hipGetLastError());
+        }
+    }
     const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
     if (simple) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
@@ -361,7 +368,7 @@ int ss_fftconv_binaural_spec_f32(const float* spec, const float* hspec, const in
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
     p.h_blocks = h_blocks;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
-    return launch_conv_spec<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream));
+    return launch_conv_spec<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream), n_cus);
 }
 
 int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,

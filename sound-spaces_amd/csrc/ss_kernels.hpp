@@ -1376,6 +1376,115 @@ __global__ __launch_bounds__(1024) void k_conv_rows(ConvParams p, int n_rows) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_conv_spec_rows: the loop-free spectral case (AudioGoal only) as a PERSISTENT kernel for launches with more rows than
+// CUs.  k_conv_spec's time line on a CU is: H' streams in (128 KiB at the ~26 GB/s a CU ingests from HBM = 5 us, nothing to
+// compute) -> products + 3 inverse passes (~6 us of instruction issue, no memory traffic) -> stores.  Here the NEXT row's
+// H' is loaded into the 32 registers the products have just freed, so it streams in under the inverse passes; the window
+// spectrum of a row (L2 hits) is loaded at the row's start, and a workgroup takes both ears of a unit back to back, so the
+// second ear finds that spectrum in the L2 it has just been pulled through.
+// Same in-order vmcnt discipline as k_conv_rows: descriptors through the scalar cache, ONE unconditional asm issue site
+// for the prefetch, placed after the row's last compiler-visible load has been waited for, retired before the row's
+// stores are issued (build-time ISA guard: scripts/check_prefetch_regs.py).
+struct SpecRowInfo { int active, slot; const f32x4* hp; };
+
+__device__ __forceinline__ SpecRowInfo spec_row_info(const ConvParams& p, int row) {
+    SpecRowInfo r{0, 0, p.hspec};                              // inactive: a valid address for the dummy prefetch
+    const i32x4 d = uniform_load4(p.desc + 8 * (row >> 1));
+    const int ridx = d.x;
+    if (ridx < 0) return r;
+    const int L = uniform_load(p.rir_len + ridx);
+    if (L > 0 && d.z <= 0 && d.z + d.w > 0) {
+        r.active = 1;
+        r.slot = d.y - d.z;
+        r.hp = p.hspec + ((size_t)ridx * 2 + (row & 1)) * (size_t)p.h_blocks * (kSpecComplex / 2);
+    }
+    return r;
+}
+
+// (item 0's half of H': the whole row, 32 registers in flight under the inverse passes, spilled at the 128-VGPR cap)
+__device__ __forceinline__ void spec_row_issue(const SpecRowInfo& r, int t, f32x4 (&h)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned off = 16u * (unsigned)(t + 1024 * k);
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(h[k]) : "v"(off), "s"(r.hp) : "memory");
+#else
+        h[k] = r.hp[t + 1024 * k];
+#endif
+    }
+}
+
+__device__ __forceinline__ void spec_row_wait(f32x4 (&h)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+#endif
+}
+
+__global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_rows) {
+    __shared__ c32 lds[kLdsComplex];
+    const int t = threadIdx.x;
+    ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    // rows are walked in (unit, ear) pairs: workgroup b takes units b, b + G, ...; row = 2 * unit + ear
+    int unit = blockIdx.x, ear = 0;
+    SpecRowInfo cur = spec_row_info(p, 2 * unit);
+    f32x4 h[4];
+    spec_row_issue(cur, t, h);
+    spec_row_wait(h);
+    SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1);   // see k_conv_rows
+    for (;;) {
+        int tl = t;
+        SSK_OPAQUE1(tl);
+        const int row = 2 * unit + ear;
+        const int n_unit = ear ? unit + (int)gridDim.x : unit, n_ear = ear ^ 1, nxt = 2 * n_unit + n_ear;
+        SpecRowInfo nx{0, 0, p.hspec};
+        if (nxt < n_rows) nx = spec_row_info(p, nxt);
+        // item by item (load -> product -> Hermitian merge + inverse radix-4 -> LDS), so that no 32-register accumulator
+        // is alive next to H' and the window spectrum.  Item 0's half of H' was prefetched; item 1's half and the window
+        // spectrum (L2 hits) are loaded here, item 1's under item 0's arithmetic.
+        c32 v1[8];
+        if (cur.active) {
+            const f32x4* sp = p.spec + (size_t)cur.slot * (kSpecComplex / 2) + tl;
+            f32x4 sv[4], h1[4], sw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv[k] = sp[k * 1024];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { h1[k] = ld_stream(cur.hp + tl + (4 + k) * 1024); sw[k] = sp[(4 + k) * 1024]; }
+            c32 v0[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 hq = h[e >> 1], sq = sv[e >> 1];
+                const c32 hh = (e & 1) ? hq.zw : hq.xy, w = (e & 1) ? sq.zw : sq.xy;
+                v0[e] = (e == 0 && tl == 0) ? mk2(hh.x * w.x, hh.y * w.y) : cmul(hh, w);    // (X[0], X[16384]) are real
+            }
+            item_store_inv(lds, tw.i0, tl, v0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x4 hq = h1[e >> 1], sq = sw[e >> 1];
+                v1[e] = cmul((e & 1) ? hq.zw : hq.xy, (e & 1) ? sq.zw : sq.xy);
+            }
+        }
+        // every compiler-visible load of this row has been consumed (item 1's products exist): the prefetch of the next
+        // row's H' goes out now, into registers that are dead until the next iteration.  ONE unconditional issue site.
+        spec_row_issue(nx, tl, h);
+        if (cur.active) item_store_inv(lds, tw.i1, tl + 1024, v1);
+        c32 y[8];
+        if (cur.active) simple_row_inv(lds, tw, tl, y);
+        else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+        }
+        spec_row_wait(h);                                   // retired BEFORE this row's stores are issued (one in-order counter)
+        store_row_block(p, tl, (size_t)row, 0, y);
+        if (nxt >= n_rows) break;
+        unit = n_unit;
+        ear = n_ear;
+        cur = nx;
+        lds_barrier();                                      // every wave is done with the LDS buffer of this row
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_intensity: av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on the audiogoal:
 //   thr = 0.1 * max(x);  onset = min over ears of the first index with x > thr (0 if none);
 //   out = mean( x[:, onset : onset+num_frame] ** 2 )      (mean over the samples that exist)

@@ -192,7 +192,7 @@ int hs_rir_spectra(const float* rir, float* hspec, int n_entries, long long us, 
 }
 
 int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, const int* rir_len, const int* desc,
-                 float* out, float* sgram, int n_units, int h_blocks, int n_valid, int out_len, int pad_mode) {
+                 float* out, float* sgram, int n_units, int h_blocks, int n_valid, int out_len, int pad_mode, int persist) {
     ssk::ConvParams p;
     p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = nullptr; p.rir_len = rir_len; p.desc = desc;
     p.out = out; p.sgram = sgram; p.tb = host_tables();
@@ -208,6 +208,16 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
     p.nb_y = nb_y;
+    if (persist > 0) {                                  // k_conv_spec_rows: `persist` workgroups walk the units
+        if (fuse || !simple) return -3;
+        gridDim = dim3{(unsigned)persist, 1, 1};
+        for (int b = 0; b < persist && b < n_units; ++b) {
+            blockIdx = dim3{(unsigned)b, 0, 0};
+            int rc = run_block(ssk::kT, [&] { ssk::k_conv_spec_rows(p, 2 * n_units); });
+            if (rc) return rc;
+        }
+        return 0;
+    }
     gridDim = dim3{(unsigned)(2 * n_units * nb_y), 1, 1};
     for (int b = 0; b < 2 * n_units * nb_y; ++b) {
         {

@@ -95,7 +95,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         assert rc == 0, rc
         rc = L.hs_conv_spec(int(fuse), simple, _p(spec, ctypes.c_float), _p(hspec, ctypes.c_float), _p(rl, ctypes.c_int),
                             _p(desc, ctypes.c_int), _p(out, ctypes.c_float), _p(sg, ctypes.c_float) if fuse else None,
-                            N, hb, n_valid, out_len, pad_mode)
+                            N, hb, n_valid, out_len, pad_mode, persist)
         assert rc == 0, rc
         if want_spectrogram and not fuse:
             rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)

@@ -411,6 +411,33 @@ def test_spectral_rir_bank_vs_oracle_and_time_domain_bank(sr, n_units, ragged):
         check(sg[n], cache[key][1])
 
 
+def test_persistent_spectral_row_kernel_large_batch():
+    """More units than CUs, AudioGoal only, spectral bank: k_conv_spec_rows (persistent workgroups, both ears of a unit back
+    to back, next row's H' prefetched) against one workgroup per row (the fused kernel's audiogoal) and the oracle."""
+    from ss_amd.renderer import UnitRequest
+    sr, n_units = 16000, 700
+    src, rirs, sel_s, sel_r = _random_batch(sr, n_units, 5, 16, seed=13, ragged=True)
+    rirs = list(rirs) + [None]
+    r = make_renderer(sr, list(src), rirs)
+    r.rirs.build_spectra()
+    units = [UnitRequest(int(s_), 0, (len(rirs) - 1) if n % 41 == 7 else int(h_), silent=(n % 37 == 5))
+             for n, (s_, h_) in enumerate(zip(sel_s, sel_r))]
+    plan = r.plan(units)
+    ag = r.render_audiogoal(plan)                                   # k_conv_spec_rows (700 units > 256 CUs)
+    ag_f, _ = r.render(plan, want_audiogoal=True)                   # k_conv_spec<FUSE>: one workgroup per row
+    assert float((ag - ag_f).abs().max()) <= 2e-6 * float(ag_f.abs().max())
+    ag = ag.cpu().numpy()
+    cache = {}
+    for n, u in enumerate(units):
+        if u.silent or u.rir == len(rirs) - 1:
+            assert not ag[n].any()
+            continue
+        key = (u.sound, u.rir)
+        if key not in cache:
+            cache[key] = O.compute_audiogoal(src[u.sound], rirs[u.rir], sr)
+        check(ag[n], cache[key])
+
+
 def test_spectral_store_keeps_spectra_in_step_with_the_rows():
     """AudioEngine(rir_spectral=True): rows loaded on demand (misses, LRU eviction, bank growth for a 1.5-s RIR with a
     multi-second clip) get their block spectra at the next observe(); every result against the oracle."""

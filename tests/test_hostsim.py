@@ -206,6 +206,27 @@ def test_spectral_rir_bank_equals_time_domain_bank(name):
         assert np.abs(a_u[0] - a_s[0]).max() <= 2e-6 * np.abs(a_t).max()
 
 
+@pytest.mark.parametrize("wgs", [1, 2, 64])
+def test_persistent_spectral_row_kernel_equals_one_workgroup_per_row(wgs):
+    """k_conv_spec_rows: `wgs` workgroups walk the units (both ears back to back, next row's H' prefetched); silent units
+    and empty RIRs in the middle of a walk, ragged RIRs, a 0.25-s step."""
+    rng = np.random.default_rng(17)
+    sr = 16000
+    srcs = O.synth_sources(rng, sr, k=2)
+    bank = np.zeros((4, 2, sr), np.float32)
+    lens = [sr, 5000, 0, 12345]
+    for i, L in enumerate(lens):
+        if L:
+            bank[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
+    units = [dict(sound=0, t0=0, rir=0), dict(rir=-1), dict(sound=1, t0=0, rir=1), dict(sound=0, t0=0, rir=2),
+             dict(sound=1, t0=0, rir=3), dict(sound=0, t0=0, rir=1), dict(rir=-1)]
+    for n_valid in (sr, 4000):
+        a_ref, _ = hs.run(srcs, bank, lens, units, n_valid, sr, spectral=True)
+        a, _ = hs.run(srcs, bank, lens, units, n_valid, sr, spectral=True, persist=wgs)
+        np.testing.assert_array_equal(a, a_ref)
+        assert not a[1].any() and not a[3].any() and a[4].any()
+
+
 def test_44k_three_output_blocks_three_rir_blocks():
     d = case_inputs("clip1s_44k")
     sr = d["sr"]
