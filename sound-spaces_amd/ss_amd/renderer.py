@@ -136,9 +136,15 @@ class Plan:
 
 class BatchedAudioRenderer:
     def __init__(self, sampling_rate: int, device="cuda", pad_mode: str = "reflect",
-                 step_time: Optional[float] = None, wrap: bool = False, spec_capacity: int = 64):
+                 step_time: Optional[float] = None, wrap: bool = False, spec_capacity: int = 64,
+                 max_window_slots: int = 2048):
         """step_time None -> SoundSpaces 1.0 semantics (1-s observations).  step_time = 0.25 with wrap=True ->
-        SoundSpaces 2.0 (_convolve_with_rir): int(sr*step_time) samples computed, zero-padded to 1 s."""
+        SoundSpaces 2.0 (_convolve_with_rir): int(sr*step_time) samples computed, zero-padded to 1 s.
+        max_window_slots bounds the cache of source-window spectra (128 KiB of HBM each): SS1.0 keys (sound, index*sr)
+        are a small fixed set, but SS2.0 draws a new sample index per env and step, so the cache is emptied at the start
+        of the plan() that finds it over the bound (plans made before that call must have been rendered: they are by
+        every caller in this package, which plans and renders a step at a time; pre-planned batches share their keys)."""
+        self.max_window_slots = int(max_window_slots)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ops._lib.SsHipError("BatchedAudioRenderer needs an MI355X (device='cuda'); there is no CPU path")
@@ -171,6 +177,9 @@ class BatchedAudioRenderer:
 
     # ---- planning --------------------------------------------------------------------------------------
     def _ensure_windows(self, keys) -> None:
+        if self._n_slots > self.max_window_slots:       # bounded: start over, this step's keys are recomputed
+            self._windows.clear()
+            self._n_slots = 0
         new = [k for k in dict.fromkeys(keys) if k not in self._windows]
         if not new:
             return

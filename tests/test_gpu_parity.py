@@ -164,6 +164,22 @@ def test_continuous_adapter_episode_on_gpu():
     assert eng.store.misses == 2                          # two live slots for the env, refreshed in place afterwards
 
 
+def test_window_cache_of_the_python_renderer_is_bounded():
+    """SS2.0 draws a new sample index per env and step; the renderer's window cache used to grow for ever."""
+    from ss_amd.renderer import UnitRequest
+    sr = 16000
+    rng = np.random.default_rng(2)
+    src3 = O.tile_short_source(O.synth_sources(rng, sr, k=1)[0], sr)
+    rir = np.ascontiguousarray(O.synth_rir(rng, sr, length=9000, n=1)[0].T)
+    r = make_renderer(sr, [src3], [rir], step_time=0.25, wrap=True, max_window_slots=64)
+    for step in range(40):
+        units = [UnitRequest(0, int((7919 * (4 * step + e)) % (3 * sr)), 0) for e in range(4)]
+        ag = r.render_audiogoal(r.plan(units))
+        assert r._n_slots <= 64 + 2 * 4 * 2
+    ref = O.convolve_with_rir(src3, rir, sr, units[0].t0, 0.25)
+    check(ag[0].cpu().numpy(), ref)
+
+
 def test_long_rir_multisecond_clip_through_the_engine_store():
     """RirStore used to cut RIRs at `cap` = sr, wrong for multi-second sounds (simulator.py:641-647 convolves
     with the full RIR).  A 1.5-s RIR with a 5-s clip driven through AudioEngine / attach() / the sensors against the
