@@ -169,3 +169,32 @@ def test_context_api_from_a_c_program_on_gpu(tmp_path):
         ref_a, ref_s, stride = case_outputs(name)
         assert O.relerr(ag[n][:, ::stride], ref_a) <= 1e-4 and O.relerr(sg[n], ref_s) <= 1e-4
     assert not ag[2].any() and not sg[2].any()
+
+
+@pytest.mark.gpu
+def test_integration_md_context_stub_runs_as_written():
+    """The reference-side ctypes binding printed in INTEGRATION.md section 2a, executed verbatim (extracted from the
+    document) against the built library, checked against the oracle."""
+    import numpy as np
+    import torch
+    from oracle import ss_oracle as O
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("# soundspaces/_ss_hip.py  (reference-side binding)"):]
+    block = block[:block.index("```")]
+    block = block.replace('ctypes.CDLL("libss_hip.so")', f'ctypes.CDLL("{_lib.SO_PATH}")')
+    sr = 16000
+    rng = np.random.default_rng(0)
+    clips = {f"s{i}": c for i, c in enumerate(O.synth_sources(rng, sr, k=2))}
+    rirs = O.synth_rir(rng, sr, n=3)                                   # planar [3, 2, sr]
+    bank = torch.from_numpy(rirs).to("cuda:0")
+    ns = {"sr": sr, "source_sound_dict": clips, "bank": bank, "cap": sr,
+          "bank_len": torch.full((3,), sr, dtype=torch.int32, device="cuda:0")}
+    exec(block, ns)
+    sg = torch.empty((3, 65, 26, 2), device="cuda:0")
+    ns["observe"]([0, 1, 0], [0, 0, 0], [2, 0, -1], sg)
+    torch.cuda.synchronize()
+    sg = sg.cpu().numpy()
+    for n, (s, h) in enumerate(((0, 2), (1, 0))):
+        a = O.compute_audiogoal(clips[f"s{s}"], np.ascontiguousarray(rirs[h].T), sr)
+        assert O.relerr(sg[n], O.compute_spectrogram(a)) <= 1e-4
+    assert not sg[2].any()
