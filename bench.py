@@ -212,7 +212,8 @@ def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, ste
                 host_us.append(1e6 * (time.perf_counter() - t0))
 
     out = {}
-    for name, move_sims in (("columns", False), ("bound_sims", True)):
+    for name, move_sims, native in (("columns", False, True), ("columns_numpy_host", False, False), ("bound_sims", True, True)):
+        obs.native = native
         run(0, warmup, move_sims)
         torch.cuda.synchronize()
         host_us = []
@@ -225,10 +226,11 @@ def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, ste
                      "observe_into_host_us": {"median": round(float(np.median(h)), 2),
                                               "p10": round(float(h[len(h) // 10]), 2),
                                               "p90": round(float(h[(9 * len(h)) // 10]), 2)}}
-    out["note"] = ("simulator state -> columns -> RIR table lookup -> ss_ctx_observe (C++ planner + window cache + pinned "
-                   "descriptor ring) -> spectrograms written into rollouts.observations['spectrogram'][step+1]; planning "
-                   "and descriptor upload inside the timed region.  'columns': agent motion applied to the state columns "
-                   "(vectorised env); 'bound_sims': motion applied through attribute writes on %d Python simulator objects "
+    out["note"] = ("simulator state columns -> ss_ctx_observe_sims (C++: silence / clip window / azimuth / RIR table lookup, "
+                   "planner + window cache + pinned descriptor ring, launch) -> spectrograms written into "
+                   "rollouts.observations['spectrogram'][step+1]; planning and descriptor upload inside the timed region.  "
+                   "'columns': agent motion applied to the state columns (vectorised env); 'columns_numpy_host': the same "
+                   "with the state -> unit columns step in numpy (ss_ctx_observe); 'bound_sims': motion applied through attribute writes on %d Python simulator objects "
                    "bound to the columns (their Python loop is the simulators' cost, not the audio path's)" % n_envs)
     out["cache"] = ctx.stats()
     return out

@@ -183,6 +183,36 @@ int ss_ctx_set_rir_spectra(ss_ctx* ctx, const float* hspec, int h_blocks);
 /* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
  * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
 int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);
+/* One step straight from the simulators' state, struct-of-arrays (ss_amd/vector.py::VectorSimState: the int64 columns a
+ * vector env keeps per env; HOST memory, n entries each).  Does, for all envs at once, what SoundSpacesSim does per env:
+ *   silent = step_count > duration (simulator.py:610) or sound < 0;   t0 = clip is 1 s ? 0 : audio_index * sr (:629-634);
+ *   audio_index = (audio_index + 1) % (clip_len / sr) for multi-second clips that are not silent (:635; written back);
+ *   azimuth = -rot mod 360 (:573);   RIR slot = index[scene][recv][src] + azimuth / (360 / azimuths)  (the pair's azimuths
+ *   sit in adjacent bank rows; table entry -1 = pair not resident);   distractor likewise from dis_sound / dis_src.
+ * If some non-silent env's pair is not resident nothing is launched and nothing advanced: their env indices go to
+ * miss_out (capacity n), *n_miss > 0 and the call returns 0 - load the pairs, fix the table, call again. */
+typedef struct ss_sim_columns {
+    const long long* sound;          /* sound id per env, -1 = unknown                     */
+    long long* audio_index;          /* in / out                                           */
+    const long long* step_count;
+    const long long* duration;
+    const long long* recv;
+    const long long* src;
+    const long long* rot;            /* _rotation_angle, degrees                           */
+    const long long* scene;          /* scene id = index into index_off / index_dim        */
+    const long long* dis_sound;      /* optional (HAS_DISTRACTOR_SOUND): both or neither   */
+    const long long* dis_src;
+    const int* index_flat;           /* concatenated [dim x dim] tables, first slot or -1  */
+    const long long* index_off;      /* [n_scenes] offset of a scene's table in index_flat */
+    const long long* index_dim;      /* [n_scenes] nodes per scene                         */
+    int n_scenes;
+    int azimuths;                    /* bank rows per (receiver, source) pair, e.g. 4      */
+} ss_sim_columns;
+int ss_ctx_observe_sims(ss_ctx* ctx, const ss_sim_columns* cols, int n, float* audiogoal, float* spectrogram,
+                        int* miss_out, int* n_miss, void* stream);
+/* The state -> unit columns step of ss_ctx_observe_sims alone (host only, needs no GPU; advances audio_index the same
+ * way): units_out int32 [5, n] = sound, t0, rir, dis_sound, dis_rir. */
+int ss_ctx_sims_units(ss_ctx* ctx, const ss_sim_columns* cols, int n, int* units_out, int* miss_out, int* n_miss);
 /* The planner alone (host only, needs no GPU): unit_desc_out int32 [n,8] as ss_fftconv_binaural_f32 takes them,
  * *flags_out the SS_FLAG_* of the launch, *n_new_windows_out the source windows whose spectra would be computed,
  * new_windows_out (optional, int32 [cap,5]) = {src_offset, src_len, start, wrap, pool slot} of those windows. */

@@ -57,7 +57,11 @@ for bank in ("spectral", "time"):
                 "tcc_hit_rate": round(sum(cs["TCC_HIT_sum"]) / (sum(cs["TCC_HIT_sum"]) + sum(cs["TCC_MISS_sum"])), 3) if "TCC_HIT_sum" in cs else None,
                 "note": "per-dispatch means of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB x 1024; separate passes).  FETCH_SIZE is the raw "
                         "counter: on gfx950 it tallies 64 B per 128-B request of a wide (16 B/lane) streaming read (MI355X_MICROARCH: x2 for "
-                        "such streams) - the block-spectra / window-spectra loads are 16 B/lane, the time-domain RIR loads 8 B/lane"}
+                        "such streams) - the block-spectra / window-spectra loads are 16 B/lane, the time-domain RIR loads 8 B/lane",
+                "fetch_correction": 2.0 if bank == "spectral" else 1.0,
+                "correction_note": ("every global load of this kernel is a 16-B/lane stream (block spectra H', window spectra S'): "
+                                    "MI355X_MICROARCH's x2 rule applies to FETCH_SIZE") if bank == "spectral" else
+                                   "mixed widths (RIR rows 8 B/lane, window spectra 16 B/lane): FETCH_SIZE left raw (uncalibrated for 8-B/lane loads)"}
 src_hash = open("sound-spaces_amd/csrc/.libss_hip.srchash").read().strip()
 json.dump({"source_hash": src_hash, "command": "bench.py --no-cpu-baseline --no-plugin-path --no-secondary --steps 200 --rir-bank {spectral,time}",
            "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -91,6 +91,7 @@ struct Context {
     bool ev_made = false;
     float* ag_scratch = nullptr;                  // hand-over buffer for rows longer than one block (44.1 kHz) when the
     size_t ag_cap = 0;                            // caller does not want the audiogoal itself
+    std::vector<int> sim_scratch;                 // ss_ctx_observe_sims: unit columns of the step
     // scratch of the last plan
     std::vector<int> new_win;                     // 5 ints per new window
 };

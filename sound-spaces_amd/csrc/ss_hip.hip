@@ -665,4 +665,85 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     return hip_err(e);
 }
 
+
+}  // extern "C"
+static int sims_to_units(ss_ctx* h, const ss_sim_columns* sc, int n, int* w, int* miss_out, int* n_miss);
+extern "C" {
+
+// One step from the simulators' state columns (see include/ss_hip.h): the per-step numpy of ss_amd/vector.py in C++.
+int ss_ctx_sims_units(ss_ctx* h, const ss_sim_columns* sc, int n, int* units_out, int* miss_out, int* n_miss) {
+    if (!units_out) return SS_EINVAL;
+    return sims_to_units(h, sc, n, units_out, miss_out, n_miss);
+}
+
+int ss_ctx_observe_sims(ss_ctx* h, const ss_sim_columns* sc, int n, float* audiogoal, float* spectrogram, int* miss_out,
+                        int* n_miss, void* stream) {
+    if (!h || n < 0) return SS_EINVAL;
+    std::vector<int>& w = h->c.sim_scratch;
+    w.resize(static_cast<size_t>(n) * 5 + 1);
+    const int rc = sims_to_units(h, sc, n, w.data(), miss_out, n_miss);
+    if (rc != 0 || n == 0 || *n_miss) return rc;
+    ss_units u;
+    std::memset(&u, 0, sizeof u);
+    u.sound = w.data(); u.t0 = u.sound + n; u.rir = u.t0 + n;
+    if (sc->dis_sound) { u.dis_sound = u.rir + n; u.dis_rir = u.dis_sound + n; }
+    return ss_ctx_observe(h, &u, n, audiogoal, spectrogram, stream);
+}
+
+}  // extern "C"
+
+static int sims_to_units(ss_ctx* h, const ss_sim_columns* sc, int n, int* w, int* miss_out, int* n_miss) {
+    if (!h || !sc || n < 0 || !n_miss || !sc->sound || !sc->audio_index || !sc->step_count || !sc->duration || !sc->recv ||
+        !sc->src || !sc->rot || !sc->scene || !sc->index_flat || !sc->index_off || !sc->index_dim || sc->azimuths < 1 ||
+        360 % sc->azimuths || (!sc->dis_sound != !sc->dis_src))
+        return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    *n_miss = 0;
+    if (n == 0) return 0;
+    const bool dis = sc->dis_sound != nullptr;
+    const int n_src = static_cast<int>(c.src_len.size()), step = 360 / sc->azimuths;
+    int* sound = w; int* t0 = sound + n; int* rir = t0 + n; int* dsound = rir + n; int* drir = dsound + n;
+    auto lookup = [&](int i, long long node_src) -> int {
+        const long long scn = sc->scene[i];
+        if (scn < 0 || scn >= sc->n_scenes) return -1;
+        const long long dim = sc->index_dim[scn], r = sc->recv[i];
+        if (r < 0 || r >= dim || node_src < 0 || node_src >= dim) return -1;
+        const int base = sc->index_flat[sc->index_off[scn] + r * dim + node_src];
+        if (base < 0) return -1;
+        long long az = (-sc->rot[i]) % 360;
+        if (az < 0) az += 360;
+        return base + static_cast<int>(az / step);
+    };
+    int misses = 0;
+    for (int i = 0; i < n; ++i) {                              // pass 1: everything except the audio_index advance
+        const long long s = sc->sound[i];
+        const bool silent = s < 0 || s >= n_src || sc->step_count[i] > sc->duration[i];
+        sound[i] = silent ? 0 : static_cast<int>(s);
+        dsound[i] = 0; drir[i] = -1;
+        if (silent) { rir[i] = -1; t0[i] = 0; continue; }
+        const int len = c.src_len[sound[i]];
+        t0[i] = len == c.sr ? 0 : static_cast<int>(sc->audio_index[i]) * c.sr;
+        rir[i] = lookup(i, sc->src[i]);
+        bool miss = rir[i] < 0;
+        if (dis) {
+            const long long ds = sc->dis_sound[i];
+            if (ds >= 0 && ds < n_src) {
+                dsound[i] = static_cast<int>(ds);
+                drir[i] = lookup(i, sc->dis_src[i]);
+                miss = miss || drir[i] < 0;
+            }
+        }
+        if (miss && miss_out && misses < n) miss_out[misses] = i;
+        misses += miss;
+    }
+    if (misses) { *n_miss = misses; return 0; }
+    for (int i = 0; i < n; ++i) {                              // pass 2: simulator.py:634-635
+        if (rir[i] < 0) continue;
+        const int len = c.src_len[sound[i]];
+        if (len != c.sr && len >= c.sr) sc->audio_index[i] = (sc->audio_index[i] + 1) % (len / c.sr);
+    }
+    return 0;
+}
+
+extern "C" {
 }  // extern "C"

@@ -12,7 +12,15 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_fftconv_binaural_f32", "ss_spectrogram_f32", "ss_audio_obs_f32", "ss_intensity_f32", "ss_logmel_f32", "ss_gccphat_f32",
            "ss_ctx_create", "ss_ctx_destroy", "ss_ctx_add_source", "ss_ctx_add_source_len", "ss_ctx_set_rir_bank",
            "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
-           "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32")
+           "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
+           "ss_ctx_sims_units")
+
+
+class SsSimColumns(ctypes.Structure):
+    """struct ss_sim_columns of include/ss_hip.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("sound", "audio_index", "step_count", "duration", "recv", "src", "rot", "scene",
+                                              "dis_sound", "dis_src", "index_flat", "index_off", "index_dim")] + \
+               [("n_scenes", ctypes.c_int), ("azimuths", ctypes.c_int)]
 
 
 class SsUnits(ctypes.Structure):
@@ -57,6 +65,8 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp]
     lib.ss_ctx_plan.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, vp, vp, c_int]
     lib.ss_ctx_stats.argtypes = [vp, vp]
+    lib.ss_ctx_observe_sims.argtypes = [vp, ctypes.POINTER(SsSimColumns), c_int, vp, vp, vp, vp, vp]
+    lib.ss_ctx_sims_units.argtypes = [vp, ctypes.POINTER(SsSimColumns), c_int, vp, vp, vp]
     lib.ss_ctx_set_rir_spectra.argtypes = [vp, vp, c_int]
     lib.ss_rir_spectra_f32.argtypes = [vp, vp, c_int, c_ll, c_int, c_int, vp]
     lib.ss_fftconv_binaural_spec_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]

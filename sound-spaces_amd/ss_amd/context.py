@@ -147,6 +147,60 @@ class AudioContext:
         with torch.cuda.device(dev):
             _lib.check(self.lib.ss_ctx_observe(self._h, ctypes.byref(u), n, ag, sg, stream), "ss_ctx_observe")
 
+    def bind_sims(self, state, index, has_distractor: bool = False):
+        """Pointers to the int64 state columns (``ss_amd.vector.VectorSimState``) and the RIR index tables, for
+        ``observe_sims``: built once, rebuilt by the caller when the index tables are rebuilt (``index.version``)."""
+        flat, off, dim = index.tables()
+        c = _lib.SsSimColumns()
+        for name, arr in (("sound", state.sound), ("audio_index", state.audio_index), ("step_count", state.step_count),
+                          ("duration", state.duration), ("recv", state.recv), ("src", state.src), ("rot", state.rot),
+                          ("scene", state.scene)):
+            assert arr.dtype == np.int64 and arr.flags.c_contiguous
+            setattr(c, name, arr.ctypes.data)
+        if has_distractor:
+            c.dis_sound, c.dis_src = state.dis_sound.ctypes.data, state.dis_src.ctypes.data
+        c.index_flat, c.index_off, c.index_dim = flat.ctypes.data, off.ctypes.data, dim.ctypes.data
+        c.n_scenes, c.azimuths = int(dim.shape[0]), int(index.azimuths)
+        n = int(state.sound.shape[0])
+        return dict(cols=c, n=n, keep=(state, flat, off, dim), miss=np.zeros((max(n, 1),), np.int32), n_miss=ctypes.c_int(0))
+
+    def sims_units(self, bound):
+        """Host only: the unit columns ``observe_sims`` would render (and the same audio_index advance) -> (dict of
+        int32 columns, missing env indices)."""
+        n = bound["n"]
+        out = np.zeros((5, max(n, 1)), np.int32)
+        _lib.check(self.lib.ss_ctx_sims_units(self._h, ctypes.byref(bound["cols"]), n, out.ctypes.data,
+                                              bound["miss"].ctypes.data, ctypes.addressof(bound["n_miss"])), "ss_ctx_sims_units")
+        cols = dict(zip(("sound", "t0", "rir", "dis_sound", "dis_rir"), out[:, :n]))
+        return cols, bound["miss"][:min(bound["n_miss"].value, n)].copy()
+
+    def observe_sims(self, bound, spectrogram_out=None, audiogoal_out=None, stream: Optional[int] = None) -> np.ndarray:
+        """One step straight from the bound state columns (ss_ctx_observe_sims: the whole per-step host work in C++).
+        Returns the env indices whose RIR pair is not resident (then nothing was launched or advanced), else empty."""
+        import torch
+        sg = ag = None
+        dev = None
+        if spectrogram_out is not None:
+            sg, dev = spectrogram_out.data_ptr(), spectrogram_out.device
+        if audiogoal_out is not None:
+            ag, dev = audiogoal_out.data_ptr(), audiogoal_out.device
+        if dev is None:
+            raise ValueError("observe_sims: pass spectrogram_out and / or audiogoal_out")
+        if bound.get("dev") != dev:                    # shapes / dtypes checked once per (bound, device)
+            n = bound["n"]
+            for t, shape in ((spectrogram_out, (n,) + self.spectrogram_shape), (audiogoal_out, (n, 2, self.sr))):
+                if t is not None:
+                    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape
+            bound["dev"] = dev
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.ss_ctx_observe_sims(self._h, ctypes.byref(bound["cols"]), bound["n"], ag, sg,
+                                                    bound["miss"].ctypes.data, ctypes.addressof(bound["n_miss"]), stream),
+                       "ss_ctx_observe_sims")
+        k = bound["n_miss"].value
+        return bound["miss"][:min(k, bound["n"])]
+
     def plan(self, sound, t0, rir, dis_sound=None, dis_rir=None, last_rir=None, wrap=None, last_wrap=None):
         """The planner alone (host only): -> (unit descriptors int32 [n,8], launch flags, new windows int32 [w,5])."""
         u, n, keep = self._units(sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap)

@@ -150,6 +150,7 @@ class RirIndex:
         self._off = np.zeros((0,), np.int64)
         self._dim = np.zeros((0,), np.int64)
         self._stale = False
+        self.version = 0                                       # bumps whenever the flat tables are re-allocated
 
     def add_scene(self, name: str, n_nodes: int) -> int:
         if name in self._names:
@@ -164,13 +165,25 @@ class RirIndex:
 
     def set(self, scene: int, recv, src, base) -> None:
         self._tables[scene][recv, src] = base
-        self._stale = True
+        if self._stale:
+            return
+        try:                                                   # keep the flat copy (and pointers into it) current
+            self._flat[self._off[scene]:self._off[scene] + self._dim[scene] ** 2].reshape(self._dim[scene], -1)[recv, src] = base
+        except (IndexError, ValueError):
+            self._stale = True
+
+    def tables(self):
+        """(flat int32, offsets int64, dims int64) of all scenes; stable until ``version`` changes."""
+        if self._stale:
+            self._rebuild()
+        return self._flat, self._off, self._dim
 
     def _rebuild(self) -> None:
         self._dim = np.array([t.shape[0] for t in self._tables], np.int64)
         self._off = np.concatenate([[0], np.cumsum(self._dim * self._dim)[:-1]]).astype(np.int64)
         self._flat = np.concatenate([t.reshape(-1) for t in self._tables]) if self._tables else np.zeros((0,), np.int32)
         self._stale = False
+        self.version += 1
 
     def lookup(self, scene: np.ndarray, recv: np.ndarray, src: np.ndarray, azimuth: np.ndarray) -> np.ndarray:
         """Vectorised: bank slot per env (base + azimuth // (360 / azimuths)), -1 where the pair is not resident."""
@@ -228,12 +241,14 @@ class FastVectorAudioObserver:
     """One launch per vector step, state read from columns (module docstring)."""
 
     def __init__(self, ctx, state: VectorSimState, index: RirIndex, sampling_rate: int, has_distractor: bool = False,
-                 miss: Optional[Callable[[int, int, int, int], int]] = None):
+                 miss: Optional[Callable[[int, int, int, int], int]] = None, native: bool = True):
         """ctx: ss_amd.context.AudioContext with its RIR bank set; miss(env, recv, src, azimuth) -> slot is called for
-        envs whose pair is not in the index (loads it; default: raise)."""
+        envs whose pair is not in the index (loads it AND enters it into the index; default: raise)."""
         self.ctx, self.state, self.index, self.sr = ctx, state, index, int(sampling_rate)
         self.has_distractor = has_distractor
         self.miss = miss
+        self.native = native and hasattr(ctx, "observe_sims")
+        self._bound, self._bound_version = None, -1
         self._clip_len = np.zeros((0,), np.int64)
 
     def _lengths(self) -> np.ndarray:
@@ -269,7 +284,31 @@ class FastVectorAudioObserver:
         return cols
 
     def observe(self, spectrogram_out=None, audiogoal_out=None) -> None:
-        self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns())
+        """Native path (default): the per-step host work runs inside libss_hip.so (``ss_ctx_observe_sims``) on pointers
+        to the state columns; ``native=False`` keeps the numpy formulation of ``columns()`` (same results, tested)."""
+        if not self.native:
+            self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns())
+            return
+        st = self.state
+        if st.dirty.any():
+            st.resolve_sounds(self.ctx.add_source)
+        for _ in range(2):
+            self.index.tables()                                                                      # rebuild if stale
+            if self._bound is None or self._bound_version != self.index.version:
+                self._bound = self.ctx.bind_sims(st, self.index, self.has_distractor)
+                self._bound_version = self.index.version
+            missing = self.ctx.observe_sims(self._bound, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+            if missing.shape[0] == 0:
+                return
+            if self.miss is None:
+                raise KeyError(f"RIR pairs of envs {missing.tolist()} are not resident and no miss loader was given")
+            az = (-st.rot) % 360
+            for i in missing:                               # load the pairs (the loader puts them into the index)
+                i = int(i)
+                self.miss(i, int(st.recv[i]), int(st.src[i]), int(az[i]))
+                if self.has_distractor and st.dis_sound[i] >= 0:
+                    self.miss(i, int(st.recv[i]), int(st.dis_src[i]), int(az[i]))
+        raise KeyError("RIR pairs still missing after the miss loader ran (it must enter them into the RirIndex)")
 
     def observe_into(self, rollouts):
         """Render this vector step straight into the rollout rows the next ``rollouts.insert()`` fills

@@ -658,9 +658,11 @@ def test_audiogoal_batcher_savi_semantics():
     assert idx.min() >= 0 and idx.max() <= len(d0["source"]) // sr - 2          # random.randint(0, n - 2), inclusive
 
 
-def test_fast_vector_observer_on_gpu():
+@pytest.mark.parametrize("native", [True, False])
+def test_fast_vector_observer_on_gpu(native):
     """Column-based observer (ss_amd/vector.py) on the real context + store: bound stand-in simulators, RIR groups of 4
-    azimuths in adjacent bank rows, spectral bank on and off; against the per-env oracle."""
+    azimuths in adjacent bank rows, spectral bank on and off; against the per-env oracle.  native: the per-step host work
+    in C++ (ss_ctx_observe_sims) or in numpy (columns() + ss_ctx_observe)."""
     from fakes import FakeSim
     from ss_amd.context import AudioContext
     from ss_amd.renderer import RirStore
@@ -686,7 +688,8 @@ def test_fast_vector_observer_on_gpu():
     state = VectorSimState(n)
     for i, sim in enumerate(sims):
         state.bind(sim, i)
-    obs = FastVectorAudioObserver(ctx, state, index, sr)
+    obs = FastVectorAudioObserver(ctx, state, index, sr, native=native)
+    assert obs.native == native
     sg = torch.empty((n, 65, 26, 2), device=DEV)
     ag = torch.empty((n, 2, sr), device=DEV)
     for step in range(4):

@@ -146,3 +146,70 @@ def test_bound_simulator_keeps_working_as_an_object():
     a._current_sound = "snd2"
     assert st.dirty[0] and not st.dirty[1] and a._audio_length == 3 and type(a).__name__ == "SsBoundFakeSim"
     assert isinstance(a, FakeSim)
+
+
+@pytest.mark.parametrize("has_distractor", [False, True])
+def test_native_state_to_units_equals_numpy_columns(has_distractor):
+    """ss_ctx_sims_units (the C++ per-step host work behind FastVectorAudioObserver's native path) against the numpy
+    formulation ``columns()`` on random vector steps: same unit columns, same _audio_index afterwards, and the miss
+    protocol (pair not resident -> env indices reported, nothing advanced)."""
+    from ss_amd.context import AudioContext
+    n = 24
+    rng = np.random.default_rng(3)
+    lengths = [SR, 3 * SR, SR, 5 * SR + 123]
+    index = RirIndex(4)
+    dims = (7, 5)
+    for k, d in enumerate(dims):
+        sid = index.add_scene(f"s{k}", d)
+        for r in range(d):
+            for s in range(d):
+                if (r, s) != (2, 3):                                                # one pair never resident
+                    index.set(sid, r, s, 4 * (100 * k + r * d + s))
+
+    def make():
+        ctx = AudioContext(SR)
+        for k, L in enumerate(lengths):
+            ctx.add_source_len(f"snd{k}", L)
+        st = VectorSimState(n)
+        return ctx, st
+
+    (ctx_a, a), (ctx_b, b) = make(), make()
+    obs = FastVectorAudioObserver(ctx_a, a, index, SR, has_distractor=has_distractor, native=False)
+    bound = ctx_b.bind_sims(b, index, has_distractor)
+    seen_miss = False
+    for step in range(40):
+        for st in (a, b):
+            st.dirty[:] = False
+        cols = dict(scene=rng.integers(0, 2, n), recv=rng.integers(-1, 7, n), src=rng.integers(0, 7, n),
+                    rot=rng.integers(-3, 4, n) * 90, sound=rng.integers(-1, len(lengths), n),
+                    step_count=rng.integers(0, 6, n), duration=rng.integers(2, 6, n),
+                    dis_sound=rng.integers(0, len(lengths), n), dis_src=rng.integers(0, 5, n))
+        if step % 7 == 0:
+            cols["audio_index"] = np.zeros(n, np.int64)
+        ok = (cols["recv"] >= 0) & (cols["recv"] < np.array(dims)[cols["scene"]]) & (cols["src"] < np.array(dims)[cols["scene"]])
+        cols["step_count"] = np.where(ok, cols["step_count"], 99)                   # out-of-table pairs only on silent envs
+        for st in (a, b):
+            for k, v in cols.items():
+                getattr(st, k)[:] = v
+        before = b.audio_index.copy()
+        ref = obs.columns()
+        got, missing = ctx_b.sims_units(bound)
+        silent = ref["rir"] < 0
+        exp_missing = np.flatnonzero(~(a.step_count > a.duration) & (a.sound >= 0) & (
+            (index.lookup(a.scene, a.recv, a.src, (-a.rot) % 360) < 0) |
+            ((ref["dis_rir"] < 0) if has_distractor else False)))
+        if exp_missing.size:
+            seen_miss = True
+            assert missing.tolist() == exp_missing.tolist()
+            assert np.array_equal(b.audio_index, before)                            # nothing advanced
+            a.audio_index[:] = before                                               # (the numpy path has no such protocol)
+            continue
+        assert missing.size == 0
+        assert np.array_equal(got["rir"], ref["rir"])
+        assert np.array_equal(got["t0"][~silent], ref["t0"][~silent])
+        assert np.array_equal(got["sound"][~silent], ref["sound"][~silent])
+        if has_distractor:
+            assert np.array_equal(got["dis_rir"][~silent], ref["dis_rir"][~silent])
+            assert np.array_equal(got["dis_sound"][~silent], ref["dis_sound"][~silent])
+        assert np.array_equal(a.audio_index, b.audio_index)
+    assert seen_miss
