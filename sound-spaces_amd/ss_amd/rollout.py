@@ -69,6 +69,7 @@ class RolloutStorage:
     def __init__(self, num_steps, num_envs, observation_space, action_space, recurrent_hidden_state_size,
                  num_recurrent_layers=1, device=None):
         z = lambda *shape, **kw: torch.zeros(*shape, device=device, **kw)
+        self._row_views = {}
         self.observations = {
             sensor: z(num_steps + 1, num_envs, *space.shape) for sensor, space in observation_space.spaces.items()
         }
@@ -99,7 +100,11 @@ class RolloutStorage:
     def observation_slot(self, sensor: str, step: Optional[int] = None) -> torch.Tensor:
         """The contiguous `[num_envs, ...]` row that the next `insert()` fills for `sensor`
         (`observations[sensor][self.step + 1]`, rollout_storage.py:89-92), or row `step` if given."""
-        return self.observations[sensor][self.step + 1 if step is None else step]
+        t = self.observations[sensor]
+        rows = self._row_views.get(sensor)
+        if rows is None or rows[0] is not t:                 # views of the rows, made once per storage tensor (a tensor
+            rows = self._row_views[sensor] = (t, list(t.unbind(0)))      # index costs microseconds on the per-step path)
+        return rows[1][self.step + 1 if step is None else step]
 
     def next_observation_slots(self, sensors: Optional[Iterable[str]] = None) -> Dict[str, torch.Tensor]:
         return DeviceObservations({s: self.observation_slot(s) for s in (sensors or self.observations)})

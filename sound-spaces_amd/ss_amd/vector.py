@@ -249,6 +249,7 @@ class FastVectorAudioObserver:
         self.miss = miss
         self.native = native and hasattr(ctx, "observe_sims")
         self._bound, self._bound_version = None, -1
+        self._rollouts, self._names = None, []
         self._clip_len = np.zeros((0,), np.int64)
 
     def _lengths(self) -> np.ndarray:
@@ -313,7 +314,8 @@ class FastVectorAudioObserver:
     def observe_into(self, rollouts):
         """Render this vector step straight into the rollout rows the next ``rollouts.insert()`` fills
         (ss_baselines/common/rollout_storage.py:89-92); returns the slots (a ``DeviceObservations``)."""
-        names = [s for s in ("spectrogram", "audiogoal") if s in rollouts.observations]
-        slots = rollouts.next_observation_slots(names)
+        if self._rollouts is not rollouts:
+            self._rollouts, self._names = rollouts, [s for s in ("spectrogram", "audiogoal") if s in rollouts.observations]
+        slots = rollouts.next_observation_slots(self._names)
         self.observe(spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
         return slots
