@@ -22,7 +22,9 @@
 
 namespace ssctx {
 
-constexpr int kRing = 8;          // descriptor ring slots (steps in flight before a slot is reused)
+constexpr int kDirectDescUnits = 256;   // steps up to this size read their descriptors in place from pinned memory
+constexpr int kRing = 16;         // descriptor ring slots (steps in flight before a slot is reused)
+constexpr int kGroup = 4;         // slots released per completion event
 constexpr int kGuardTicks = 8;    // a cache entry used within the last kGuardTicks observe() calls is never evicted
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }   // a >= 0, b > 0
@@ -87,7 +89,10 @@ struct Context {
     int win_cap = 0;
     int* h_win = nullptr;                         // pinned [kRing][win_cap][5]: {src_offset, src_len, start, wrap, pool slot}
     int* d_win = nullptr;
-    hipEvent_t ev_copy[kRing] = {}, ev_done[kRing] = {};
+    hipEvent_t ev_done[kRing / kGroup] = {};      // group g's launches have finished
+    bool group_open = false;                      // a group has been started and its event not yet recorded
+    int open_group = 0;
+    hipStream_t group_stream = nullptr;           // ... on this stream
     bool ev_made = false;
     float* ag_scratch = nullptr;                  // hand-over buffer for rows longer than one block (44.1 kHz) when the
     size_t ag_cap = 0;                            // caller does not want the audiogoal itself

@@ -426,7 +426,7 @@ static void ctx_free_device(ssctx::Context& c) {
     if (c.ag_scratch) (void)hipFree(c.ag_scratch);
     c.ag_scratch = nullptr; c.ag_cap = 0;
     if (c.ev_made)
-        for (int k = 0; k < ssctx::kRing; ++k) { (void)hipEventDestroy(c.ev_copy[k]); (void)hipEventDestroy(c.ev_done[k]); }
+        for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done[k]);
     c.pool = nullptr; c.src_dev = nullptr; c.d_desc = nullptr; c.d_win = nullptr; c.h_desc = nullptr; c.h_win = nullptr;
     c.ev_made = false;
 }
@@ -537,9 +537,7 @@ int ss_ctx_stats(ss_ctx* h, long long* out8) {
 static int ctx_ensure_ring(ssctx::Context& c, int n, int n_win, hipStream_t st) {
     hipError_t e;
     if (!c.ev_made) {
-        for (int k = 0; k < ssctx::kRing; ++k) {
-            e = hipEventCreateWithFlags(&c.ev_copy[k], hipEventDisableTiming);
-            if (e != hipSuccess) return hip_err(e);
+        for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) {
             e = hipEventCreateWithFlags(&c.ev_done[k], hipEventDisableTiming);
             if (e != hipSuccess) return hip_err(e);
         }
@@ -606,14 +604,34 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = ctx_ensure_ring(c, n, 0, st);
     if (rc) return rc;
-    const int k = c.ring_k;
+    // Ring slots are released in GROUPS: one completion event per kGroup consecutive steps (recorded after the group's
+    // last launch, waited for - on the host - before the group's first slot is written again, a full ring later).  An
+    // event record per step puts a marker packet between every two launches (measured: ~2 us of a 26-us step).  A caller
+    // that changes streams inside a group closes it on the old stream and starts the next group.
+    hipError_t e;
+    if (c.group_open && (st != c.group_stream || c.ring_k / ssctx::kGroup != c.open_group)) {
+        e = hipEventRecord(c.ev_done[c.open_group], c.group_stream);     // (also a group a failed step left open)
+        if (e != hipSuccess) return hip_err(e);
+        c.group_open = false;
+        c.ring_k = (c.open_group + 1) * ssctx::kGroup % ssctx::kRing;
+    }
+    const int k = c.ring_k, g = k / ssctx::kGroup;
+    if (k % ssctx::kGroup == 0) {
+        e = hipEventSynchronize(c.ev_done[g]);                 // every launch that read the group's slots has finished
+        if (e != hipSuccess) return hip_err(e);
+        c.group_open = true;
+        c.group_stream = st;
+        c.open_group = g;
+    }
     c.ring_k = (k + 1) % ssctx::kRing;
-    hipError_t e = hipEventSynchronize(c.ev_copy[k]);          // the copy that last read this pinned slot has run
-    if (e != hipSuccess) return hip_err(e);
-    e = hipStreamWaitEvent(st, c.ev_done[k], 0);               // the launch that last read the device slot (any stream)
-    if (e != hipSuccess) return hip_err(e);
+    // Small steps: the kernels read the unit descriptors straight from the pinned ring slot (one 32-byte scalar load per
+    // workgroup over the host link) - an upload between two launches on the stream costs a blit kernel plus a barrier on
+    // either side of it (measured: ~15 us of idle GPU per 25-us step).  Large steps (several descriptors per workgroup,
+    // long kernels) keep the upload.
+    static const bool force_copy = std::getenv("SS_HIP_DESC_COPY") != nullptr;
+    const bool direct = !force_copy && n <= ssctx::kDirectDescUnits;
     int* hd = c.h_desc + static_cast<size_t>(k) * c.ring_cap * 8;
-    int* dd = c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
+    int* dd = direct ? hd : c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
     ssctx::PlanResult res;
     rc = ssctx::plan_units(c, units, n, hd, &res);
     if (rc) return rc;
@@ -630,10 +648,10 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
         rc = launch_windows_scatter(c.src_dev, dw, c.pool, res.n_new_windows, st);
         if (rc) return rc;
     }
-    e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return hip_err(e);
-    e = hipEventRecord(c.ev_copy[k], st);
-    if (e != hipSuccess) return hip_err(e);
+    if (!direct) {
+        e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return hip_err(e);
+    }
     if (spectrogram && !audiogoal && c.out_len > ssk::kB) {    // rows longer than one block hand over through memory
         const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
         if (need > c.ag_cap) {
@@ -661,8 +679,12 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
         rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
                                      c.n_valid, c.out_len, res.flags, stream);
     if (rc) return rc;
-    e = hipEventRecord(c.ev_done[k], st);
-    return hip_err(e);
+    if (k % ssctx::kGroup == ssctx::kGroup - 1) {
+        e = hipEventRecord(c.ev_done[g], st);
+        if (e != hipSuccess) return hip_err(e);
+        c.group_open = false;
+    }
+    return 0;
 }
 
 

@@ -179,6 +179,47 @@ def test_ctx_observe_matches_renderer_and_oracle():
 
 
 @pytest.mark.gpu
+def test_ctx_ring_many_steps_in_flight_and_stream_switches():
+    """The descriptor ring of ss_ctx_observe: 70 steps queued WITHOUT a host sync in between (several ring revolutions;
+    small steps read their descriptors in place from pinned memory, the 300-unit steps upload them), the caller hopping
+    between two streams at irregular points (a group of slots is closed early on a stream switch); every step's output
+    is checked afterwards against the Python-planned renderer."""
+    import torch
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank
+    dev = "cuda:0"
+    rng = np.random.default_rng(21)
+    src = [O.synth_sources(rng, SR, k=1, seconds=s)[0] for s in (1, 1, 3)]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=16)]
+    bank = RirBank.from_arrays(rirs, dev)
+    r = BatchedAudioRenderer(SR, device=dev)
+    ctx = AudioContext(SR, max_window_sets=8)
+    for i, s in enumerate(src):
+        r.add_source(f"s{i}", s)
+        ctx.add_source(f"s{i}", s)
+    r.set_rir_bank(bank)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    steps, outs, which = [], [], 0
+    torch.cuda.synchronize()
+    for k in range(70):
+        n = 300 if k % 9 == 4 else int(rng.integers(1, 40))
+        sound = rng.integers(0, 3, n)
+        t0 = np.array([0 if len(src[s]) == SR else rng.integers(0, 3) * SR for s in sound])
+        rir = rng.integers(-1, 16, n)
+        if k in (2, 3, 11, 29, 30, 31, 50):
+            which ^= 1
+        sg = torch.empty((n, 65, 26, 2), device=dev)
+        with torch.cuda.stream(streams[which]):
+            ctx.observe(sound, t0, rir, spectrogram_out=sg)
+        steps.append((sound, t0, rir))
+        outs.append(sg)
+    torch.cuda.synchronize()
+    for (sound, t0, rir), sg in zip(steps, outs):
+        _, ref = r.render(r.plan_arrays(sound, t0, rir))
+        assert torch.equal(sg, ref)
+
+
+@pytest.mark.gpu
 def test_ctx_observe_distractor_crossfade_and_44k():
     import torch
     from ss_amd.renderer import BatchedAudioRenderer, RirBank, UnitRequest
