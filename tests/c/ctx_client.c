@@ -2,6 +2,7 @@
  * of the reference's audio path would use it.  TEST INFRASTRUCTURE.
  *
  *   ctx_client plan                          host only (no GPU): plans two steps, prints the unit descriptors
+ *   ctx_client sims                          host only: simulator state columns -> unit columns (ss_ctx_sims_units)
  *   ctx_client observe in.bin out.bin        GPU: reads {sr, n_src, src_len[], src..., R, cap, rir_len[], rir[R][2][cap],
  *                                            n, sound[], t0[], rir_idx[]} and writes audiogoal [n][2][sr] + spectrogram
  *                                            [n][65][T4][2]; device memory through the HIP C API.
@@ -44,6 +45,33 @@ static int plan_only(void) {
         long long st[8];
         CHECK(ss_ctx_stats(ctx, st));
         printf("hits %lld misses %lld resident %lld\n", st[0], st[1], st[5]);
+    }
+    CHECK(ss_ctx_destroy(ctx));
+    return 0;
+}
+
+/* A vector env's state columns -> unit columns, as a C host would hand them over each step (host only). */
+static int sims_only(void) {
+    ss_ctx* ctx = NULL;
+    /* 3 envs in one scene of 3 nodes; pair (receiver 1, source 2) sits in bank rows 40..43, (2, 2) in 8..11, rest absent */
+    long long sound[3] = {0, 1, 1}, audio_index[3] = {0, 1, 4}, step_count[3] = {3, 3, 9}, duration[3] = {5, 5, 5};
+    long long recv[3] = {1, 2, 0}, src[3] = {2, 2, 1}, rot[3] = {0, 90, 0}, scene[3] = {0, 0, 0};
+    int index_flat[9] = {-1, -1, -1, -1, -1, 40, -1, -1, 8};
+    long long off[1] = {0}, dim[1] = {3};
+    int units[15], miss[3], n_miss = -1, i, step;
+    ss_sim_columns c;
+    CHECK(ss_ctx_create(&ctx, 16000, 16000, SS_PAD_REFLECT, 0, 8));
+    if (ss_ctx_add_source_len(ctx, 16000) != 0 || ss_ctx_add_source_len(ctx, 80000) != 1) return 11;
+    memset(&c, 0, sizeof c);
+    c.sound = sound; c.audio_index = audio_index; c.step_count = step_count; c.duration = duration;
+    c.recv = recv; c.src = src; c.rot = rot; c.scene = scene;
+    c.index_flat = index_flat; c.index_off = off; c.index_dim = dim; c.n_scenes = 1; c.azimuths = 4;
+    for (step = 0; step < 2; ++step) {
+        CHECK(ss_ctx_sims_units(ctx, &c, 3, units, miss, &n_miss));
+        printf("step %d misses %d\n", step, n_miss);
+        for (i = 0; i < 3; ++i)
+            printf("env %d: sound %d t0 %d rir %d audio_index %lld\n", i, units[i], units[3 + i], units[6 + i], audio_index[i]);
+        recv[2] = 0; src[2] = 0; step_count[2] = 1;      /* env 2 starts a new episode at a pair that is not resident */
     }
     CHECK(ss_ctx_destroy(ctx));
     return 0;
@@ -103,9 +131,10 @@ static int observe(const char* in_path, const char* out_path) {
 
 int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "plan") == 0) return plan_only();
+    if (argc >= 2 && strcmp(argv[1], "sims") == 0) return sims_only();
 #ifdef WITH_HIP
     if (argc >= 4 && strcmp(argv[1], "observe") == 0) return observe(argv[2], argv[3]);
 #endif
-    fprintf(stderr, "usage: ctx_client plan | observe in.bin out.bin\n");
+    fprintf(stderr, "usage: ctx_client plan | sims | observe in.bin out.bin\n");
     return 2;
 }

@@ -131,6 +131,23 @@ def test_context_api_from_a_c_program_planning(tmp_path):
     assert lines[-1] == "hits 2 misses 2 resident 2"
 
 
+def test_sim_state_columns_from_a_c_program(tmp_path):
+    """ss_ctx_sims_units from C: azimuth = -rot mod 360 picks the row inside the pair's group of 4, the multi-second
+    clip's window follows and advances _audio_index (simulator.py:629-635), an env past its duration is silent, and a
+    pair that is not resident is reported without advancing anything."""
+    import subprocess
+    exe = _build_client(tmp_path, with_hip=False)
+    out = subprocess.run([str(exe), "sims"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "step 0 misses 0"
+    assert lines[1] == "env 0: sound 0 t0 0 rir 40 audio_index 0"              # 1-s clip: window 0, index untouched
+    assert lines[2] == "env 1: sound 1 t0 16000 rir 11 audio_index 2"          # rot 90 -> azimuth 270 -> row 8 + 3; 1 -> 2 of 5
+    assert lines[3] == "env 2: sound 0 t0 0 rir -1 audio_index 4"              # step 9 > duration 5: silent
+    assert lines[4] == "step 1 misses 1"                                       # env 2's new pair (0, 0) is not in the table
+    assert lines[6] == "env 1: sound 1 t0 32000 rir 11 audio_index 2"          # window 2 now; nothing advanced on a miss
+
+
 @pytest.mark.gpu
 def test_context_api_from_a_c_program_on_gpu(tmp_path):
     """GPU half: the same C client uploads a bank with the HIP C API, calls ss_ctx_observe once and its outputs match the
