@@ -343,9 +343,7 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
     static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
     if constexpr (!FUSE) {              // more rows than CUs: persistent workgroups prefetching the next row's H'
         if (simple && !no_rows && n_cus > 0 && n_units > n_cus && !(reinterpret_cast<size_t>(p.hspec) & 15)) {
-            static const bool rows2 = getenv("SS_HIP_ROWS2") != nullptr;            // A/B: 512-thread, whole-row prefetch
-            if (rows2) hipLaunchKernelGGL(ssk::k_conv_spec_rows2, dim3(n_cus), dim3(512), 0, st, p, 2 * n_units);
-            else hipLaunchKernelGGL(ssk::k_conv_spec_rows, dim3(n_cus), dim3(ssk::kT), 0, st, p, 2 * n_units);
+            hipLaunchKernelGGL(ssk::k_conv_spec_rows, dim3(n_cus), dim3(ssk::kT), 0, st, p, 2 * n_units);
             return hip_err(hipGetLastError());
         }
     }

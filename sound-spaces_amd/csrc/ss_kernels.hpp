@@ -1485,150 +1485,6 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_conv_spec_rows2: k_conv_spec_rows with the register budget to prefetch a WHOLE row.
-// The 1024-thread kernels give a wave 128 registers, of which the transform passes need ~100: only 16 are left to keep
-// loads in flight under them (half of H'; all of it spilled, profiles/r2/NOTES.md section 6).  Here the same program runs
-// on 512 threads, every thread playing two of the 1024 roles one after the other (t and t + 512: same LDS layouts, same
-// twiddles, same arithmetic, bit-identical results).  The temporaries of a pass exist once per thread instead of once
-// per role, the budget is 256 registers, and the next row's H' AND window spectrum (2 x 2 x 32 registers = 256 KiB per
-// CU) are in flight from the moment the current row's products are done until the next row's products need them.
-// Plain loads: the compiler sees them and places the waits at their first use (top of the next iteration); the stores of
-// the current row are younger than the prefetch and never waited for.
-template <int DA, int DB>
-__device__ __forceinline__ void pass3_inv2_tail(c32* dst_a, c32* dst_b, c32 (&xa)[16], c32 (&xb)[16]) {
-    if (DA) twiddle16_const<true, DA>(xa);
-    fft16<true>(xa);
-    twiddle16_const<true, DB>(xb);
-    fft16<true>(xb);
-    lds_barrier();                       // every layout-B read done before layout-A writes
-#pragma unroll
-    for (int c = 0; c < 16; ++c) lds_st(dst_a + 4 * c, xa[c]);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) lds_st(dst_b + 4 * c, xb[c]);
-}
-// pass 3 inverse for the roles t (d = t >> 8 in {0, 1}) and t + 512 (d + 2)
-__device__ __forceinline__ void pass3_inv2(c32* lds, int t) {
-    const int d = t >> 8, ab = t & 255;
-    const c32* src_a = lds + 4352 * d + 17 * ab;
-    const c32* src_b = src_a + 2 * 4352;
-    c32* dst_a = lds + 65 * ab + d;
-    c32* dst_b = dst_a + 2;
-    c32 xa[16], xb[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) xa[c] = lds_ld(src_a + c);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) xb[c] = lds_ld(src_b + c);
-    const int du = __builtin_amdgcn_readfirstlane(d);
-    if (du == 0) pass3_inv2_tail<0, 2>(dst_a, dst_b, xa, xb);
-    else pass3_inv2_tail<1, 3>(dst_a, dst_b, xa, xb);
-}
-
-__device__ __forceinline__ void spec_products(const f32x4 (&h)[4], const f32x4 (&w)[4], bool first_is_real, c32 (&v)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const f32x4 hq = h[e >> 1], sq = w[e >> 1];
-        const c32 hh = (e & 1) ? hq.zw : hq.xy, ww = (e & 1) ? sq.zw : sq.xy;
-        v[e] = (e == 0 && first_is_real) ? mk2(hh.x * ww.x, hh.y * ww.y) : cmul(hh, ww);    // (X[0], X[16384]) are real
-    }
-}
-
-__global__ __launch_bounds__(512) void k_conv_spec_rows2(ConvParams p, int n_rows) {
-    __shared__ c32 lds[kLdsComplex];
-    __shared__ c32 s_p1[1024];                             // twM[role]: pass 1' base twiddles, read back per row through LDS
-    const int t = threadIdx.x;                             // (a register pair less per role; a spilled pair would be
-    ThreadTw tw0 = load_thread_tw(p.tb.twM, p.tb.twItem, t), tw1 = load_thread_tw(p.tb.twM, p.tb.twItem, t + 512);
-    s_p1[t] = tw0.p1;                                      //  reloaded from scratch = a vector-memory wait inside the
-    s_p1[t + 512] = tw1.p1;                                //  passes, i.e. a wait for the prefetch)
-    int unit = blockIdx.x, ear = 0;
-    SpecRowInfo cur = spec_row_info(p, 2 * unit);
-    // [role][item][slot pair]: role r, item s, pair k sits at f32x4 index (s * 4 + k) * 1024 + t + 512 r of the row.
-    // In flight across the transform passes: all of H' and item 0's half of the window spectrum (96 registers); item 1's
-    // half of the window spectrum (L2 hits) is loaded at the row's start, under item 0's arithmetic.
-    f32x4 h[2][2][4], w0[2][4];
-    {
-        const f32x4* hp = cur.hp + t;
-        const f32x4* sp = p.spec + (size_t)cur.slot * (kSpecComplex / 2) + t;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                h[r][0][k] = ld_stream(hp + k * 1024 + 512 * r);
-                h[r][1][k] = ld_stream(hp + (4 + k) * 1024 + 512 * r);
-                w0[r][k] = sp[k * 1024 + 512 * r];
-            }
-    }
-    // A row's samples are stored one iteration late, right after the NEXT row's products and the prefetch issue: gfx9 has
-    // one in-order counter for loads and stores and the compiler's loop-carried state is "everything of the previous
-    // iteration may be pending", so (a) stores issued at the end of an iteration are waited for at the top of the next
-    // one, right after they were issued, and (b) stores issued in front of the prefetch are waited for before the
-    // prefetch may overwrite its registers (seen in the ISA: vmcnt(0) in both places).
-    c32 y0[8], y1[8];
-    int prow = -1;
-    for (;;) {
-        int tl = t;
-        SSK_OPAQUE1(tl);                                    // keeps LICM from hoisting the body's addresses
-        const int row = 2 * unit + ear;
-        const int n_unit = ear ? unit + (int)gridDim.x : unit, n_ear = ear ^ 1, nxt = 2 * n_unit + n_ear;
-        SpecRowInfo nx{0, 0, p.hspec};
-        if (nxt < n_rows) nx = spec_row_info(p, nxt);
-        if (cur.active && p.dbg != 6) {
-            const f32x4* sp = p.spec + (size_t)cur.slot * (kSpecComplex / 2) + tl;
-            f32x4 w1[2][4];
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) w1[r][k] = sp[(4 + k) * 1024 + 512 * r];
-            c32 v[8];
-            spec_products(h[0][0], w0[0], tl == 0, v);
-            item_store_inv(lds, tw0.i0, tl, v);
-            spec_products(h[1][0], w0[1], false, v);
-            item_store_inv(lds, tw1.i0, tl + 512, v);
-            spec_products(h[0][1], w1[0], false, v);
-            item_store_inv(lds, tw0.i1, tl + 1024, v);
-            spec_products(h[1][1], w1[1], false, v);
-            item_store_inv(lds, tw1.i1, tl + 1536, v);
-        }
-        if (p.dbg != 5) {   // the next row goes out now (an inactive next row reads row 0 of both banks; the values are not used)
-            const f32x4* hp = nx.hp + tl;
-            const f32x4* sp = p.spec + (size_t)nx.slot * (kSpecComplex / 2) + tl;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    h[r][0][k] = ld_stream(hp + k * 1024 + 512 * r);
-                    h[r][1][k] = ld_stream(hp + (4 + k) * 1024 + 512 * r);
-                    w0[r][k] = sp[k * 1024 + 512 * r];
-                }
-        }
-        if (prow >= 0) {                                    // the previous row's samples (see above): younger than the
-            store_row_block(p, tl, (size_t)prow, 0, y0);    // prefetch, and nothing waits on vector memory before the
-            store_row_block(p, tl + 512, (size_t)prow, 0, y1);   // next iteration's products
-        }
-        if (cur.active && p.dbg != 4) {
-            lds_barrier();
-            pass3_inv2(lds, tl);
-            lds_barrier();
-            pass2<true>(lds, tw0.p2, tl);
-            pass2<true>(lds, tw1.p2, tl + 512);
-            lds_barrier();
-            pass1_inv(lds, lds_ld(s_p1 + tl), tl, y0);
-            pass1_inv(lds, lds_ld(s_p1 + tl + 512), tl + 512, y1);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 8; ++a) { y0[a] = mk2(0.f, 0.f); y1[a] = mk2(0.f, 0.f); }
-        }
-        prow = row;
-        if (nxt >= n_rows) break;
-        unit = n_unit;
-        ear = n_ear;
-        cur = nx;
-        lds_barrier();                                      // every wave is done with the LDS buffer of this row
-    }
-    store_row_block(p, t, (size_t)prow, 0, y0);
-    store_row_block(p, t + 512, (size_t)prow, 0, y1);
-}
-
-// ---------------------------------------------------------------------------------------------
 // k_intensity: av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on the audiogoal:
 //   thr = 0.1 * max(x);  onset = min over ears of the first index with x > thr (0 if none);
 //   out = mean( x[:, onset : onset+num_frame] ** 2 )      (mean over the samples that exist)
