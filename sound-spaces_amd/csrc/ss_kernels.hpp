@@ -40,6 +40,22 @@ __device__ __forceinline__ i32x4 uniform_load4(const int* ptr) {   // 4 consecut
 #endif
 }
 
+// both terms of a unit descriptor (8 words) in ONE scalar round trip
+__device__ __forceinline__ void uniform_load8(const int* ptr, i32x4& lo, i32x4& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int a, b, c, d, e, f, g, h;
+    asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x4\n\ts_load_dword %2, %8, 0x8\n\t"
+                 "s_load_dword %3, %8, 0xc\n\ts_load_dword %4, %8, 0x10\n\ts_load_dword %5, %8, 0x14\n\t"
+                 "s_load_dword %6, %8, 0x18\n\ts_load_dword %7, %8, 0x1c\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(f), "=&s"(g), "=&s"(h) : "s"(ptr) : "memory");
+    lo = i32x4{a, b, c, d};
+    hi = i32x4{e, f, g, h};
+#else
+    lo = i32x4{ptr[0], ptr[1], ptr[2], ptr[3]};
+    hi = i32x4{ptr[4], ptr[5], ptr[6], ptr[7]};
+#endif
+}
+
 __device__ __forceinline__ f32x4 mk4(c32 a, c32 b) { f32x4 r; r.xy = a; r.zw = b; return r; }
 
 // Streamed-once global accesses (a RIR row is read by ONE workgroup once per step, an audiogoal row written once):
@@ -1203,22 +1219,29 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
         const i32x4 dw = uniform_load4(d);
         const int ridx = dw.x;
         if (ridx >= 0) {
-            // the H' row needs only the bank index: its loads go out before the length word is waited for
+            // The length word is NOT read here: it would be a third dependent scalar round trip (kernel arguments ->
+            // descriptor -> rir_len[ridx]) in front of the row's loads, and all it could say is "empty RIR" - whose
+            // block spectrum is exactly zero (rows are zero beyond rir_len, H' = FFT of zeros), so the products and
+            // everything after them come out as zeros anyway.
             const f32x4* hp = p.hspec + ((size_t)ridx * 2 + ch) * row_f4 + t;
-            const int L = uniform_load(p.rir_len + ridx);
-            if (L > 0 && dw.z <= 0 && dw.z + dw.w > 0) {
+            if (dw.z <= 0 && dw.z + dw.w > 0) {
                 spec_block_product(p, t, hp, dw.y - dw.z, false, acc);
                 any = true;
             }
         }
     } else {
+        // Scalar round trips in front of the first loads: kernel arguments -> both descriptor terms (one trip).  The
+        // length words are read only when a bank entry has several blocks (to skip the all-zero ones); with one block
+        // per entry all they could say is "empty RIR", whose block spectrum is exactly zero (see the SIMPLE branch).
+        i32x4 dws[2];
+        uniform_load8(d, dws[0], dws[1]);
         for (int term = 0; term < 2; ++term) {
-            const i32x4 dw = uniform_load4(d + 4 * term);
+            const i32x4 dw = dws[term];
             const int ridx = dw.x;
             if (ridx < 0) continue;
-            const int L = uniform_load(p.rir_len + ridx);
             const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
-            const int nbh = min(p.h_blocks, (L + kB - 1) / kB);
+            int nbh = p.h_blocks;
+            if (nbh > 1) nbh = min(nbh, (uniform_load(p.rir_len + ridx) + kB - 1) / kB);
             for (int i = 0; i < nbh; ++i) {
                 const int m = j - i;
                 if (m < m_min || m >= m_min + m_cnt) continue;
@@ -1392,8 +1415,7 @@ __device__ __forceinline__ SpecRowInfo spec_row_info(const ConvParams& p, int ro
     const i32x4 d = uniform_load4(p.desc + 8 * (row >> 1));
     const int ridx = d.x;
     if (ridx < 0) return r;
-    const int L = uniform_load(p.rir_len + ridx);
-    if (L > 0 && d.z <= 0 && d.z + d.w > 0) {
+    if (d.z <= 0 && d.z + d.w > 0) {                          // (an empty RIR's H' is zero: see k_conv_spec)
         r.active = 1;
         r.slot = d.y - d.z;
         r.hp = p.hspec + ((size_t)ridx * 2 + (row & 1)) * (size_t)p.h_blocks * (kSpecComplex / 2);
