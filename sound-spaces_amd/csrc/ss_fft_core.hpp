@@ -29,9 +29,16 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SSK_OPAQUE2(v) asm volatile("" : "+v"(v))
 #define SSK_OPAQUE1(v) asm volatile("" : "+v"(v))
+#define SSK_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)      // nothing is scheduled across this point
+// a wave-uniform value that must already sit in a scalar register HERE: placed in front of the descriptor load it makes
+// the compiler fetch the kernel arguments it names in the kernel's first batch of scalar loads, instead of one more
+// dependent round trip at their first use (the asm blocks of the descriptor loads are barriers for its scheduler)
+#define SSK_HAVE_S(v) asm volatile("" : "+s"(v))
 #else
 #define SSK_OPAQUE2(v) (void)(v)
 #define SSK_OPAQUE1(v) (void)(v)
+#define SSK_SCHED_BARRIER() (void)0
+#define SSK_HAVE_S(v) (void)(v)
 #endif
 
 namespace ssk {

@@ -1174,14 +1174,18 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 // are defined on the time-domain bank, the actual traffic of this kernel is about twice that - reported as such.
 // Same unit descriptors as k_conv (term = {bank entry | -1, first window slot, m_min, count}); rir_len[entry] still
 // says how many blocks of the entry are non-zero.
-__device__ __forceinline__ void spec_block_product(const ConvParams& p, int t, const f32x4* hp, int slot, bool accumulate,
+__device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, const f32x4* hp, int slot, bool accumulate,
                                                    c32 (&acc)[2][8]) {
-    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+    const f32x4* sp = spec + (size_t)slot * (kSpecComplex / 2) + t;
     f32x4 hv[2][4], sv[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) { hv[s][hh] = ld_stream(hp + (s * 4 + hh) * 1024); sv[s][hh] = sp[(s * 4 + hh) * 1024]; }
+    // ALL sixteen loads are issued before the first multiply: left alone, the scheduler starts the first product after
+    // four loads and puts an s_waitcnt vmcnt(2) in front of it (seen in the ISA) - the wave then sits out one full memory
+    // latency with a quarter of its loads in flight before it issues the other twelve
+    SSK_SCHED_BARRIER();
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1202,7 +1206,13 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     // to each other in slot order, i.e. on one XCD at about the same time, so the block spectra H'_i that block j re-reads
     // after block j-1 (i <= j: 6 block reads per row, 3 distinct) come out of that XCD's L2 instead of HBM
     // (44.1 kHz, 128 units: 77.7 -> 67.8 us).
-    const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
+    // every kernel argument the start of the kernel needs, in ONE batch of scalar loads (see SSK_HAVE_S): the chain in
+    // front of the row's first vector loads is then arguments -> descriptor, two round trips
+    int grid = (int)gridDim.x;
+    const f32x4* spec_base = p.spec;
+    const f32x4* hspec_base = p.hspec;
+    SSK_HAVE_S(grid); SSK_HAVE_S(spec_base); SSK_HAVE_S(hspec_base);
+    const int slot = row_slot(blockIdx.x, grid, p.xcd_map);
     // (the division of two uniform values is done on the vector unit: bring the quotient back to a scalar register)
     const int row = SIMPLE ? slot : __builtin_amdgcn_readfirstlane(slot / p.nb_y), j = SIMPLE ? 0 : slot - row * p.nb_y;
     const int unit = row >> 1, ch = row & 1;
@@ -1211,6 +1221,18 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
     c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
     float win_v = 0.f;
+    ThreadTw tw;
+    if (SIMPLE) {
+        // The thread's table entries (L2 hits, independent of the descriptor) go out FIRST: they travel under the scalar
+        // round trips and the row's loads.  Issued after the products (where they are first needed) they were one more
+        // exposed round trip in front of the item stage.
+        tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+        if (FUSE) {                                     // unconditional (clamped) loads: a predicated load would be
+            win_v = p.tb.win[t & (kNfft - 1)];          // merged with the default value by a register move, i.e. waited
+            tw512_v = p.tb.tw512[t & 255];              // for right here; only threads < 512 / < 256 store theirs to LDS
+            wq = p.tb.twM[64 * (t & 15)];
+        }
+    }
     c32 acc[2][8];
     c32 y[8];
     bool any = false;
@@ -1223,9 +1245,9 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
             // descriptor -> rir_len[ridx]) in front of the row's loads, and all it could say is "empty RIR" - whose
             // block spectrum is exactly zero (rows are zero beyond rir_len, H' = FFT of zeros), so the products and
             // everything after them come out as zeros anyway.
-            const f32x4* hp = p.hspec + ((size_t)ridx * 2 + ch) * row_f4 + t;
+            const f32x4* hp = hspec_base + ((size_t)ridx * 2 + ch) * row_f4 + t;
             if (dw.z <= 0 && dw.z + dw.w > 0) {
-                spec_block_product(p, t, hp, dw.y - dw.z, false, acc);
+                spec_block_product(spec_base, t, hp, dw.y - dw.z, false, acc);
                 any = true;
             }
         }
@@ -1247,17 +1269,19 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
                 if (m < m_min || m >= m_min + m_cnt) continue;
                 int tl = t;
                 SSK_OPAQUE1(tl);
-                const f32x4* hp = p.hspec + ((size_t)ridx * 2 + ch) * row_f4 + (size_t)i * (kSpecComplex / 2) + tl;
-                spec_block_product(p, tl, hp, spec0 + (m - m_min), any, acc);
+                const f32x4* hp = hspec_base + ((size_t)ridx * 2 + ch) * row_f4 + (size_t)i * (kSpecComplex / 2) + tl;
+                spec_block_product(spec_base, tl, hp, spec0 + (m - m_min), any, acc);
                 any = true;
             }
         }
     }
-    const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
-    if (FUSE) {
-        if (t < kNfft) win_v = p.tb.win[t];
-        if (t < 256) tw512_v = p.tb.tw512[t];
-        wq = p.tb.twM[64 * (t & 15)];
+    if (!SIMPLE) {                                      // (the loop kernels have no registers to spare for this)
+        tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+        if (FUSE) {
+            if (t < kNfft) win_v = p.tb.win[t];
+            if (t < 256) tw512_v = p.tb.tw512[t];
+            wq = p.tb.twM[64 * (t & 15)];
+        }
     }
     if (p.dbg == 1) {                                   // exit after the loads + products
         if (acc[0][0].x == 123.456f && any) p.out[0] = acc[1][7].y + tw.p1.x;
