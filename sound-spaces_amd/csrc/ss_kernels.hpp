@@ -1031,9 +1031,9 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     // right away put two load -> s_waitcnt vmcnt(0) -> ds_write round trips (~1.7 us) in front of the RIR loads.
     c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
     float win_v = 0.f;
-    if (FUSE) {
-        if (t < kNfft) win_v = p.tb.win[t];
-        if (t < 256) tw512_v = p.tb.tw512[t];
+    if (FUSE) {                                         // unconditional (clamped) loads: a predicated load is merged with
+        win_v = p.tb.win[t & (kNfft - 1)];              // the default value by a register move, i.e. waited for right here;
+        tw512_v = p.tb.tw512[t & 255];                  // only threads < 512 / < 256 store theirs to LDS
         wq = p.tb.twM[64 * (t & 15)];
     }
 
@@ -1053,15 +1053,16 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                 const c32* h2 = reinterpret_cast<const c32*>(h);
                 const int m_end = cap >> 1;
 #pragma unroll
-                for (int a = 0; a < 8; ++a) hraw[a] = (t + 1024 * a < m_end) ? ld_stream(h2 + t + 1024 * a) : mk2(0.f, 0.f);
-            }
+                for (int a = 0; a < 8; ++a) hraw[a] = ld_stream(h2 + min(t + 1024 * a, m_end - 1));   // clamped, not
+            }                                                   // predicated (see the table loads); masked where consumed
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
             const int m_min = __builtin_amdgcn_readfirstlane(d[2]);
             const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
             if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
                 if (planar) {
-                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return hraw[(m - t) >> 10]; });
+                    const int m_end = cap >> 1;
+                    pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? hraw[(m - t) >> 10] : mk2(0.f, 0.f); });
                 } else {
                     pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
                         const int n = 2 * m;
