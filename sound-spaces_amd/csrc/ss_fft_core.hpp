@@ -33,7 +33,8 @@
 // a wave-uniform value that must already sit in a scalar register HERE: placed in front of the descriptor load it makes
 // the compiler fetch the kernel arguments it names in the kernel's first batch of scalar loads, instead of one more
 // dependent round trip at their first use (the asm blocks of the descriptor loads are barriers for its scheduler)
-#define SSK_HAVE_S(v) asm volatile("" : "+s"(v))
+// (input-only operand: an in/out one would make the pointer's address space unknown to the compiler, i.e. FLAT loads)
+#define SSK_HAVE_S(v) asm volatile("" : : "s"(v))
 #else
 #define SSK_OPAQUE2(v) (void)(v)
 #define SSK_OPAQUE1(v) (void)(v)

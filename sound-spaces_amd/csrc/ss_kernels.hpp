@@ -1284,6 +1284,13 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
             wq = p.tb.twM[64 * (t & 15)];
         }
     }
+    if (FUSE) {
+        // The table values are "arrived" from here on as far as the compiler is concerned (they were the first loads of
+        // the kernel; the row's data, fetched after them, has just been consumed).  Left pending, their first use - inside
+        // the STFT blocks - is guarded by s_waitcnt vmcnt(0), which (one in-order counter) also waits for whatever was
+        // stored just before: the audiogoal row, and in the second block the first block's 65 result stores.
+        SSK_OPAQUE2(wq); SSK_OPAQUE2(tw512_v); SSK_OPAQUE1(win_v);
+    }
     if (p.dbg == 1) {                                   // exit after the loads + products
         if (acc[0][0].x == 123.456f && any) p.out[0] = acc[1][7].y + tw.p1.x;
         return;
