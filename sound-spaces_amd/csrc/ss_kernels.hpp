@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
     float win_v = 0.f;
     ThreadTw tw;
-    if (SIMPLE) {
+    {
         // The thread's table entries (L2 hits, independent of the descriptor) go out FIRST: they travel under the scalar
         // round trips and the row's loads.  Issued after the products (where they are first needed) they were one more
         // exposed round trip in front of the item stage.
@@ -1274,14 +1274,6 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
                 spec_block_product(spec_base, tl, hp, spec0 + (m - m_min), any, acc);
                 any = true;
             }
-        }
-    }
-    if (!SIMPLE) {                                      // (the loop kernels have no registers to spare for this)
-        tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
-        if (FUSE) {
-            if (t < kNfft) win_v = p.tb.win[t];
-            if (t < 256) tw512_v = p.tb.tw512[t];
-            wq = p.tb.twM[64 * (t & 15)];
         }
     }
     if (FUSE) {
