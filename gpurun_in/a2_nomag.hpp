@@ -258,41 +258,7 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
     //   M0[b]   = |X[256-4b]|                           -> row 64-b
     //   M123[b] = sum_{e=1..3} |X[256-4b-e]|            -> row 63-b          (+ |X[128]| = |Z[128]| for row 32)
     float* ps = reinterpret_cast<float*>(sc);           // per frame: D[32] | M0[32] | M123[32] | X128 ; stride kPsStride
-    float dsum[2], m0[2], m123[2];
-    // Z[256-4b], the mirror of Z[4b], sits just above this lane's aligned mirror quad: it is the previous lane's
-    // Z[252-4(b-1)], fetched by DPP (a direct LDS read at this lane stride would be 4-way bank conflicted)
-    f32x4 k01[2], k23[2], p01[2], p23[2], w01[2], w23[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int b = q + 16 * i;
-        const f32x4* zk4 = reinterpret_cast<const f32x4*>(fn + posN(4 * b));          // Z[4b .. 4b+3]
-        const f32x4* zp4 = reinterpret_cast<const f32x4*>(fn + posN(252 - 4 * b));    // Z[252-4b .. 255-4b]
-        const f32x4* w4 = reinterpret_cast<const f32x4*>(tw512 + posN(4 * b));
-        k01[i] = zk4[0]; k23[i] = zk4[1]; p01[i] = zp4[0]; p23[i] = zp4[1]; w01[i] = w4[0]; w23[i] = w4[1];
-    }
-    const c32 prev0 = mk2(row_ror1(p01[0].x, lane), row_ror1(p01[0].y, lane));         // lane q-1 (15 for q = 0), i = 0
-    const c32 prev1 = mk2(row_ror1(p01[1].x, lane), row_ror1(p01[1].y, lane));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        // b = 0: Z[256] = Z[0];  b = 16 (q = 0, i = 1): Z[192] is lane 15's i = 0 quad start
-        const c32 ptop = i == 0 ? (q == 0 ? k01[0].xy : prev0) : (q == 0 ? prev0 : prev1);
-        const c32 zk[4] = {k01[i].xy, k01[i].zw, k23[i].xy, k23[i].zw};
-        const c32 zp[4] = {ptop, p23[i].zw, p23[i].xy, p01[i].zw};
-        const c32 ww[4] = {w01[i].xy, w01[i].zw, w23[i].xy, w23[i].zw};
-        float d = 0.f, m = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const c32 P = add_conj(zk[e], zp[e]), Q = sub_conj(zk[e], zp[e]);
-            const c32 wq = cmul(Q, ww[e]);
-            // X = P - i wq = 2 X[k], Y = P + i wq = conj(2 X[256-k]), by component; m2 = (|X|^2, |Y|^2)
-            const c32 m2 = mag2(xy_re(P, wq), xy_im(P, wq));
-            d += fast_sqrt(m2.x);
-            const float my = fast_sqrt(m2.y);
-            if (e == 0) m0[i] = 0.5f * my; else m += my;
-        }
-        dsum[i] = 0.5f * d;
-        m123[i] = 0.5f * m;
-    }
+    float dsum[2] = {x[0].x, x[1].x}, m0[2] = {x[2].x, x[3].y}, m123[2] = {x[4].x, x[5].y};
     float x128 = 0.f;
     if (q == 0) { const c32 z = fn[posN(128)]; x128 = fast_sqrt(z.x * z.x + z.y * z.y); }
     wave_sync();
@@ -974,9 +940,8 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
 }
 
 // Fused STFT phase (out_len <= kB, t4 <= 26): the 1-s row goes from registers into LDS and feeds the STFT directly.
-constexpr int kResFloats = kBins4 * 26;     // pooled spectrogram of one ear (t4 <= 26 on the fused path)
 __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
-                                                 const float* s_win, const c32* s_tw512, c32 wq, float* s_res) {
+                                                 const float* s_win, const c32* s_tw512, c32 wq) {
     // The row goes to LDS with librosa's centre padding materialised around it (256 samples on each side), so that
     // every frame is an aligned, branch-free read.  (With the padding resolved per sample at load time, the three
     // waves that own the first / last frames ran a ~300-instruction edge path on top of their two blocks; two of them
@@ -1009,18 +974,14 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     stft_load_padded(padded, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, s_win, x0);
     stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
     lds_barrier();
-    // The pooled values of this ear are collected in LDS and leave together: written straight from the blocks, lane r
-    // stores row r of out[unit][r][block][ear] - 64 lanes, 64 different cache lines, 4 bytes each, 26 times per workgroup.
-    // From s_res, consecutive threads write consecutive (row, block) elements: every other float of a contiguous range.
+    float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
     if (wv < p.t4)
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * p.t4 + wv] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
     if (two) {
         wave_sync();
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * p.t4 + wv + 16] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1,
+                   [&](int b, float v) { o[(b * p.t4 + wv + 16) * 2 + ch] = v; });
     }
-    lds_barrier();
-    float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
-    for (int e = t; e < kBins4 * p.t4; e += kT) o[2 * e] = s_res[e];
 }
 
 // SIMPLE: the caller guarantees one output block (nb_y == 1), RIR capacity <= kB and no distractor term,
@@ -1100,11 +1061,6 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     // the FFT buffer leaves free, while the row is convolved with the current RIR: kept in registers it spilled
     // (the loop kernel already carries the accumulator across the passes at the 128-VGPR cap)
     __shared__ c32 s_prev[XFADE ? kPrevPairs : 1];
-    // results of the fused STFT phase (see fused_stft_phase); the XFADE kernels are at the LDS limit and reuse s_prev,
-    // which is dead once the row is blended
-    __shared__ float s_res_own[FUSE && !XFADE ? kResFloats : 1];
-    static_assert(2 * kPrevPairs >= kResFloats, "s_prev must be able to hold the pooled spectrogram");
-    float* s_res = XFADE ? reinterpret_cast<float*>(s_prev) : s_res_own;
     bool have_prev = false;
     if (!SIMPLE) {
         // XFADE: round 0 = term 1 alone (previous RIR; only block 0 holds ramp samples), round 1 = term 0.
@@ -1180,7 +1136,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
     }
 }
 
@@ -1244,7 +1200,6 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const int* d = p.desc + 8 * unit;
     __shared__ float s_win[FUSE ? kNfft : 1];
     __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
-    __shared__ float s_res[FUSE ? kResFloats : 1];          // results of the fused STFT phase (see fused_stft_phase)
     c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
     float win_v = 0.f;
     ThreadTw tw;
@@ -1330,7 +1285,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
     }
 }
 

@@ -303,31 +303,18 @@ __device__ __forceinline__ void stft_block(c32* sc, int lane, c32 wq, const c32*
         ps[f * kPsStride + 64 + q + 16 * i] = m123[i];
     }
     if (q == 0) ps[f * kPsStride + 96] = x128;
-    if (q == 1) ps[f * kPsStride + 97] = 0.f;            // the "no second term" slot of the gather below
     wave_sync();
-    // Pooled row r = lane (0..63) is the sum over the 4 frames of ONE or TWO partial sums:
-    //   r < 32: D[r]      r == 32: M123[31] + X128      32 < r < 64: M123[63-r] + M0[64-r]
-    // as a branch-free gather through two per-lane offsets (the absent second term reads the zero slot; x + 0 is exact):
-    // eight independent LDS reads and one wait.  (Written as a chain of if / else per frame it compiled to exec-masked
-    // branches with an LDS read and an s_waitcnt lgkmcnt(0) in every arm: a dozen dependent LDS round trips per block.)
-    {
-        const int r = lane;
-        const bool lo = r < 32, mid = r == 32;
-        const int oa = lo ? r : mid ? 64 + 31 : 64 + 63 - r;
-        const int ob = lo ? 97 : mid ? 96 : 32 + 64 - r;
-        float a[4], b[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { a[g] = ps[g * kPsStride + oa]; b[g] = ps[g * kPsStride + ob]; }
+    for (int r = lane; r < kBins4; r += 64) {
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v += a[g] + b[g];
+        for (int g = 0; g < 4; ++g) {
+            const float* pf = ps + g * kPsStride;
+            if (r < 32) v += pf[r];
+            else if (r == 32) v += pf[64 + 31] + pf[96];
+            else if (r < 64) v += pf[64 + 63 - r] + pf[32 + 64 - r];
+            else v += pf[32];
+        }
         store(r, fast_log1p(v * (1.0f / 16.0f)));
-    }
-    if (lane == 0) {                                     // row 64 = bin 256 alone: M0[0] of the 4 frames
-        float v = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) v += ps[g * kPsStride + 32];
-        store(64, fast_log1p(v * (1.0f / 16.0f)));
     }
 }
 
@@ -974,9 +961,8 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
 }
 
 // Fused STFT phase (out_len <= kB, t4 <= 26): the 1-s row goes from registers into LDS and feeds the STFT directly.
-constexpr int kResFloats = kBins4 * 26;     // pooled spectrogram of one ear (t4 <= 26 on the fused path)
 __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
-                                                 const float* s_win, const c32* s_tw512, c32 wq, float* s_res) {
+                                                 const float* s_win, const c32* s_tw512, c32 wq) {
     // The row goes to LDS with librosa's centre padding materialised around it (256 samples on each side), so that
     // every frame is an aligned, branch-free read.  (With the padding resolved per sample at load time, the three
     // waves that own the first / last frames ran a ~300-instruction edge path on top of their two blocks; two of them
@@ -1009,18 +995,14 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     stft_load_padded(padded, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, s_win, x0);
     stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
     lds_barrier();
-    // The pooled values of this ear are collected in LDS and leave together: written straight from the blocks, lane r
-    // stores row r of out[unit][r][block][ear] - 64 lanes, 64 different cache lines, 4 bytes each, 26 times per workgroup.
-    // From s_res, consecutive threads write consecutive (row, block) elements: every other float of a contiguous range.
+    float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2;
     if (wv < p.t4)
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * p.t4 + wv] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { o[(b * p.t4 + wv) * 2 + ch] = v; });
     if (two) {
         wave_sync();
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * p.t4 + wv + 16] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1,
+                   [&](int b, float v) { o[(b * p.t4 + wv + 16) * 2 + ch] = v; });
     }
-    lds_barrier();
-    float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
-    for (int e = t; e < kBins4 * p.t4; e += kT) o[2 * e] = s_res[e];
 }
 
 // SIMPLE: the caller guarantees one output block (nb_y == 1), RIR capacity <= kB and no distractor term,
@@ -1100,11 +1082,6 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     // the FFT buffer leaves free, while the row is convolved with the current RIR: kept in registers it spilled
     // (the loop kernel already carries the accumulator across the passes at the 128-VGPR cap)
     __shared__ c32 s_prev[XFADE ? kPrevPairs : 1];
-    // results of the fused STFT phase (see fused_stft_phase); the XFADE kernels are at the LDS limit and reuse s_prev,
-    // which is dead once the row is blended
-    __shared__ float s_res_own[FUSE && !XFADE ? kResFloats : 1];
-    static_assert(2 * kPrevPairs >= kResFloats, "s_prev must be able to hold the pooled spectrogram");
-    float* s_res = XFADE ? reinterpret_cast<float*>(s_prev) : s_res_own;
     bool have_prev = false;
     if (!SIMPLE) {
         // XFADE: round 0 = term 1 alone (previous RIR; only block 0 holds ramp samples), round 1 = term 0.
@@ -1180,7 +1157,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
     }
 }
 
@@ -1236,7 +1213,6 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const f32x4* spec_base = p.spec;
     const f32x4* hspec_base = p.hspec;
     SSK_HAVE_S(grid); SSK_HAVE_S(spec_base); SSK_HAVE_S(hspec_base);
-    if (p.dbg == 10) return;                            // SS_HIP_DBG=10: the launch alone (dispatch of 2N x 1024 threads)
     const int slot = row_slot(blockIdx.x, grid, p.xcd_map);
     // (the division of two uniform values is done on the vector unit: bring the quotient back to a scalar register)
     const int row = SIMPLE ? slot : __builtin_amdgcn_readfirstlane(slot / p.nb_y), j = SIMPLE ? 0 : slot - row * p.nb_y;
@@ -1244,7 +1220,6 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const int* d = p.desc + 8 * unit;
     __shared__ float s_win[FUSE ? kNfft : 1];
     __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
-    __shared__ float s_res[FUSE ? kResFloats : 1];          // results of the fused STFT phase (see fused_stft_phase)
     c32 wq = mk2(1.f, 0.f), tw512_v = mk2(0.f, 0.f);
     float win_v = 0.f;
     ThreadTw tw;
@@ -1330,7 +1305,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq);
     }
 }
 
