@@ -266,6 +266,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-steps", type=int, default=-1,
+                    help="untimed device spin-up before the warm-up steps (GPU clocks take milliseconds to come up; a "
+                         "20-step timed region lasts half a millisecond); -1 = 1500 steps at <= 128 units per GPU, fewer for "
+                         "larger launches; 0 disables")
     ap.add_argument("--envs", type=int, default=128, help="envs per GPU per step (weak scaling) / in total (--scaling strong)")
     ap.add_argument("--rotations", type=int, default=1, help="agent rotations rendered per env and step (BASELINE configs[2]: "
                                                              "4; the azimuths of a pair sit in adjacent bank rows)")
@@ -378,6 +382,8 @@ def main():
     fused = sr <= P.KB
     want_ag = args.with_audiogoal or not fused
 
+    spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128))
+
     def run_loop(S, gather_every, spectral, per_step_events=False):
         """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms: average over
         the region from two HIP events on the launch stream, or the per-step list with per_step_events, note).
@@ -425,6 +431,15 @@ def main():
                 print("[bench] " + note, file=sys.stderr, flush=True)
                 state["no_exchange"] = True
         torch.cuda.synchronize()
+        # device spin-up (clocks, TLBs, instruction caches): untimed, reported in the JSON line; the W warm-up steps follow.
+        # A fixed NUMBER of steps (every rank issues the same collectives), sized for ~40 ms at the headline shape.
+        for k in range(spin_steps):
+            step(k % total)
+            if k % 64 == 63:
+                torch.cuda.synchronize()                           # keep the launch queue shallow
+        if spin_steps:
+            flush()
+            torch.cuda.synchronize()
         for k in range(args.warmup):
             step(k)
         flush()
@@ -519,7 +534,7 @@ def main():
             "metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
             "value": round(world * N * args.steps / elapsed, 1),
             "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_untimed": spin_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
