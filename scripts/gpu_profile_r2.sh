@@ -16,7 +16,7 @@ for BANK in spectral time; do
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
              "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    ( cd /tmp && timeout 600 rocprofv3 --pmc $PMC --output-format csv -d "$D" -o pmc$i -- $CMD > /dev/null 2>&1 ) || echo "pmc pass $i failed"
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $PMC --output-format csv -d "$D" -o pmc$i -- $CMD --spinup-steps 0 > /dev/null 2>&1 ) || echo "pmc pass $i failed"   # (counters are per dispatch: no clock spin-up needed)
   done
   python scripts/prof_summary.py "$D" > /dev/null 2>&1
   cp "$D/summary.txt" "$OUT/summary_$BANK.txt"
