@@ -34,6 +34,7 @@ if a.spectral:
     r.rirs.build_spectra()
 
 def timeit(fn, reps):
+    spin_up(fn)
     for _ in range(5): fn(0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,6 +42,19 @@ def timeit(fn, reps):
     for k in range(reps): fn(k)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+
+_spun = [False]
+def spin_up(fn, ms=40.0):
+    """GPU clocks take milliseconds to come up (profiles/r2/NOTES.md section 12): run `fn` untimed for `ms` first."""
+    import time
+    if _spun[0]:
+        return
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < ms * 1e-3:
+        for _ in range(32):
+            fn(k); k += 1
+        torch.cuda.synchronize()
+    _spun[0] = True
 
 from ss_amd import _lib
 LIB = _lib.load()
