@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <new>
 #include <vector>
 
@@ -79,6 +81,63 @@ int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, 
     return hip_err(hipGetLastError());
 }
 
+// ---- k_obs_rows: fused observation for rows longer than one partition block -------------------------------------
+// The kernel's workgroups keep the block spectra of the row they are rendering in a private stash (see k_obs_rows).
+// Launches on ONE stream run one after the other, so the stash is owned by (device, stream): two streams never share
+// one, whatever their launches overlap with.  Grown on demand (first long-row launch of a stream), never shrunk.
+struct StashBuf { float* ptr = nullptr; size_t bytes = 0; };
+std::map<std::pair<int, hipStream_t>, StashBuf> g_stash;
+
+int get_stash(hipStream_t st, size_t bytes, float** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_err(e);
+    std::lock_guard<std::mutex> lk(g_mu);
+    StashBuf& b = g_stash[std::make_pair(dev, st)];
+    if (b.bytes < bytes) {
+        if (b.ptr) {
+            e = hipStreamSynchronize(st);                       // earlier launches of this stream still use the old one
+            if (e != hipSuccess) return hip_err(e);
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr; b.bytes = 0;
+        }
+        e = hipMalloc(reinterpret_cast<void**>(&b.ptr), bytes);
+        if (e != hipSuccess) { b.ptr = nullptr; return hip_err(e); }
+        b.bytes = bytes;
+    }
+    *out = b.ptr;
+    return 0;
+}
+
+// can k_obs_rows serve this shape?  (rows of 2 or 3 blocks, no cross-fade, stash mask of 32 bits)
+inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags) {
+    return out_len > ssk::kB && out_len <= 3 * ssk::kB && n_valid <= out_len && !(flags & SS_FLAG_CROSSFADE) &&
+           nbh_max >= 1 && nbh_max <= 16;
+}
+
+template <bool SPECTRAL>
+int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStream_t st) {
+    const int n_rows = 2 * n_units;
+    const int grid = n_rows < n_cus ? n_rows : n_cus;
+    p.nb_y = p.n_valid == 0 ? 0 : (p.n_valid + ssk::kB - 1) / ssk::kB;
+    p.stash = nullptr;
+    p.stash_nbh = 0;
+    p.stash_terms = 0;
+    p.n_terms = (flags & SS_FLAG_NO_DISTRACTOR) ? 1 : 2;
+    if (!SPECTRAL && p.nb_y > 1) {                              // a block spectrum is only ever needed twice with nb_y > 1
+        const int nbh_max = (p.rir_cap + ssk::kB - 1) / ssk::kB;
+        p.stash_terms = p.n_terms;                              // no distractor terms: half the stash
+        p.stash_nbh = nbh_max;
+        const size_t per_wg = static_cast<size_t>(p.stash_terms) * nbh_max * ssk::kSpecComplex * sizeof(ssk::c32);
+        float* buf = nullptr;
+        int rc = get_stash(st, per_wg * static_cast<size_t>(grid), &buf);
+        if (rc) return rc;
+        p.stash = reinterpret_cast<ssk::f32x4*>(buf);
+    }
+    hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
+    return hip_err(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
@@ -151,8 +210,14 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     // default on: the two ears of a unit (same window spectrum) share an XCD's L2; SS_HIP_XCD_MAP=0 is the A/B switch
     static const int xcd_map = getenv("SS_HIP_XCD_MAP") ? atoi(getenv("SS_HIP_XCD_MAP")) : 1;
     p.xcd_map = xcd_map;
+    p.stash = nullptr;
+    p.stash_nbh = 0;
+    p.stash_terms = 0;
+    p.n_terms = 2;
+#if defined(SS_LADDER)                                     // profiling builds only (scripts/gpu_ladder.sh compiles with -DSS_LADDER)
     static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
     p.dbg = dbg;
+#endif
     return 0;
 }
 
@@ -267,7 +332,12 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
         p.sgram = spectrogram;
         return launch_conv<true>(p, n_units, 1, flags, n_cus, static_cast<hipStream_t>(stream));
     }
-    if (!audiogoal) return SS_EINVAL;                   // long rows hand over through HBM/L2
+    if (obs_rows_ok(out_len, n_valid, (rir_cap + ssk::kB - 1) / ssk::kB, flags)) {   // rows of 2-3 blocks: fused as well
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_obs_rows<false>(p, n_units, flags, n_cus, static_cast<hipStream_t>(stream));
+    }
+    if (!audiogoal) return SS_EINVAL;                   // cross-faded long rows hand over through HBM/L2
     rc = ss_fftconv_binaural_f32(spec, rir, rir_len, unit_desc, audiogoal, n_units, rir_unit_stride,
                                  rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, flags, stream);
     if (rc) return rc;
@@ -389,6 +459,11 @@ int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_
         p.out = audiogoal;
         p.sgram = spectrogram;
         return launch_conv_spec<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
+    }
+    if (obs_rows_ok(out_len, n_valid, h_blocks, flags)) {
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_obs_rows<true>(p, n_units, flags, n_cus, static_cast<hipStream_t>(stream));
     }
     if (!audiogoal) return SS_EINVAL;
     rc = ss_fftconv_binaural_spec_f32(spec, hspec, rir_len, unit_desc, audiogoal, n_units, h_blocks, n_valid, out_len,
@@ -652,7 +727,9 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
         e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return hip_err(e);
     }
-    if (spectrogram && !audiogoal && c.out_len > ssk::kB) {    // rows longer than one block hand over through memory
+    const int nbh_bank = c.hspec ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
+    if (spectrogram && !audiogoal && c.out_len > ssk::kB &&
+        !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags)) {  // only cross-faded long rows still hand over through memory
         const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
         if (need > c.ag_cap) {
             e = hipDeviceSynchronize();

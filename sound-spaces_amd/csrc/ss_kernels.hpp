@@ -833,7 +833,15 @@ struct ConvParams {
     int h_blocks;
     int xcd_map;                 // != 0: launch slots are dealt to the XCDs in contiguous ranges (row_slot)
     int nb_y;                    // output blocks per row; k_conv_spec: grid = 2N * nb_y, slot = (row, j), j fastest
-    int dbg;                     // timing experiments only (scripts/gpu_ladder.sh): early exit point, 0 = full kernel
+    // k_obs_rows (rows longer than one block, fused): per-workgroup scratch for the block spectra H' of the row being
+    // rendered, [gridDim.x][stash_terms][stash_nbh][8192] f32x4 (time-domain bank only); stash_terms = 1 when the
+    // launch has no distractor terms
+    f32x4* stash;
+    int stash_nbh, stash_terms;
+    int n_terms;                 // k_obs_rows: descriptor terms read per unit (1 under SS_FLAG_NO_DISTRACTOR)
+#if defined(SS_LADDER)
+    int dbg;                     // timing experiments only (scripts/gpu_ladder.sh, -DSS_LADDER builds): early exit point
+#endif
 };
 
 // Workgroup b of a 1-D launch runs on XCD b % 8 (MI355X_MICROARCH: observed dispatch order, for speed only).  Dealing
@@ -1236,7 +1244,9 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const f32x4* spec_base = p.spec;
     const f32x4* hspec_base = p.hspec;
     SSK_HAVE_S(grid); SSK_HAVE_S(spec_base); SSK_HAVE_S(hspec_base);
+#if defined(SS_LADDER)
     if (p.dbg == 10) return;                            // SS_HIP_DBG=10: the launch alone (dispatch of 2N x 1024 threads)
+#endif
     const int slot = row_slot(blockIdx.x, grid, p.xcd_map);
     // (the division of two uniform values is done on the vector unit: bring the quotient back to a scalar register)
     const int row = SIMPLE ? slot : __builtin_amdgcn_readfirstlane(slot / p.nb_y), j = SIMPLE ? 0 : slot - row * p.nb_y;
@@ -1308,6 +1318,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
         // stored just before: the audiogoal row, and in the second block the first block's 65 result stores.
         SSK_OPAQUE2(wq); SSK_OPAQUE2(tw512_v); SSK_OPAQUE1(win_v);
     }
+#if defined(SS_LADDER)                                  // early exits of the timing ladder: never in the product build
     if (p.dbg == 1) {                                   // exit after the loads + products
         if (acc[0][0].x == 123.456f && any) p.out[0] = acc[1][7].y + tw.p1.x;
         return;
@@ -1316,16 +1327,19 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
         if (any) { item_store_inv(lds, tw.i0, t, acc[0]); item_store_inv(lds, tw.i1, t + 1024, acc[1]); }
         return;
     }
+#endif
     if (any) {
         items_to_time(lds, tw, t, acc, y);
     } else {
 #pragma unroll
         for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
     }
+#if defined(SS_LADDER)
     if (p.dbg == 3) {                                   // exit before the stores / STFT
         if (y[0].x == 123.456f) p.out[0] = y[7].y;
         return;
     }
+#endif
     store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;
@@ -1552,6 +1566,246 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
         ear = n_ear;
         cur = nx;
         lds_barrier();                                      // every wave is done with the LDS buffer of this row
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_obs_rows: the FUSED observation for rows longer than one partition block - 44.1 kHz, the reference's own Replica
+// rate (configs/audionav/av_nav/replica/audiogoal.yaml:18): simulator.py:629-632 on 44100-sample rows followed by
+// nav.py:86-100 -> (65, 69, 2).  One launch; the waveform never leaves the CU unless the caller wants the audiogoal.
+//
+// A workgroup owns one CU (the LDS allows one) and walks (unit, ear) rows: row_slot(b) + k * gridDim.x.  Per row it
+// renders the output blocks j = 0 .. nb_rows-1 IN ORDER and streams the STFT behind them:
+//
+//   convolution of block j:  Y_j = sum over (term, RIR block i) of H'_i * S'_{j-i}  (as k_conv / k_conv_spec).
+//     Time-domain bank: every RIR block is transformed ONCE per row.  The block spectrum H'_i is multiplied into Y_j
+//     straight from the registers of the forward item stage and, if a later output block needs it again (44.1 kHz,
+//     1-s clip: H'_0 for j = 1, 2; H'_1 for j = 2), written to the workgroup's private stash in global memory in the
+//     kernels' register order - the on-the-fly equivalent of the spectral bank, L2 / Infinity-Cache resident
+//     (<= 6 x 128 KiB per CU).  Later blocks read it back with the same coalesced 16-byte loads as the window spectra.
+//     (k_conv re-ran the forward FFTs per output block: 6 instead of 3 at 44.1 kHz, plus 3 workgroups per row.)
+//     Spectral bank: H'_i comes from the bank, no forward FFT and no stash.
+//   STFT behind block j:  hann(400) centred in 512 with hop 160: pooled time block b (frames 4b .. 4b+3) needs samples
+//     [640 b - 256, 640 b + 736).  After block j the row is known up to (j+1) kB, so the pooled blocks
+//     b0_j <= b < b1_j = floor((floor(((j+1) kB - 256) / 160) + 1) / 4) are complete (44.1 kHz: 25 + 26 + 18 = 69).
+//     The block's samples go from registers into LDS behind a CONTEXT of the samples [640 b0_j - 256, j kB) that the
+//     previous block left in s_tail (<= 640 floats; block 0: librosa's left centre padding), the last block appends the
+//     right padding, and the pooled blocks run exactly as in the one-block kernels (fused_stft_phase): two rounds of
+//     16 waves, wave-private scratch overlaying the row buffer.
+// Unit descriptors, silent units, distractor term, n_valid < out_len (0.25-s SS2.0 steps: blocks beyond n_valid are
+// zeros without any transform) as in k_conv.  SS_FLAG_CROSSFADE is not served here (the launcher keeps the two-kernel
+// path for cross-faded rows longer than one block).
+constexpr int kTailFloats = 640;            // context handed from output block j to j+1 (nb_rows <= 3: 640, 384)
+constexpr int kRowsMaxBlocks = 27;          // pooled blocks behind one output block (32768-sample rows: 25 + 27)
+constexpr int kRowsResFloats = kBins4 * kRowsMaxBlocks;
+
+// pooled time blocks that are complete once the row is known up to sample `known` (not the row's end)
+__host__ __device__ constexpr int pooled_blocks_complete(int known) {
+    return (known < kNfft / 2) ? 0 : (((known - kNfft / 2) / kHop + 1) / kPool);
+}
+
+// forward FFT of RIR block i (time-domain bank) -> acc (= or +=) H'_i * S'[slot]; `st` != nullptr: H'_i is also written
+// to the stash (thread t's 8 f32x4 at st[(s*4+h)*1024], the order every consumer load uses)
+template <bool ACCUMULATE>
+__device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const float* h,
+                                                 int i, int slot, f32x4* st, c32 (&acc)[2][8]) {
+    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+    const int lo = i * kB, es = p.rir_elem_stride, cap = p.rir_cap;
+    if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
+        const c32* h2 = reinterpret_cast<const c32*>(h + lo);
+        const int m_end = (cap - lo) >> 1;
+        pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? ld_stream(h2 + m) : mk2(0.f, 0.f); });
+    } else {
+        pass1_fwd<true>(lds, tw.p1, t, [&](int m) {
+            const int n = lo + 2 * m;
+            return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
+        });
+    }
+    lds_barrier();
+    pass2<false>(lds, tw.p2, t);
+    lds_barrier();
+    pass3_fwd(lds, t);
+    lds_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 sv[4];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) sv[hh] = sp[(s * 4 + hh) * 1024];
+        c32 v[8];
+        item_load_fwd(lds, s ? tw.i1 : tw.i0, t + 1024 * s, v);
+        if (st) {
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) st[(s * 4 + hh) * 1024 + t] = mk4(v[2 * hh], v[2 * hh + 1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const c32 w = (e & 1) ? sv[e >> 1].zw : sv[e >> 1].xy;
+            c32 pr = cmul(v[e], w);
+            if (s == 0 && e == 0 && t == 0) pr = mk2(v[0].x * w.x, v[0].y * w.y);   // (X[0], X[16384]) are real
+            if (ACCUMULATE) acc[s][e] += pr;
+            else acc[s][e] = pr;
+        }
+    }
+}
+
+// STFT of the pooled blocks [b0, b1) that output block j completes (see the kernel comment).  y = the block's kB samples
+// (packed pairs t + 1024 a).  `last`: j is the row's last block (right centre padding, frames up to n_frames - 1).
+__device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, int j, int b0, int b1,
+                                                bool last, const c32 (&y)[8], const float* s_win, const c32* s_tw512, c32 wq,
+                                                float* s_res, float* s_tail) {
+    float* buf = reinterpret_cast<float*>(lds);           // buf[k] = row sample 640 b0 - 256 + k
+    const int base = kB * j;                              // first sample of this block
+    const int ctx = j == 0 ? kNfft / 2 : base - (kHop * kPool * b0 - kNfft / 2);    // even, <= kTailFloats
+    float* yl = buf + ctx;                                // sample `base`
+    const int len = p.out_len;
+    lds_barrier();                                        // every earlier use of the buffer (pass 1', previous STFT) is over
+    {
+        c32* yl2 = reinterpret_cast<c32*>(yl) + t;        // one ds_write_b64 per packed pair
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int n = base + 2 * (t + 1024 * a);
+            yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);   // zeros beyond n_valid
+        }
+        if (j > 0 && t < ctx) buf[t] = s_tail[t];         // the previous block's last samples
+    }
+    lds_barrier();
+    if (j == 0 && t < kNfft / 2) yl[-1 - t] = p.pad_mode == 0 ? yl[1 + t] : 0.f;              // left centre padding
+    if (last && t >= 256 && t < 256 + kNfft / 2) {        // right centre padding: sample len + k = sample len - 2 - k
+        const int k = t - 256;
+        yl[len - base + k] = p.pad_mode == 0 ? yl[len - base - 2 - k] : 0.f;
+    }
+    if (!last) {                                          // context of the next block: samples [640 b1 - 256, base + kB)
+        const int s0n = kHop * kPool * b1 - kNfft / 2;
+        if (t < kTailFloats && s0n + t < base + kB) s_tail[t] = yl[s0n - base + t];
+    }
+    lds_barrier();
+    const int lane = t & 63, wv = t >> 6, cnt = b1 - b0;
+    // frames relative to the buffer: pooled block b0 + k starts at buf + 640 k; both rounds are pulled into registers
+    // before the wave scratches overlay the buffer (see fused_stft_phase)
+    c32 x0[16], x1[16];
+    const bool one = wv < cnt, two = wv + 16 < cnt;
+    const int live = p.n_frames - kPool * b0;             // frames of this phase that exist (relative index < live)
+    stft_load_padded(buf, 4 * wv + (lane >> 4), one ? live : 0, lane & 15, s_win, x0);
+    stft_load_padded(buf, 4 * (wv + 16) + (lane >> 4), two ? live : 0, lane & 15, s_win, x1);
+    lds_barrier();
+    if (one) stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * cnt + wv] = v; });
+    if (two) {
+        wave_sync();
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * cnt + wv + 16] = v; });
+    }
+    lds_barrier();
+    float* o = p.sgram + ((size_t)unit * kBins4 * p.t4 + b0) * 2 + ch;
+    for (int b = t / 32; b < kBins4; b += kT / 32) {      // 32 threads per pooled row (cnt <= 27): no division by cnt
+        const int k = t & 31;
+        if (k < cnt) o[((size_t)b * p.t4 + k) * 2] = s_res[b * cnt + k];
+    }
+}
+
+template <bool SPECTRAL>
+__global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
+    __shared__ c32 lds[16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
+    __shared__ float s_win[kNfft];
+    __shared__ c32 s_tw512[kTw512Lds];
+    __shared__ float s_res[kRowsResFloats];
+    __shared__ float s_tail[kTailFloats];
+    const int t = threadIdx.x;
+    ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    {   // the STFT's tables, staged once per workgroup (unconditional clamped loads: see k_conv)
+        const float win_v = p.tb.win[t & (kNfft - 1)];
+        const c32 tw512_v = p.tb.tw512[t & 255];
+        if (t < kNfft) s_win[t] = win_v;
+        if (t < 256) s_tw512[posN(t)] = tw512_v;
+    }
+    c32 wq = p.tb.twM[64 * (t & 15)];
+    // nothing the compiler tracks may be pending when the row loop starts (see k_conv_rows)
+    SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1); SSK_OPAQUE2(wq);
+    const int G = (int)gridDim.x;
+    const int nb_rows = (p.out_len + kB - 1) / kB;
+    const size_t blk_f4 = kSpecComplex / 2;               // f32x4 per block spectrum
+    f32x4* stash = SPECTRAL ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
+    for (int row = row_slot(blockIdx.x, G, p.xcd_map); row < n_rows; row += G) {
+        const int unit = row >> 1, ch = row & 1;
+        i32x4 dws[2];
+        uniform_load8(p.desc + 8 * unit, dws[0], dws[1]);
+        if (p.n_terms < 2) dws[1].x = -1;                 // SS_FLAG_NO_DISTRACTOR: term 1 is ignored, as in k_conv<SIMPLE>
+        // (scalars, not arrays indexed by `term`: a dynamically indexed array lives in scratch memory)
+        int nbh0 = 0, nbh1 = 0;
+        if (dws[0].x >= 0) nbh0 = (uniform_load(p.rir_len + dws[0].x) + kB - 1) / kB;
+        if (dws[1].x >= 0) nbh1 = (uniform_load(p.rir_len + dws[1].x) + kB - 1) / kB;
+        if (SPECTRAL) { nbh0 = min(nbh0, p.h_blocks); nbh1 = min(nbh1, p.h_blocks); }
+        if (dws[0].x < 0 && dws[1].x < 0) {               // silent unit (simulator.py:610-612): exact zeros, no transforms
+            int tz = t;
+            SSK_OPAQUE1(tz);                              // nothing of these loops is worth a register outside them
+            if (p.out) {
+#pragma nounroll
+                for (int n = tz; n < p.out_len; n += kT) p.out[(size_t)row * p.out_len + n] = 0.f;
+            }
+            float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
+#pragma nounroll
+            for (int e = tz; e < kBins4 * p.t4; e += kT) o[2 * e] = 0.f;
+            continue;
+        }
+        unsigned computed = 0;                            // bit (term * stash_nbh + i): H'_i of the term is in the stash
+        int b0 = 0;
+        for (int j = 0; j < nb_rows; ++j) {
+            int tl = t;
+            SSK_OPAQUE1(tl);                              // see k_conv: keeps LICM from hoisting the body's addresses
+            c32 acc[2][8];
+            c32 y[8];
+            bool any = false, lds_used = false;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[s][e] = mk2(0.f, 0.f);   // every product accumulates (0 + x is exact)
+            if (j < p.nb_y) {
+                for (int term = 0; term < 2; ++term) {
+                    const i32x4 dw = term ? dws[1] : dws[0];
+                    const int ridx = dw.x, spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
+                    const int nb = term ? nbh1 : nbh0;
+                    for (int i = 0; i < nb; ++i) {
+                        const int m = j - i;
+                        if (m < m_min || m >= m_min + m_cnt) continue;
+                        const int slot = spec0 + (m - m_min);
+                        // lane id made opaque per product: otherwise LICM hoists every lane-invariant address of the (large)
+                        // bodies out of the loops and the 128-VGPR budget spills them all (see k_conv)
+                        int ti = tl;
+                        SSK_OPAQUE1(ti);
+                        if (SPECTRAL) {
+                            const f32x4* hp = p.hspec + (((size_t)ridx * 2 + ch) * p.h_blocks + i) * blk_f4 + ti;
+                            spec_block_product(p.spec, ti, hp, slot, true, acc);
+                        } else {
+                            const int sidx = term * p.stash_nbh + i;
+                            if ((computed >> sidx) & 1u) {
+                                spec_block_product(p.spec, ti, stash + (size_t)sidx * blk_f4 + ti, slot, true, acc);
+                            } else {
+                                // needed again by a later output block of this row?  (m grows with j)
+                                const bool keep = j + 1 < p.nb_y && m + 1 < m_min + m_cnt;
+                                f32x4* st = keep ? stash + (size_t)sidx * blk_f4 : nullptr;
+                                const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
+                                if (lds_used) lds_barrier();          // the previous block's item reads of layout B are done
+                                conv_block_stash<true>(lds, p, tw, ti, h, i, slot, st, acc);
+                                lds_used = true;
+                                if (keep) computed |= 1u << sidx;
+                            }
+                        }
+                        any = true;
+                    }
+                }
+            }
+            if (any) {
+                if (lds_used) lds_barrier();
+                items_to_time(lds, tw, tl, acc, y);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+            }
+            if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row, j, y);
+            const bool last = j == nb_rows - 1;
+            const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
+            rows_stft_phase(lds, p, tl, unit, ch, j, b0, b1, last, y, s_win, s_tw512, wq, s_res, s_tail);
+            b0 = b1;
+        }
+        lds_barrier();                                    // s_res / the scratches are reused by the next row
     }
 }
 

@@ -142,7 +142,8 @@ def gccphat(x: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="ref
 
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
                    pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
-    """Fused observation.  ``audiogoal`` may be None when out_len <= KB (waveform never leaves the CU)."""
+    """Fused observation.  ``audiogoal`` may be None (the waveform then never leaves the CU) unless the rows are longer
+    than one partition block AND cross-faded (SS_FLAG_CROSSFADE) - the one shape that still runs as two kernels."""
     _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
     _chk(unit_desc, torch.int32, "unit_desc"); _chk(spectrogram_out, torch.float32, "spectrogram_out")
     N = unit_desc.shape[0]
@@ -163,7 +164,7 @@ def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_ou
 def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pad_mode="reflect",
               want_audiogoal: bool = False, interleaved: bool = False, flags: int = 0):
     N = unit_desc.shape[0]
-    need_ag = want_audiogoal or out_len > KB
+    need_ag = want_audiogoal or (out_len > KB and (bool(flags & FLAG_CROSSFADE) or out_len > 3 * KB))
     ag = torch.empty((N, 2, out_len), dtype=torch.float32, device=spec.device) if need_ag else None
     sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
     audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved, flags)

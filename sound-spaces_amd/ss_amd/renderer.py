@@ -280,10 +280,11 @@ class BatchedAudioRenderer:
     # ---- rendering ---------------------------------------------------------------------------------------
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
-        """One launch (two for rows longer than one partition block) on the current stream.
-        Returns (audiogoal [N,2,sr] or None, spectrogram [N,65,T4,2])."""
+        """One launch on the current stream (two only for cross-faded rows longer than one partition block, which hand
+        the waveform over through memory).  Returns (audiogoal [N,2,sr] or None, spectrogram [N,65,T4,2])."""
         N = len(plan)
-        need_ag = want_audiogoal or audiogoal_out is not None or self.out_len > P.KB
+        need_ag = (want_audiogoal or audiogoal_out is not None or
+                   (self.out_len > P.KB and (bool(plan.flags & ops.FLAG_CROSSFADE) or self.out_len > 3 * P.KB)))
         ag = audiogoal_out
         if need_ag and ag is None:
             ag = torch.empty((N, 2, self.out_len), dtype=torch.float32, device=self.device)

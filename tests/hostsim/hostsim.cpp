@@ -131,7 +131,7 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.n_frames = 1 + out_len / ssk::kHop;
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
-    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.dbg = 0;
+    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
     p.fade_len = static_cast<int>(0.05 * out_len);
     const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
     if (xfade) simple = 0;
@@ -203,7 +203,7 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     p.pad_mode = pad_mode;
     p.fade_len = 0;
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
-    p.h_blocks = h_blocks; p.xcd_map = 0; p.dbg = 0;
+    p.h_blocks = h_blocks; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
@@ -228,6 +228,43 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
             });
             if (rc) return rc;
         }
+    }
+    return 0;
+}
+
+// k_obs_rows: `wgs` persistent workgroups walk the (unit, ear) rows; hspec != nullptr selects the spectral-bank variant
+int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const int* rir_len, const int* desc, float* out,
+                float* sgram, int n_units, long long us, int cs, int es, int cap, int h_blocks, int n_valid, int out_len,
+                int pad_mode, int wgs, int no_distractor) {
+    if (out_len <= ssk::kB || out_len > 3 * ssk::kB || !sgram) return -1;
+    ssk::ConvParams p;
+    p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
+    p.out = out; p.sgram = sgram; p.tb = host_tables();
+    p.rir_unit_stride = us; p.rir_chan_stride = cs; p.rir_elem_stride = es; p.rir_cap = cap;
+    p.n_valid = n_valid; p.out_len = out_len;
+    p.n_frames = 1 + out_len / ssk::kHop;
+    p.t4 = (p.n_frames + 3) / 4;
+    p.pad_mode = pad_mode;
+    p.fade_len = 0;
+    p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec); p.h_blocks = h_blocks; p.xcd_map = wgs >= 8;
+    p.nb_y = n_valid == 0 ? 0 : (n_valid + ssk::kB - 1) / ssk::kB;
+    p.n_terms = no_distractor ? 1 : 2;
+    const int n_rows = 2 * n_units, grid = wgs < n_rows ? wgs : n_rows;
+    std::vector<float> stash;
+    p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
+    if (!hspec && p.nb_y > 1) {
+        p.stash_nbh = (cap + ssk::kB - 1) / ssk::kB;
+        p.stash_terms = p.n_terms;
+        stash.assign(static_cast<size_t>(grid) * p.stash_terms * p.stash_nbh * 2 * ssk::kSpecComplex, 12345.0f);
+        p.stash = reinterpret_cast<ssk::f32x4*>(stash.data());
+    }
+    gridDim = dim3{(unsigned)grid, 1, 1};
+    for (int b = 0; b < grid; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(ssk::kT, [&] {
+            if (hspec) ssk::k_obs_rows<true>(p, n_rows); else ssk::k_obs_rows<false>(p, n_rows);
+        });
+        if (rc) return rc;
     }
     return 0;
 }

@@ -33,7 +33,7 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False):
+        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -84,9 +84,25 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         us, cs, es = 2 * cap, 1, 2
     else:
         bank, us, cs, es = rir_bank, 2 * cap, cap, 1
-    simple = int(simple and not any(u.get("dis_rir", -1) >= 0 for u in units) and cap <= P.KB and nby == 1)
+    no_dis = not any(u.get("dis_rir", -1) >= 0 for u in units)
+    simple = int(simple and no_dis and cap <= P.KB and nby == 1)
     if crossfade:
         simple = 2
+    if row_wgs:                                          # k_obs_rows: fused rows of 2-3 blocks, `row_wgs` persistent workgroups
+        assert not crossfade and out_len > P.KB
+        hb, hspec = 0, None
+        if spectral:
+            assert not interleaved
+            hb = P.ceil_div(cap, P.KB)
+            hspec = np.zeros((R, 2, hb, P.SPEC_FLOATS), np.float32)
+            rc = L.hs_rir_spectra(_p(rir_bank, ctypes.c_float), _p(hspec, ctypes.c_float), R, ctypes.c_longlong(2 * cap), cap, cap)
+            assert rc == 0, rc
+        rc = L.hs_obs_rows(_p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(hspec, ctypes.c_float) if spectral else None,
+                           _p(rl, ctypes.c_int), _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
+                           _p(sg, ctypes.c_float), int(N), ctypes.c_longlong(us), int(cs), int(es), int(cap), int(hb), int(n_valid),
+                           int(out_len), int(pad_mode), int(row_wgs), int(no_dis))
+        assert rc == 0, rc
+        return (out if want_audiogoal else None), sg
     if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)
         assert not crossfade and not interleaved
         hb = P.ceil_div(cap, P.KB)

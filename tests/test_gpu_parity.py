@@ -811,3 +811,104 @@ def test_vectorised_planner_equals_per_unit_planner():
     assert torch.equal(a.desc, b.desc) and a.flags == b.flags
     sg = r.render(a)[1].cpu().numpy()
     assert not sg[rir < 0].any()
+
+
+# ---- k_obs_rows: the fused observation at the reference's Replica rate (44.1 kHz) ----------------------------------------
+def _two_kernel(r, plan):
+    """the pre-round-3 path: convolution kernel -> waveform in HBM -> k_spectrogram"""
+    from ss_amd import ops
+    ag = r.render_audiogoal(plan)
+    return ag, ops.spectrogram(ag, r.pad_mode)
+
+
+@pytest.mark.parametrize("spectral", [False, True])
+def test_fused_rows_44k_one_launch_equals_two_kernel_path(spectral):
+    """simulator.py:629-632 + nav.py:86-100 on 44100-sample rows in ONE launch (k_obs_rows): 600 units (rows walked by
+    persistent workgroups, 4-5 rows each), multi-second clips in both branches, a 2-s RIR, ragged and empty RIRs, silent
+    units, distractors; against the two-kernel path and, for a sample of units, the oracle.  The waveform is optional."""
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(91)
+    sr, n_units = 44100, 600
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in (1, 1, 3, 2)]
+    lens = [sr, 2 * sr, 30000, 9001, 17000, 0]
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T) if L else None for L in lens]
+    r = make_renderer(sr, src, rirs)
+    if spectral:
+        r.rirs.build_spectra()
+    units, refs = [], {}
+    for n in range(n_units):
+        s_, h_ = int(rng.integers(0, 4)), int(rng.integers(0, 6))
+        idx = int(rng.integers(0, len(src[s_]) // sr))
+        dis = n % 7 == 3
+        units.append(UnitRequest(s_, P.window_start_sim(len(src[s_]), sr, idx), h_, silent=n % 29 == 5,
+                                 dis_sound=0 if dis else -1, dis_rir=2 if dis else -1))
+        if n < 12 and not units[-1].silent and rirs[h_] is not None:
+            refs[n] = O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx, distractor=src[0] if dis else None,
+                                          distractor_rir=rirs[2] if dis else None).astype(np.float32)
+    plan = r.plan(units)
+    ag, sg = r.render(plan, want_audiogoal=True)
+    ag2, sg2 = _two_kernel(r, plan)
+    assert float((ag - ag2).abs().max()) <= 2e-6 * float(ag2.abs().max())
+    assert float((sg - sg2).abs().max()) <= 2e-6 * float(sg2.abs().max())
+    none, sg3 = r.render(plan)                                                  # SpectrogramSensor alone: no waveform at all
+    assert none is None and torch.equal(sg3, sg)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    for n, a in refs.items():
+        check(ag[n], a)
+        check(sg[n], O.compute_spectrogram(a))
+    for n, u in enumerate(units):
+        if u.silent or rirs[u.rir] is None:
+            assert not ag[n].any() and not sg[n].any()
+
+
+def test_fused_rows_two_streams_keep_their_stashes_apart():
+    """The block-spectra stash of k_obs_rows belongs to (device, stream): launches of two streams that overlap on the GPU
+    must not see each other's spectra.  Many alternating launches with different inputs, results against single-stream."""
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(93)
+    sr = 44100
+    src = O.synth_sources(rng, sr, k=3)
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=12)]
+    r = make_renderer(sr, list(src), rirs)
+    plans = [r.plan([UnitRequest(int(rng.integers(0, 3)), 0, int(rng.integers(0, 12))) for _ in range(40)]) for _ in range(6)]
+    want = [r.render(p)[1].clone() for p in plans]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    outs = [[torch.empty_like(want[0]) for _ in plans] for _ in range(3)]
+    for rep in range(3):
+        for k, p in enumerate(plans):
+            with torch.cuda.stream(streams[k % 2]):
+                r.render(p, spectrogram_out=outs[rep][k])
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(len(plans)):
+            assert torch.equal(outs[rep][k], want[k])
+
+
+def test_fused_rows_short_steps_and_context_api_without_waveform():
+    """SS2.0 0.25-s steps at 44.1 kHz (n_valid = 11025 < out_len: one convolved block, the other two are zeros) through the
+    renderer, and a 44.1 kHz step through the context API with spectrogram only (no hand-over buffer any more)."""
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(95)
+    sr = 44100
+    src = O.synth_sources(rng, sr, k=2, seconds=3)
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, length=30000, n=4)]
+    r = make_renderer(sr, list(src), rirs, step_time=0.25, wrap=True)
+    units = [UnitRequest(n % 2, 5000 + 9000 * n, n % 4, wrap=5000 + 9000 * n >= 30000) for n in range(9)]
+    ag, sg = r.render(r.plan(units), want_audiogoal=True)
+    ag, sg = ag.cpu().numpy(), sg.cpu().numpy()
+    for n, u in enumerate(units):
+        a = O.convolve_with_rir(src[u.sound], rirs[u.rir], sr, u.t0, 0.25).astype(np.float32)
+        check(ag[n], a)
+        check(sg[n], O.compute_spectrogram(a))
+    ctx = AudioContext(sr)
+    for i, s_ in enumerate(src):
+        ctx.add_source(f"s{i}", s_[:sr])
+    r2 = make_renderer(sr, [s_[:sr] for s_ in src], rirs)
+    ctx.set_rir_bank(r2.rirs.data, r2.rirs.lengths)
+    sg_c = torch.empty((9, 65, 69, 2), device=DEV)
+    ctx.observe([n % 2 for n in range(9)], [0] * 9, [n % 4 for n in range(9)], spectrogram_out=sg_c)
+    _, sg_r = r2.render(r2.plan([UnitRequest(n % 2, 0, n % 4) for n in range(9)]))
+    torch.cuda.synchronize()
+    assert float((sg_c - sg_r).abs().max()) <= 2e-6 * float(sg_r.abs().max())

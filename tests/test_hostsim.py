@@ -353,3 +353,83 @@ def test_randomised_edge_cases(seed):
         out3, _ = hs.run([src], bank, [L], [dict(sound=0, t0=t0, rir=0)] * 3, n_valid, sr, persist=2)
         for k in range(3):
             np.testing.assert_array_equal(out3[k], out[0])
+
+
+# ---- k_obs_rows: fused observation for rows of 2-3 partition blocks (44.1 kHz) -------------------------------------------
+@pytest.mark.parametrize("spectral", [False, True])
+def test_fused_rows_44k_vs_reference_vectors(spectral):
+    """One launch at the reference's Replica rate: simulator.py:629-632 on 44100-sample rows + nav.py:86-100 -> (65, 69, 2);
+    the waveform is optional.  Time-domain bank (every RIR block transformed once, block spectra stashed for the later
+    output blocks) and spectral bank."""
+    d = case_inputs("clip1s_44k")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("clip1s_44k")
+    units = [dict(sound=0, t0=0, rir=0), dict(rir=-1)]
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [sr], units, sr, sr, row_wgs=1, spectral=spectral)
+    assert sg.shape[1:] == (65, 69, 2)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+    assert not out[1].any() and not sg[1].any()                                  # silent unit: exact zeros
+    none, sg2 = hs.run([d["source"]], planar(d["rir"]), [sr], units, sr, sr, row_wgs=4, spectral=spectral,
+                       want_audiogoal=False)                                     # SpectrogramSensor alone: no waveform
+    assert none is None
+    np.testing.assert_array_equal(sg2, sg)
+
+
+@pytest.mark.parametrize("wgs", [1, 3, 64])
+def test_fused_rows_equal_two_kernel_path(wgs):
+    """k_obs_rows against k_conv (loop kernel, forward FFTs re-run per output block) + k_spectrogram on the same inputs:
+    multi-second clips in the early and the steady branch (negative partition offsets), a 2-s RIR (6 blocks), ragged and
+    empty RIRs, a distractor, silent units in the middle of a walk - bit-identical waveforms (same products in the same
+    order), spectrograms to rounding."""
+    rng = np.random.default_rng(23)
+    sr = 44100
+    srcs = [O.synth_sources(rng, sr, k=1, seconds=s)[0] for s in (1, 3, 1)]
+    lens = [sr, 2 * sr, 0, 30000, 9001]
+    cap = 2 * sr
+    bank = np.zeros((len(lens), 2, cap), np.float32)
+    for i, L in enumerate(lens):
+        if L:
+            bank[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
+    units = [dict(sound=0, t0=0, rir=0),
+             dict(sound=1, t0=P.window_start_sim(3 * sr, sr, 2), rir=1),         # steady branch, RIR longer than the row
+             dict(rir=-1),
+             dict(sound=1, t0=P.window_start_sim(3 * sr, sr, 1), rir=3),         # early branch
+             dict(sound=0, t0=0, rir=2),                                         # empty RIR file: zero row
+             dict(sound=2, t0=0, rir=4, dis_sound=0, dis_t0=0, dis_rir=3),       # distractor (simulator.py:649-664)
+             dict(sound=1, t0=0, rir=0)]
+    a_ref, s_ref = hs.run(srcs, bank, lens, units, sr, sr, fuse=False, want_spectrogram=True)
+    a, sg = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs)
+    np.testing.assert_array_equal(a, a_ref)
+    assert np.abs(sg - s_ref).max() <= 1e-6 * np.abs(s_ref).max()
+    assert not a[2].any() and not sg[2].any() and not a[4].any() and not sg[4].any()
+    # and against the oracle, unit by unit
+    check(a[1], O.compute_audiogoal(srcs[1], np.ascontiguousarray(bank[1].T), sr, audio_index=2))
+    check(sg[1], O.compute_spectrogram(a_ref[1]))
+    ref5 = O.compute_audiogoal(srcs[2], np.ascontiguousarray(bank[4, :, :9001].T), sr, distractor=srcs[0],
+                               distractor_rir=np.ascontiguousarray(bank[3, :, :30000].T))
+    check(a[5], ref5)
+    # spectral bank, same units
+    a_s, s_s = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs, spectral=True)
+    assert np.abs(a_s - a_ref).max() <= 2e-6 * np.abs(a_ref).max()
+    assert np.abs(s_s - s_ref).max() <= 2e-6 * np.abs(s_ref).max()
+
+
+@pytest.mark.parametrize("out_len,n_valid,pad", [(44100, 11025, 0), (20000, 20000, 1), (32768, 32768, 0), (48000, 48000, 0),
+                                                  (16386, 16386, 0), (44100, 0, 0)])
+def test_fused_rows_lengths_pads_and_short_steps(out_len, n_valid, pad):
+    """Row lengths around the block boundaries (2 and 3 blocks, a last block of 2 samples, 27 pooled blocks behind one
+    output block), librosa >= 0.10 zero padding, SS2.0 0.25-s steps at 44.1 kHz (n_valid < out_len: blocks beyond
+    n_valid are zeros), n_valid = 0; wav-interleaved bank rows."""
+    rng = np.random.default_rng(out_len + n_valid)
+    src = O.synth_sources(rng, out_len, k=1, seconds=2)[0]
+    L = 25001
+    bank = np.zeros((1, 2, L + 1), np.float32)
+    bank[0, :, :L] = O.synth_rir(rng, out_len, length=L, n=1)[0]
+    units = [dict(sound=0, t0=777, rir=0, wrap=False)]
+    a_ref, s_ref = hs.run([src], bank, [L], units, n_valid, out_len, fuse=False, want_spectrogram=True, pad_mode=pad)
+    a, sg = hs.run([src], bank, [L], units, n_valid, out_len, row_wgs=2, pad_mode=pad, interleaved=True)
+    np.testing.assert_array_equal(a, a_ref)
+    assert np.abs(sg - s_ref).max() <= 1e-6 * max(1e-30, np.abs(s_ref).max())
+    assert not a[0, :, n_valid:].any()
+    check(sg[0], O.compute_spectrogram(a_ref[0], pad_mode="constant" if pad else "reflect"))
