@@ -7,7 +7,10 @@ in an HBM bank larger than the Infinity Cache) -> 2-ear FFT convolution with the
 (reference: soundspaces/simulator.py:608-701 + soundspaces/tasks/nav.py:86-100, cache-miss path).
 Workload = BASELINE.json's metric shape: 128 envs, 16 kHz, 1-s clips, 2-channel RIRs of 1 s.
 
-  python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+      N>1 without a torch.distributed environment: bench.py re-launches itself as N ranks (python -m
+      torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1, one rank per GPU over RCCL - the
+      reference's own launcher shape, ss_baselines/av_nav/single_node.sh:8-11); under torchrun it checks WORLD_SIZE == N.
 
 N>1: every rank renders its own 128 envs (weak scaling, units are independent; --scaling strong splits 128 envs over the
 ranks, BASELINE configs[3]) and the per-rank spectrogram slabs are all-gathered over RCCL on a side stream (the exchange
@@ -245,20 +248,63 @@ def dist_of(ms):
 
 
 def measured_traffic(units, sr, kernel):
-    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r2/traffic.json written by
-    scripts/gpu_profile_r2.sh with the hash of the kernel sources): null when the sources have changed since."""
+    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r3/traffic.json written by
+    scripts/gpu_profile_r3.sh with the hash of the kernel sources): null when the sources have changed since."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r2", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic.json")))
         have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.srchash")).read().strip()
         e = tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
             corr = float(e.get("fetch_correction", 1.0))
             return {"bytes": int(corr * e["fetch_bytes"] + e["write_bytes"]), "fetch_bytes_raw": int(e["fetch_bytes"]),
                     "fetch_correction": corr, "write_bytes": int(e["write_bytes"]), "tcc_hit_rate": e.get("tcc_hit_rate"),
+                    "traffic_source": "profiles/r3 rocprofv3 --pmc pass of this build (source hash matches), not measured in this run",
                     "note": e.get("note", "") + "; " + e.get("correction_note", "")}
     except Exception:
         pass
     return None
+
+
+def dry_run(args, rank, world):
+    """The multi-rank flow of this script without a GPU: ranks, barrier + max-over-ranks timing, the chunked slab exchange
+    (ss_amd.dist over gloo, CPU tensors standing in for the renderer's output) and the one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from ss_amd import planning as P
+    from ss_amd.dist import ChunkedSlabExchange
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_env = args.envs // world if args.scaling == "strong" else args.envs
+    N = n_env * args.rotations
+    shape = P.spectrogram_shape(args.sr)
+    seen = []
+    cx = ChunkedSlabExchange(N, shape, args.gather_every, device="cpu",
+                             gathered=lambda full, n: seen.append((tuple(full.shape), n, float(full[(world - 1) * args.gather_every * N, 0, 0, 0]))))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        cx.step_rows().fill_(float(rank))          # stands in for the kernels' output rows
+        cx.step_done()
+    cx.flush()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = all(sh == (world * args.gather_every * N,) + shape and last == float(world - 1) for sh, _, last in seen)
+    if rank == 0:
+        print(json.dumps({"metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
+                          "dry_run": True, "value": None, "unit": "env-steps/s", "n_gpus": world, "rccl_ranks": 0,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 5),
+                          "scaling": args.scaling, "gathers": cx.gathers, "gather_ok": bool(ok),
+                          "config": {"workload": "dry run: no kernels", "envs_per_gpu": n_env, "units_per_gpu": N}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -274,7 +320,8 @@ def main():
     ap.add_argument("--rotations", type=int, default=1, help="agent rotations rendered per env and step (BASELINE configs[2]: "
                                                              "4; the azimuths of a pair sit in adjacent bank rows)")
     ap.add_argument("--sr", type=int, default=16000)
-    ap.add_argument("--bank-mib", type=int, default=512, help="RIR bank size per GPU (> 256 MiB Infinity Cache)")
+    ap.add_argument("--bank-mib", type=int, default=1024, help="time-domain RIR bank size per GPU (4x the 256 MiB Infinity "
+                                                              "Cache: the rows of the timed region are first touches)")
     ap.add_argument("--sounds", type=int, default=102)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --envs per GPU (default); strong: --envs in total, split over the ranks (BASELINE configs[3]: "
@@ -296,11 +343,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the conv-only / spectral-bank / 2-stream side measurements")
-    ap.add_argument("--rir-bank", choices=["spectral", "time"], default="spectral",
-                    help="format of the HBM-resident RIR bank the headline loop reads: 'spectral' = block spectra computed "
-                         "once at bank load (ss_rir_spectra_f32; SoundSpaces 1.0 RIRs are static files), no forward FFT per "
-                         "step, 2x the bytes per RIR; 'time' = the reference's time-domain samples.  The other format is "
-                         "timed in the same run and reported beside it (16 kHz)")
+    ap.add_argument("--rir-bank", choices=["spectral", "time"], default="time",
+                    help="format of the HBM-resident RIR bank the headline loop reads: 'time' = the reference's time-domain "
+                         "samples (the format SURVEY 8(d) defines the metric and its algorithmic bytes on); 'spectral' = block "
+                         "spectra computed once at bank load (ss_rir_spectra_f32), no forward FFT per step, 2x the bytes per "
+                         "RIR.  The other format is timed in the same run and reported beside it")
+    ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg4"], default="headline",
+                    help="BASELINE.json configs[] presets: cfg1 = 32 envs @16 kHz; cfg2 = 128 envs x 4 rotations @44.1 kHz "
+                         "(512 units / launch); cfg4 = savi: 256 envs, 21 sounds of 1-20 s, distractor, audiogoal + "
+                         "spectrogram.  (cfg3 = --scaling strong --envs 128 on 8 GPUs.)  Explicit flags override nothing here: "
+                         "a preset sets --envs/--sr/--rotations/--workload")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no kernels: the multi-rank launch / exchange / JSON flow on CPU tensors over gloo (tests only; "
+                         "the line says dry_run and its value is not a measurement)")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
     ap.add_argument("--workload", choices=["audiogoal", "savi"], default="audiogoal",
                     help="audiogoal: the headline shape (1-s clips, no distractor).  savi: BASELINE configs[4] (semantic_audionav): "
@@ -308,10 +363,32 @@ def main():
                          "(two convolutions + add), audiogoal AND spectrogram written; use with --envs 256")
     args = ap.parse_args()
     args.spectral = args.rir_bank == "spectral"
+    if args.config == "cfg1":
+        args.envs, args.sr, args.rotations = 32, 16000, 1
+    elif args.config == "cfg2":
+        args.envs, args.sr, args.rotations = 128, 44100, 4
+    elif args.config == "cfg4":
+        args.envs, args.sr, args.rotations, args.workload = 256, 16000, 1, "savi"
 
+    # --gpus N is a request, not a label: without a torch.distributed environment this process becomes the launcher of N
+    # ranks (one per GPU; ss_baselines/av_nav/single_node.sh:8-11 does the same with torch.distributed.launch)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}"
+    if args.dry_run:
+        return dry_run(args, rank, world)
     sr = args.sr
     if args.scaling == "strong":
         assert args.envs % world == 0, "--scaling strong: --envs must divide by the number of ranks"
@@ -374,15 +451,22 @@ def main():
             idx = np.array([rng.integers(0, secs[s]) for s in snd])
             return [UnitRequest(int(s), 0 if secs[s] == 1 else int(i) * sr, int(h), dis_sound=int(d), dis_rir=int(hd))
                     for s, i, h, d, hd in zip(snd, idx, rng.integers(0, R, n_env), rng.integers(0, 3, n_env), rng.integers(0, R, n_env))]
-        descs = [r.plan(savi_units()) for _ in range(total)]
+
+        def draw_plan():
+            return r.plan(savi_units())
     else:
-        descs = [r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
-                 for _ in range(total)]
+        def draw_plan():
+            return r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
+    descs = [draw_plan() for _ in range(total)]
+    # the untimed spin-up has descriptor sets OF ITS OWN: cycling over the timed region's sets would re-read the timed
+    # region's bank rows dozens of times before the clock starts ("8(d)'s bank larger than the Infinity Cache
+    # guarantee is void")
+    spin_descs = [draw_plan() for _ in range(16)]
     t4 = r.spectrogram_shape[1]
-    fused = sr <= P.KB
+    fused = sr <= 3 * P.KB                                   # one launch per step (16 kHz: k_conv; 44.1 kHz: k_obs_rows)
     want_ag = args.with_audiogoal or not fused
 
-    spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128))
+    spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128) * 16000 // sr)
 
     def run_loop(S, gather_every, spectral, per_step_events=False):
         """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms: average over
@@ -399,14 +483,14 @@ def main():
         sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
         ag_bufs = [torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(S)] if want_ag else [None] * S
 
-        def step(k):
+        def step(k, plans=descs):
             st = streams[k % S]
             with torch.cuda.stream(st):
                 if cx is not None and not state["no_exchange"]:
-                    r.render(descs[k], spectrogram_out=cx.step_rows(streams), audiogoal_out=ag_bufs[k % S])
+                    r.render(plans[k], spectrogram_out=cx.step_rows(streams), audiogoal_out=ag_bufs[k % S])
                     cx.step_done(streams)                          # all-gather of the chunk once it is full
                 else:
-                    r.render(descs[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
+                    r.render(plans[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
 
         def fence():
             if world > 1:
@@ -434,7 +518,7 @@ def main():
         # device spin-up (clocks, TLBs, instruction caches): untimed, reported in the JSON line; the W warm-up steps follow.
         # A fixed NUMBER of steps (every rank issues the same collectives), sized for ~40 ms at the headline shape.
         for k in range(spin_steps):
-            step(k % total)
+            step(k % len(spin_descs), spin_descs)
             if k % 64 == 63:
                 torch.cuda.synchronize()                           # keep the launch queue shallow
         if spin_steps:
@@ -518,8 +602,11 @@ def main():
         kernel_ms = float(np.mean(per_step)) if per_step else 1e3 * elapsed / args.steps
         b = bytes_per_unit(sr, L, t4)
         kk = "k_conv_spec" if args.spectral else "k_conv"
-        kname = f"{kk}<FUSE=true>" if fused else f"{kk}<FUSE=false>+k_spectrogram"
-        bpu = b["fused"] if fused else b["conv"] + b["spec"]
+        if sr > P.KB:
+            kname = f"k_obs_rows<SPECTRAL={'true' if args.spectral else 'false'}>"
+        else:
+            kname = f"{kk}<FUSE=true>" if fused else f"{kk}<FUSE=false>+k_spectrogram"
+        bpu = (b["fused"] + (2 * sr * 4 if args.with_audiogoal else 0)) if fused else b["conv"] + b["spec"]
         if savi:
             bpu = 2 * (2 * L * 4) + 2 * sr * 4 + 65 * t4 * 2 * 4        # two RIRs read, waveform and spectrogram written
         ach = bpu * N / (kernel_ms * 1e-3) / 1e9
@@ -534,14 +621,15 @@ def main():
             "metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
             "value": round(world * N * args.steps / elapsed, 1),
             "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_untimed": spin_steps,
+            "n_gpus": world, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0, "steps": args.steps, "warmup": args.warmup, "spinup_steps_untimed": spin_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
                        "sampling_rate": sr, "rir_len": L, "rir_bank": "spectral" if args.spectral else "time-domain",
                        "actual_bytes_per_unit": ((2 * P.ceil_div(L, P.KB) * P.SPEC_FLOATS * 4 if args.spectral else 2 * L * 4)
-                                                 + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)),
+                                                 + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)
+                                                 + (2 * sr * 4 if (fused and want_ag) else 0)),
                        "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
                        "streams": S_auto, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -554,7 +642,7 @@ def main():
             out["roofline"]["traffic_detail"] = tr
         if step_dist:
             out["gpu_ms_per_step"] = step_dist
-        if fused:
+        if fused and sr <= P.KB:
             # FFT convolution sits at the FP32 ridge (~20 FLOP/B), so the vector-FP32 roofline is reported
             # beside the declared HBM one.  Algorithmic FLOPs per env-step (radix-2 real-FFT count 2.5 N log2 N):
             # conv 5.1 MFLOP + STFT 2.3 MFLOP @16 kHz; peak = 157.3 TFLOP/s dense FP32 vector (packed FMA) on MI355X.
@@ -571,12 +659,21 @@ def main():
                                          "kernel": "k_conv_spec<FUSE=false>" if args.spectral else "k_conv<FUSE=false>",
                                          "bytes_per_unit": b["conv"], "avg_launch_ms": round(cm, 5)}
         out.update(side)
-        if world == 1 and not args.no_plugin_path and fused and rot == 1 and not savi:
+        if fused and sr > P.KB:
+            flops = (23.1e6 + 6.4e6) * N                      # SURVEY 8(d) @44.1 kHz: conv 23.1 MFLOP + STFT 6.4 MFLOP per unit
+            tf = flops / (kernel_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "valu-fp32", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                    "frac": round(tf / 157.3, 4), "flops_per_unit": 29.5e6}
+        if world == 1 and not args.no_plugin_path and sr <= P.KB and rot == 1 and not savi:
             srcs = [r.sources._host[i] for i in range(len(r.sources))]
             out["plugin_path"] = measure_plugin_path(torch, np, dev, sr, n_env, bank, args.sounds, srcs,
                                                      min(args.steps, 400), min(args.warmup, 50),
                                                      spectra if args.spectral else None)
             out["plugin_path"]["rir_bank"] = "spectral" if args.spectral else "time-domain"
+            # the figure to quote as "the plugin path": reference-style Python simulator objects (their attribute writes
+            # included); `columns` - a struct-of-arrays vector env the reference does not have - is the ceiling
+            out["plugin_path"]["headline"] = dict(out["plugin_path"]["bound_sims"], mode="bound_sims")
+            out["plugin_path"]["ceiling"] = dict(out["plugin_path"]["columns"], mode="columns")
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)

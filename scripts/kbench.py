@@ -96,13 +96,13 @@ for N in [int(x) for x in a.sizes.split(",")]:
     descs = [r.plan_arrays(snd(), np.zeros(N, np.int64), rng.integers(0, R, N)) for _ in range(a.distinct)]
     ag = torch.empty((N, 2, sr), device=dev); sg = torch.empty((N,) + r.spectrogram_shape, device=dev)
     res = {}
-    if a.raw and sr <= 16384:
+    if a.raw:
         cf = [raw_fused(d, sg) for d in descs]; cc = [raw_conv(d, ag) for d in descs]
         if a.only in ("", "fused"): res["fused"] = timeit(lambda k: cf[k % a.distinct](), a.reps)
         if a.only in ("", "conv"): res["conv"] = timeit(lambda k: cc[k % a.distinct](), a.reps)
         print(f"N={N} sr={sr} raw {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} dbg={os.environ.get('SS_HIP_DBG', '0')} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)
         continue
-    if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % a.distinct], spectrogram_out=sg, audiogoal_out=(ag if sr > 16384 else None)), a.reps)
+    if a.only in ("", "fused"): res["fused"] = timeit(lambda k: r.render(descs[k % a.distinct], spectrogram_out=sg), a.reps)
     if a.only in ("", "conv"): res["conv"] = timeit(lambda k: r.render_audiogoal(descs[k % a.distinct], out=ag), a.reps)
     if a.only in ("", "spec"): res["spec"] = timeit(lambda k: ops.spectrogram_into(ag, sg), a.reps)
     print(f"N={N} sr={sr} {'spectral' if a.spectral else 'time'} map={os.environ.get('SS_HIP_XCD_MAP', '0')} sort={int(a.sort)} " + " ".join(f"{k}={v:.1f}us" for k, v in res.items()), flush=True)

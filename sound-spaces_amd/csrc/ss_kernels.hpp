@@ -1206,6 +1206,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 // are defined on the time-domain bank, the actual traffic of this kernel is about twice that - reported as such.
 // Same unit descriptors as k_conv (term = {bank entry | -1, first window slot, m_min, count}); rir_len[entry] still
 // says how many blocks of the entry are non-zero.
+template <bool NT = true>
 __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, const f32x4* hp, int slot, bool accumulate,
                                                    c32 (&acc)[2][8]) {
     const f32x4* sp = spec + (size_t)slot * (kSpecComplex / 2) + t;
@@ -1213,7 +1214,18 @@ __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, con
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) { hv[s][hh] = ld_stream(hp + (s * 4 + hh) * 1024); sv[s][hh] = sp[(s * 4 + hh) * 1024]; }
+        for (int hh = 0; hh < 4; ++hh) {
+            hv[s][hh] = NT ? ld_stream(hp + (s * 4 + hh) * 1024) : hp[(s * 4 + hh) * 1024];
+            sv[s][hh] = sp[(s * 4 + hh) * 1024];
+        }
+#if defined(SS_ROWS_ABL)
+    if (SS_ROWS_ABL & 4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = f32x4{1.f, 0.f, 1.f, 0.f};
+    }
+#endif
     // ALL sixteen loads are issued before the first multiply: left alone, the scheduler starts the first product after
     // four loads and puts an s_waitcnt vmcnt(2) in front of it (seen in the ISA) - the wave then sits out one full memory
     // latency with a quarter of its loads in flight before it issues the other twelve
@@ -1578,12 +1590,13 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 // renders the output blocks j = 0 .. nb_rows-1 IN ORDER and streams the STFT behind them:
 //
 //   convolution of block j:  Y_j = sum over (term, RIR block i) of H'_i * S'_{j-i}  (as k_conv / k_conv_spec).
-//     Time-domain bank: every RIR block is transformed ONCE per row.  The block spectrum H'_i is multiplied into Y_j
-//     straight from the registers of the forward item stage and, if a later output block needs it again (44.1 kHz,
-//     1-s clip: H'_0 for j = 1, 2; H'_1 for j = 2), written to the workgroup's private stash in global memory in the
-//     kernels' register order - the on-the-fly equivalent of the spectral bank, L2 / Infinity-Cache resident
-//     (<= 6 x 128 KiB per CU).  Later blocks read it back with the same coalesced 16-byte loads as the window spectra.
-//     (k_conv re-ran the forward FFTs per output block: 6 instead of 3 at 44.1 kHz, plus 3 workgroups per row.)
+//     Time-domain bank: the forward FFT of RIR block i is re-run wherever H'_i is needed (44.1 kHz, 1-s clip: 6 per
+//     row).  With a stash (p.stash != nullptr; launcher switch SS_HIP_ROWS_STASH) every block is transformed ONCE: H'_i
+//     is multiplied into Y_j straight from the registers of the forward item stage and, if a later output block needs
+//     it again (H'_0 for j = 1, 2; H'_1 for j = 2), written to the workgroup's private stash in global memory in the
+//     kernels' register order - the on-the-fly equivalent of the spectral bank - and read back with the same coalesced
+//     16-byte loads as the window spectra.  Measured (profiles/r3/NOTES.md): the 3 saved FFTs and the 640 KiB of extra
+//     L2 / Infinity-Cache traffic per row cancel (96.9 vs 91.5 us at 128 units, 359 vs 360 us at 512).
 //     Spectral bank: H'_i comes from the bank, no forward FFT and no stash.
 //   STFT behind block j:  hann(400) centred in 512 with hop 160: pooled time block b (frames 4b .. 4b+3) needs samples
 //     [640 b - 256, 640 b + 736).  After block j the row is known up to (j+1) kB, so the pooled blocks
@@ -1595,6 +1608,17 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 // Unit descriptors, silent units, distractor term, n_valid < out_len (0.25-s SS2.0 steps: blocks beyond n_valid are
 // zeros without any transform) as in k_conv.  SS_FLAG_CROSSFADE is not served here (the launcher keeps the two-kernel
 // path for cross-faded rows longer than one block).
+// timing ablations (scripts/gpu_rows_ladder.sh builds with -DSS_ROWS_ABL=<mask>; results are WRONG, only the time is read):
+//   1 no STFT phase   2 no stash traffic (nothing kept, stashed products skipped)   4 no window-spectrum loads
+//   8 no forward passes (item stage on whatever the LDS holds)   16 no inverse passes
+// and design variants (results CORRECT):  32 no stash at all: every use of a block spectrum re-runs its forward FFT
+//   64 stash RIR block 0 only   128 stash read back with plain (L1/L2-allocating) loads   256 half of the workgroups of an
+//   XCD start ~7 us late (de-synchronises the CUs' memory phases)
+#if defined(SS_ROWS_ABL)
+constexpr int kRowsAbl = SS_ROWS_ABL;
+#else
+constexpr int kRowsAbl = 0;
+#endif
 constexpr int kTailFloats = 640;            // context handed from output block j to j+1 (nb_rows <= 3: 640, 384)
 constexpr int kRowsMaxBlocks = 27;          // pooled blocks behind one output block (32768-sample rows: 25 + 27)
 constexpr int kRowsResFloats = kBins4 * kRowsMaxBlocks;
@@ -1621,16 +1645,18 @@ __device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, 
             return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
         });
     }
-    lds_barrier();
-    pass2<false>(lds, tw.p2, t);
-    lds_barrier();
-    pass3_fwd(lds, t);
+    if (!(kRowsAbl & 8)) {
+        lds_barrier();
+        pass2<false>(lds, tw.p2, t);
+        lds_barrier();
+        pass3_fwd(lds, t);
+    }
     lds_barrier();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         f32x4 sv[4];
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) sv[hh] = sp[(s * 4 + hh) * 1024];
+        for (int hh = 0; hh < 4; ++hh) sv[hh] = (kRowsAbl & 4) ? f32x4{1.f, 0.f, 1.f, 0.f} : sp[(s * 4 + hh) * 1024];
         c32 v[8];
         item_load_fwd(lds, s ? tw.i1 : tw.i0, t + 1024 * s, v);
         if (st) {
@@ -1722,7 +1748,10 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
     const int G = (int)gridDim.x;
     const int nb_rows = (p.out_len + kB - 1) / kB;
     const size_t blk_f4 = kSpecComplex / 2;               // f32x4 per block spectrum
-    f32x4* stash = SPECTRAL ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if ((kRowsAbl & 256) && ((blockIdx.x >> 3) & 1)) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+#endif
+    f32x4* stash = (SPECTRAL || !p.stash) ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
     for (int row = row_slot(blockIdx.x, G, p.xcd_map); row < n_rows; row += G) {
         const int unit = row >> 1, ch = row & 1;
         i32x4 dws[2];
@@ -1776,11 +1805,13 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                         } else {
                             const int sidx = term * p.stash_nbh + i;
                             if ((computed >> sidx) & 1u) {
-                                spec_block_product(p.spec, ti, stash + (size_t)sidx * blk_f4 + ti, slot, true, acc);
+                                if (!(kRowsAbl & 2))
+                                    spec_block_product<!(kRowsAbl & 128)>(p.spec, ti, stash + (size_t)sidx * blk_f4 + ti, slot, true, acc);
                             } else {
                                 // needed again by a later output block of this row?  (m grows with j)
-                                const bool keep = j + 1 < p.nb_y && m + 1 < m_min + m_cnt;
-                                f32x4* st = keep ? stash + (size_t)sidx * blk_f4 : nullptr;
+                                const bool keep = stash != nullptr && j + 1 < p.nb_y && m + 1 < m_min + m_cnt &&
+                                                  !(kRowsAbl & 32) && (!(kRowsAbl & 64) || i == 0);
+                                f32x4* st = keep && !(kRowsAbl & 2) ? stash + (size_t)sidx * blk_f4 : nullptr;
                                 const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
                                 if (lds_used) lds_barrier();          // the previous block's item reads of layout B are done
                                 conv_block_stash<true>(lds, p, tw, ti, h, i, slot, st, acc);
@@ -1792,16 +1823,20 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                     }
                 }
             }
-            if (any) {
+            if (any && !(kRowsAbl & 16)) {
                 if (lds_used) lds_barrier();
                 items_to_time(lds, tw, tl, acc, y);
             } else {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+                for (int a = 0; a < 8; ++a) y[a] = (kRowsAbl & 16) ? acc[0][a] : mk2(0.f, 0.f);
             }
             if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row, j, y);
             const bool last = j == nb_rows - 1;
             const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
+            if (kRowsAbl & 1) {
+                if (y[0].x == 123.456f) p.sgram[0] = y[7].y;      // keeps the convolution alive
+                lds_barrier();
+            } else
             rows_stft_phase(lds, p, tl, unit, ch, j, b0, b1, last, y, s_win, s_tw512, wq, s_res, s_tail);
             b0 = b1;
         }

@@ -235,7 +235,7 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
 // k_obs_rows: `wgs` persistent workgroups walk the (unit, ear) rows; hspec != nullptr selects the spectral-bank variant
 int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const int* rir_len, const int* desc, float* out,
                 float* sgram, int n_units, long long us, int cs, int es, int cap, int h_blocks, int n_valid, int out_len,
-                int pad_mode, int wgs, int no_distractor) {
+                int pad_mode, int wgs, int no_distractor, int use_stash) {
     if (out_len <= ssk::kB || out_len > 3 * ssk::kB || !sgram) return -1;
     ssk::ConvParams p;
     p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
@@ -252,7 +252,7 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     const int n_rows = 2 * n_units, grid = wgs < n_rows ? wgs : n_rows;
     std::vector<float> stash;
     p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
-    if (!hspec && p.nb_y > 1) {
+    if (!hspec && p.nb_y > 1 && use_stash) {
         p.stash_nbh = (cap + ssk::kB - 1) / ssk::kB;
         p.stash_terms = p.n_terms;
         stash.assign(static_cast<size_t>(grid) * p.stash_terms * p.stash_nbh * 2 * ssk::kSpecComplex, 12345.0f);

@@ -33,7 +33,7 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True):
+        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -100,7 +100,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         rc = L.hs_obs_rows(_p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(hspec, ctypes.c_float) if spectral else None,
                            _p(rl, ctypes.c_int), _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
                            _p(sg, ctypes.c_float), int(N), ctypes.c_longlong(us), int(cs), int(es), int(cap), int(hb), int(n_valid),
-                           int(out_len), int(pad_mode), int(row_wgs), int(no_dis))
+                           int(out_len), int(pad_mode), int(row_wgs), int(no_dis), int(row_stash))
         assert rc == 0, rc
         return (out if want_audiogoal else None), sg
     if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)

@@ -356,16 +356,16 @@ def test_randomised_edge_cases(seed):
 
 
 # ---- k_obs_rows: fused observation for rows of 2-3 partition blocks (44.1 kHz) -------------------------------------------
-@pytest.mark.parametrize("spectral", [False, True])
-def test_fused_rows_44k_vs_reference_vectors(spectral):
+@pytest.mark.parametrize("spectral,stash", [(False, False), (False, True), (True, False)])
+def test_fused_rows_44k_vs_reference_vectors(spectral, stash):
     """One launch at the reference's Replica rate: simulator.py:629-632 on 44100-sample rows + nav.py:86-100 -> (65, 69, 2);
-    the waveform is optional.  Time-domain bank (every RIR block transformed once, block spectra stashed for the later
-    output blocks) and spectral bank."""
+    the waveform is optional.  Time-domain bank (forward FFTs re-run per use, or every RIR block transformed once and its
+    spectrum stashed for the later output blocks) and spectral bank."""
     d = case_inputs("clip1s_44k")
     sr = d["sr"]
     ref_a, ref_s, stride = case_outputs("clip1s_44k")
     units = [dict(sound=0, t0=0, rir=0), dict(rir=-1)]
-    out, sg = hs.run([d["source"]], planar(d["rir"]), [sr], units, sr, sr, row_wgs=1, spectral=spectral)
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [sr], units, sr, sr, row_wgs=1, spectral=spectral, row_stash=stash)
     assert sg.shape[1:] == (65, 69, 2)
     check(out[0][:, ::stride], ref_a)
     check(sg[0], ref_s)
@@ -400,6 +400,9 @@ def test_fused_rows_equal_two_kernel_path(wgs):
              dict(sound=1, t0=0, rir=0)]
     a_ref, s_ref = hs.run(srcs, bank, lens, units, sr, sr, fuse=False, want_spectrogram=True)
     a, sg = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs)
+    a_st, sg_st = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs, row_stash=True)      # block spectra stashed
+    np.testing.assert_array_equal(a_st, a)
+    np.testing.assert_array_equal(sg_st, sg)
     np.testing.assert_array_equal(a, a_ref)
     assert np.abs(sg - s_ref).max() <= 1e-6 * np.abs(s_ref).max()
     assert not a[2].any() and not sg[2].any() and not a[4].any() and not sg[4].any()
