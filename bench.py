@@ -441,64 +441,100 @@ def main():
     total = args.warmup + args.steps
     rot = args.rotations
 
-    def draw_rir():                                          # rotations > 1: first row of an azimuth group of `rot` rows
-        return rng.integers(0, R // rot, n_env) * rot if rot > 1 else rng.integers(0, R, n_env)
-    if savi:
-        from ss_amd.renderer import UnitRequest
+    # ---- the steps: unit columns {sound, t0, rir, (distractor)} per step, drawn once; the SAME columns feed the product
+    # path (ss_ctx_observe: planning inside the timed region) and the pre-planned descriptors of the kernel-rate passes
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import UnitRequest
 
-        def savi_units():
+    def draw_cols():
+        if savi:
             snd = rng.integers(0, 21, n_env)
             idx = np.array([rng.integers(0, secs[s]) for s in snd])
-            return [UnitRequest(int(s), 0 if secs[s] == 1 else int(i) * sr, int(h), dis_sound=int(d), dis_rir=int(hd))
-                    for s, i, h, d, hd in zip(snd, idx, rng.integers(0, R, n_env), rng.integers(0, 3, n_env), rng.integers(0, R, n_env))]
+            return dict(sound=snd.astype(np.int32), t0=np.array([0 if secs[s] == 1 else int(i) * sr for s, i in zip(snd, idx)], np.int32),
+                        rir=rng.integers(0, R, n_env).astype(np.int32), dis_sound=rng.integers(0, 3, n_env).astype(np.int32),
+                        dis_rir=rng.integers(0, R, n_env).astype(np.int32))
+        snd = rng.integers(0, args.sounds, n_env)
+        base = rng.integers(0, R // rot, n_env) * rot          # rotations > 1: first row of an azimuth group of `rot` rows
+        return dict(sound=np.repeat(snd, rot).astype(np.int32), t0=np.zeros(N, np.int32),
+                    rir=(np.repeat(base, rot) + np.tile(np.arange(rot), n_env)).astype(np.int32))
 
-        def draw_plan():
-            return r.plan(savi_units())
-    else:
-        def draw_plan():
-            return r.plan_arrays(rng.integers(0, args.sounds, n_env), np.zeros(n_env, np.int64), draw_rir(), rotations=rot)
-    descs = [draw_plan() for _ in range(total)]
-    # the untimed spin-up has descriptor sets OF ITS OWN: cycling over the timed region's sets would re-read the timed
-    # region's bank rows dozens of times before the clock starts ("8(d)'s bank larger than the Infinity Cache
-    # guarantee is void")
-    spin_descs = [draw_plan() for _ in range(16)]
+    def plan_of(c):
+        if savi:
+            return r.plan([UnitRequest(int(s), int(t), int(h), dis_sound=int(d), dis_rir=int(hd))
+                           for s, t, h, d, hd in zip(c["sound"], c["t0"], c["rir"], c["dis_sound"], c["dis_rir"])])
+        return r.plan_arrays(c["sound"][::rot], np.zeros(n_env, np.int64), c["rir"][::rot], rotations=rot)
+    cols = [draw_cols() for _ in range(total)]
+    descs = [plan_of(c) for c in cols]
+    # the untimed spin-up has steps OF ITS OWN: cycling over the timed region's steps would re-read the timed region's bank
+    # rows dozens of times before the clock starts ("8(d)'s bank-larger-than-the-Infinity-Cache guarantee is void")
+    spin_cols = [draw_cols() for _ in range(16)]
+    spin_descs = [plan_of(c) for c in spin_cols]
     t4 = r.spectrogram_shape[1]
     fused = sr <= 3 * P.KB                                   # one launch per step (16 kHz: k_conv; 44.1 kHz: k_obs_rows)
     want_ag = args.with_audiogoal or not fused
+    lengths_dev = torch.full((R,), L, dtype=torch.int32, device=dev)
+    ctx = AudioContext(sr, max_window_sets=max(256, 4 * args.sounds))
+    for i in range(len(r.sources)):
+        ctx.add_source(f"sound{i}", r.sources._host[i])
+    ctx.set_rir_bank(bank, lengths_dev)
 
     spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128) * 16000 // sr)
 
-    def run_loop(S, gather_every, spectral, per_step_events=False):
-        """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms: average over
-        the region from two HIP events on the launch stream, or the per-step list with per_step_events, note).
+    def run_loop(S, gather_every, spectral, per_step_events=False, lanes=0):
+        """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms per step from
+        HIP events on the launch stream: the region average, or the per-step list with per_step_events; note).
+        lanes = 0: pre-planned descriptors through the stateless entry points on S torch streams (kernel-rate passes; with
+        S = 1 the event average IS the kernel's average launch duration, the figure the rocprofv3 kernel trace reports).
+        lanes >= 1: the product path, ss_ctx_observe on the step's unit columns (planning, window cache, descriptor ring in
+        the timed region); lanes = 2: its overlap mode (consecutive steps on two internal streams, joined when a slab is
+        gathered and at the end of the region).
         Per-step event records put a marker packet between consecutive launches (measured: +2-3 us per step), so the
         headline loop records only the two ends and the distribution comes from a separate pass."""
         r.rirs.spectra = spectra if spectral else None
+        use_ctx = lanes >= 1
+        if use_ctx:
+            ctx.set_rir_bank(bank, lengths_dev)                    # (drops the spectral form)
+            if spectral:
+                ctx.set_rir_spectra(spectra)
+            ctx.set_overlap(lanes)
         cx = None
         if world > 1 and gather_every > 0:
             cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev,
                                      exchange_cls=PeerCopyExchange if args.exchange == "peercopy" else None)
         ex = cx.exchange if cx is not None else None
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
-        sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S))]
-        ag_bufs = [torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(S)] if want_ag else [None] * S
+        sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S, lanes))]
+        ag_bufs = ([torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(max(S, lanes))] if want_ag
+                   else [None] * max(S, lanes))
 
-        def step(k, plans=descs):
+        def render(k, plans, columns, rows, ag):
+            if use_ctx:
+                ctx.observe(spectrogram_out=rows, audiogoal_out=ag, **columns[k])
+            else:
+                r.render(plans[k], spectrogram_out=rows, audiogoal_out=ag)
+
+        def step(k, plans=descs, columns=cols):
             st = streams[k % S]
             with torch.cuda.stream(st):
                 if cx is not None and not state["no_exchange"]:
-                    r.render(plans[k], spectrogram_out=cx.step_rows(streams), audiogoal_out=ag_bufs[k % S])
+                    render(k, plans, columns, cx.step_rows(streams), ag_bufs[k % len(ag_bufs)])
+                    if use_ctx and cx.will_gather():
+                        ctx.join()                                 # the slab is complete once both lanes have drained
                     cx.step_done(streams)                          # all-gather of the chunk once it is full
                 else:
-                    r.render(plans[k], spectrogram_out=sg_buf[k % len(sg_buf)], audiogoal_out=ag_bufs[k % S])
+                    render(k, plans, columns, sg_buf[k % len(sg_buf)], ag_bufs[k % len(ag_bufs)])
 
         def fence():
+            if use_ctx:
+                ctx.join()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
 
         def flush():
             if cx is not None and not state["no_exchange"]:
+                if use_ctx:
+                    ctx.join()
                 cx.flush(streams)                                  # partial last chunk + wait
 
         note = None
@@ -518,11 +554,15 @@ def main():
         # device spin-up (clocks, TLBs, instruction caches): untimed, reported in the JSON line; the W warm-up steps follow.
         # A fixed NUMBER of steps (every rank issues the same collectives), sized for ~40 ms at the headline shape.
         for k in range(spin_steps):
-            step(k % len(spin_descs), spin_descs)
+            step(k % len(spin_descs), spin_descs, spin_cols)
             if k % 64 == 63:
+                if use_ctx:
+                    ctx.join()
                 torch.cuda.synchronize()                           # keep the launch queue shallow
         if spin_steps:
             flush()
+            if use_ctx:
+                ctx.join()
             torch.cuda.synchronize()
         for k in range(args.warmup):
             step(k)
@@ -537,7 +577,9 @@ def main():
             step(k)
             if evs and per_step_events:
                 evs[k - args.warmup + 1].record(streams[0])
-        if evs and not per_step_events:
+        if use_ctx:
+            ctx.join()                                             # the launch stream waits for both lanes: the closing
+        if evs and not per_step_events:                            # event then covers all of the region's work
             evs[1].record(streams[0])
         flush()
         fence()
@@ -550,6 +592,8 @@ def main():
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+        if use_ctx:
+            ctx.set_overlap(1)
         return elapsed, per_step, note
 
     spectra = None
@@ -557,29 +601,40 @@ def main():
         r.rirs.build_spectra()
         spectra = r.rirs.spectra
     exchanging = world > 1 and args.exchange != "none"
-    S_auto = args.streams if args.streams > 0 else (2 if exchanging else 1)
     G_head = args.gather_every if exchanging else 0
-    elapsed, per_step, exchange_note = run_loop(S_auto, G_head, args.spectral)
+    LANES = 2 if args.streams == 0 else max(1, min(2, args.streams))
+
+    def rate(e):
+        return {"value": round(world * N * args.steps / e, 1), "ms_per_step": round(1e3 * e / args.steps, 5)}
+    # ---- headline: the product path (one call site, ss_ctx_observe, overlap mode), exchange on when there are ranks ------
+    elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, lanes=LANES)
     side = {}
     step_dist = None
-    if world == 1 and S_auto == 1 and not args.no_secondary:
+    # ---- the kernel's own rate: pre-planned descriptors, ONE stream - per-launch durations are separable only without
+    # overlap, and this is the average the rocprofv3 kernel trace of the same command reports for the kernel
+    per_step = None
+    if rank == 0 or world > 1:
+        e_k, per_step, _ = run_loop(1, 0, args.spectral)
+        side["preplanned_single_stream"] = dict(rate(e_k), note="stateless entry point, descriptors planned outside the timed "
+                                                "region, one stream: the kernel rate (r1 / r2 headline protocol)")
+    if world == 1 and not args.no_secondary:
         _, ps, _ = run_loop(1, 0, args.spectral, per_step_events=True)
         step_dist = dist_of(ps)
-        step_dist["note"] = "separate pass with one HIP event record per step (the records themselves add 2-3 us per step)"
+        step_dist["note"] = "separate single-stream pass with one HIP event record per step (the records themselves add 2-3 us per step)"
+        e1, _, _ = run_loop(1, 0, args.spectral, lanes=1)
+        side["ctx_single_stream"] = dict(rate(e1), note="ss_ctx_observe without overlap (a caller that joins every step)")
     if exchanging and not args.no_secondary:
-        e1, _, _ = run_loop(S_auto, 1, args.spectral)             # per-step gather, same run
-        side["exchange_per_step_gather"] = {"value": round(world * N * args.steps / e1, 1), "ms_per_step": round(1e3 * e1 / args.steps, 5)}
-        e0, _, _ = run_loop(S_auto, 0, args.spectral)             # no collective (the reference's DD-PPO arrangement)
-        side["exchange_none"] = {"value": round(world * N * args.steps / e0, 1), "ms_per_step": round(1e3 * e0 / args.steps, 5)}
+        e1, _, _ = run_loop(1, 1, args.spectral, lanes=LANES)      # per-step gather, same run
+        side["exchange_per_step_gather"] = rate(e1)
+        e0, _, _ = run_loop(1, 0, args.spectral, lanes=LANES)      # no collective (the reference's DD-PPO arrangement)
+        side["exchange_none"] = rate(e0)
     if world == 1 and not args.no_secondary:
-        e2, _, _ = run_loop(2, 0, args.spectral)                  # consecutive steps on two streams
-        side["two_streams"] = {"value": round(N * args.steps / e2, 1), "ms_per_step": round(1e3 * e2 / args.steps, 5)}
-        eo, ps_o, _ = run_loop(1, 0, not args.spectral)           # the other RIR bank format
-        side["spectral_bank" if not args.spectral else "time_domain_bank"] = {
-            "value": round(N * args.steps / eo, 1), "ms_per_step": round(1e3 * eo / args.steps, 5),
-            "avg_launch_ms": round(float(np.mean(ps_o)), 5),
-            "note": "RIR bank stored as block spectra (ss_rir_spectra_f32): no forward FFT per step, 2x the bytes per RIR "
-                    "(actual reads per unit: 2*2*L*4 + window spectrum from L2)" if not args.spectral else "time-domain bank"}
+        eo, _, _ = run_loop(1, 0, not args.spectral, lanes=LANES)  # the other RIR bank format, same protocol as the headline
+        _, ps_o, _ = run_loop(1, 0, not args.spectral)
+        side["spectral_bank" if not args.spectral else "time_domain_bank"] = dict(
+            rate(eo), avg_launch_ms=round(float(np.mean(ps_o)), 5),
+            note=("RIR bank stored as block spectra (ss_rir_spectra_f32): no forward FFT per step, 2x the bytes per RIR "
+                  "(actual reads per unit: 2*2*L*4 + window spectrum from L2)" if not args.spectral else "time-domain bank"))
     r.rirs.spectra = spectra if args.spectral else None
 
     # ---- secondary measurement: the convolution kernel alone (audiogoal written), same inputs -------------
@@ -631,10 +686,16 @@ def main():
                                                  + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)
                                                  + (2 * sr * 4 if (fused and want_ag) else 0)),
                        "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
-                       "streams": S_auto, "kernel": kname},
+                       "path": "ss_ctx_observe (planner + window cache + descriptor ring inside the timed region), "
+                               f"{LANES} internal stream(s)" + (", consecutive steps overlap" if LANES > 1 else ""),
+                       "streams": LANES, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
-                         "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5)},
+                         "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5),
+                         "pass": "single-stream pass of the same run over the same steps (preplanned_single_stream): per-launch "
+                                 "durations are only separable without overlap; HIP events around its timed region",
+                         "pipeline_achieved": round(bpu * N / (elapsed / args.steps) / 1e9, 1),
+                         "pipeline_frac": round(bpu * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         tr = measured_traffic(N, sr, kname)
         if tr is not None:

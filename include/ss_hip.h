@@ -142,7 +142,9 @@ int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mod
  * source-window spectra it needs in a bounded cache, uploads the descriptors and launches.  A C caller therefore needs
  * neither ss_amd/planning.py nor the opaque spectrum slots of the entry points above.
  *
- * A context is bound to the HIP device that is current when it is created and serves one stream at a time.
+ * A context is bound to the HIP device that is current when it is created.  Calls must come from one host thread at a time;
+ * consecutive calls may name different streams (the library orders the shared window-spectra pool between them), and
+ * ss_ctx_set_overlap lets the library alternate two internal streams itself.
  * ---------------------------------------------------------------------------------------------------------------*/
 typedef struct ss_ctx ss_ctx;
 
@@ -186,6 +188,16 @@ int ss_ctx_set_rir_spectra(ss_ctx* ctx, const float* hspec, int h_blocks);
 /* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
  * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
 int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);
+/* Overlap mode.  ss_ctx_set_overlap(ctx, 2): consecutive ss_ctx_observe calls run on two internal streams in turn, each
+ * ordered behind what the CALLER's stream holds at the time of the call (the consumers of the output rows it overwrites,
+ * uploads of the RIR rows it reads), so the head of step k+1 (descriptor and row loads: HBM latency, nothing to compute)
+ * overlaps the tail of step k (STFT: no memory traffic) - what the reference's serial per-env loop
+ * (ss_baselines/common/sync_vector_env.py:397-410) cannot do.  Results become visible to a stream through
+ * ss_ctx_join(ctx, stream) (the stream waits for every step issued so far); a caller that needs step k before it issues
+ * step k+1 joins every step and gets the single-stream behaviour.  n_streams = 1 switches back (synchronises the device).
+ * Steps must write disjoint output rows while they are in flight (rollout rows are). */
+int ss_ctx_set_overlap(ss_ctx* ctx, int n_streams);
+int ss_ctx_join(ss_ctx* ctx, void* stream);
 /* One step straight from the simulators' state, struct-of-arrays (ss_amd/vector.py::VectorSimState: the int64 columns a
  * vector env keeps per env; HOST memory, n entries each).  Does, for all envs at once, what SoundSpacesSim does per env:
  *   silent = step_count > duration (simulator.py:610) or sound < 0;   t0 = clip is 1 s ? 0 : audio_index * sr (:629-634);

@@ -26,6 +26,9 @@ constexpr int kDirectDescUnits = 256;   // steps up to this size read their desc
 constexpr int kRing = 16;         // descriptor ring slots (steps in flight before a slot is reused)
 constexpr int kGroup = 4;         // slots released per completion event
 constexpr int kGuardTicks = 8;    // a cache entry used within the last kGuardTicks observe() calls is never evicted
+                                  // (overlap mode: kRing - steps on the other lane may still be reading it; whatever is
+                                  //  older than a full ring has finished, see the ring's completion events)
+constexpr int kLanes = 2;         // internal streams of the overlap mode (ss_ctx_set_overlap)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }   // a >= 0, b > 0
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
@@ -99,6 +102,22 @@ struct Context {
     std::vector<int> sim_scratch;                 // ss_ctx_observe_sims: unit columns of the step
     // scratch of the last plan
     std::vector<int> new_win;                     // 5 ints per new window
+    std::vector<int> new_entries;                 // cache entries inserted by the last plan (rolled back if the step fails)
+    bool plan_only_keys = false;                  // ss_ctx_plan inserted keys whose spectra were never computed
+    hipStream_t last_stream = nullptr;            // stream of the last ss_ctx_observe that launched anything
+    bool have_last_stream = false;
+    hipEvent_t ev_xstream = nullptr;              // orders a new stream behind the previous one (pool reads / writes)
+    // overlap mode (ss_ctx_set_overlap): consecutive steps alternate between internal streams ("lanes")
+    int n_lanes = 1, lane_next = 0;
+    hipStream_t lane_stream[kLanes] = {};
+    bool lane_dirty[kLanes] = {};                 // work issued on the lane since the last ss_ctx_join
+    hipEvent_t ev_lane[kLanes] = {};              // join: "everything issued on the lane so far"
+    hipEvent_t ev_in = nullptr;                   // the caller's stream at the time of the call
+    hipEvent_t ev_win[kLanes] = {};               // after the lane's latest k_source_windows launch
+    long long win_seq[kLanes] = {};               // ... and how many it has recorded
+    long long win_seen[kLanes][kLanes] = {};      // [waiting lane][recording lane]: highest seq already waited for
+    hipEvent_t ev_done2[kRing / kGroup] = {};     // ring release, lane 1's half of a group (ev_done: lane 0 / single stream)
+    bool lanes_made = false;
 };
 
 inline uint64_t make_key(int sound, long long t0, bool wrap) {
@@ -155,7 +174,7 @@ inline int cache_get(Context& c, int sound, long long t0, bool wrap, int nbh_max
         c.free_list.pop_back();
     } else {
         e = c.lru_tail;
-        if (e < 0 || c.entries[e].tick > c.tick - kGuardTicks) {
+        if (e < 0 || c.entries[e].tick > c.tick - (c.n_lanes > 1 ? kRing : kGuardTicks)) {
             cache_grow(c);
             e = c.free_list.back();
             c.free_list.pop_back();
@@ -171,12 +190,30 @@ inline int cache_get(Context& c, int sound, long long t0, bool wrap, int nbh_max
     x.key = key; x.m_min = ws.m_min; x.count = ws.count; x.tick = c.tick; x.used = true;
     lru_push_front(c, e);
     c.map.emplace(key, e);
+    c.new_entries.push_back(e);
     for (int k = 0; k < ws.count; ++k) {
         const long long start = t0 + (long long)(ws.m_min + k - 1) * c.kb;
         const int row[5] = {c.src_off[sound], c.src_len[sound], static_cast<int>(start), wrap ? 1 : 0, e * c.stride + k};
         c.new_win.insert(c.new_win.end(), row, row + 5);
     }
     return e;
+}
+
+// A step that fails after its plan (allocation, copy, launch) never computes the spectra of the keys the plan inserted:
+// take them out again, or the next plan would report them as hits on pool slots that hold nothing.
+// (An entry evicted to make room is simply gone: its key re-plans as a miss.)
+inline void cache_rollback(Context& c) {
+    for (int e : c.new_entries) {
+        Entry& x = c.entries[e];
+        if (!x.used) continue;
+        auto it = c.map.find(x.key);
+        if (it != c.map.end() && it->second == e) c.map.erase(it);
+        lru_unlink(c, e);
+        x = Entry{};
+        c.free_list.push_back(e);
+    }
+    c.new_entries.clear();
+    c.new_win.clear();
 }
 
 struct PlanResult {
@@ -189,10 +226,38 @@ inline int plan_units(Context& c, const ss_units* u, int n, int* desc, PlanResul
     if (!u || n < 0 || (n > 0 && (!u->sound || !u->t0 || !u->rir))) return SS_EINVAL;
     const int nbh_max = c.rir_cap > 0 ? ceil_div(c.rir_cap, c.kb) : 1;
     const int nby = c.n_valid > 0 ? ceil_div(c.n_valid, c.kb) : 1;
+    const int n_src = static_cast<int>(c.src_len.size());
+    // Pass 1: every reason to refuse the step, BEFORE the cache is touched (planning is transactional: a refused step
+    // leaves no keys behind).  Window sets are a pure function of (clip length, t0), so "does this term convolve anything"
+    // needs no cache entry.
+    {
+        bool fade = false, dis_term = false;
+        for (int i = 0; i < n; ++i) {
+            if (u->rir[i] < 0) continue;
+            const int s = u->sound[i];
+            if (s < 0 || s >= n_src) return SS_EINVAL;
+            const long long t0 = u->t0[i];
+            const bool over = t0 + c.n_valid > c.src_len[s];
+            const bool w0 = c.wrap_mode && over && (!u->wrap || u->wrap[i]);
+            if (plan_window_set(c.src_len[s], t0, nbh_max, nby, w0, c.kb).count <= 0) continue;
+            const int last = u->last_rir ? u->last_rir[i] : -1;
+            const int dis = u->dis_rir ? u->dis_rir[i] : -1;
+            if (last >= 0) {
+                if (dis >= 0) return SS_EINVAL;
+                fade = true;
+            } else if (dis >= 0) {
+                if (!u->dis_sound) return SS_EINVAL;
+                const int ds = u->dis_sound[i];
+                if (ds < 0 || ds >= n_src) return SS_EINVAL;
+                if (plan_window_set(c.src_len[ds], 0, nbh_max, nby, false, c.kb).count > 0) dis_term = true;
+            }
+        }
+        if (fade && dis_term) return SS_EINVAL;                   // a launch is either cross-faded or has distractors
+    }
     ++c.tick;
     c.new_win.clear();
+    c.new_entries.clear();
     bool any_dis = false, any_fade = false;
-    const int n_src = static_cast<int>(c.src_len.size());
     for (int i = 0; i < n; ++i) {
         int* d = desc + 8 * i;
         d[0] = -1; d[1] = d[2] = d[3] = 0; d[4] = -1; d[5] = d[6] = d[7] = 0;

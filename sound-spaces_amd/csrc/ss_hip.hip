@@ -507,6 +507,19 @@ static void ctx_free_device(ssctx::Context& c) {
     c.ag_scratch = nullptr; c.ag_cap = 0;
     if (c.ev_made)
         for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done[k]);
+    if (c.ev_xstream) (void)hipEventDestroy(c.ev_xstream);
+    c.ev_xstream = nullptr; c.have_last_stream = false;
+    if (c.lanes_made) {
+        for (int l = 0; l < ssctx::kLanes; ++l) {
+            (void)hipStreamSynchronize(c.lane_stream[l]);
+            (void)hipEventDestroy(c.ev_lane[l]);
+            (void)hipEventDestroy(c.ev_win[l]);
+            (void)hipStreamDestroy(c.lane_stream[l]);
+        }
+        (void)hipEventDestroy(c.ev_in);
+        for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done2[k]);
+        c.lanes_made = false;
+    }
     c.pool = nullptr; c.src_dev = nullptr; c.d_desc = nullptr; c.d_win = nullptr; c.h_desc = nullptr; c.h_win = nullptr;
     c.ev_made = false;
 }
@@ -565,6 +578,10 @@ int ss_ctx_set_rir_bank(ss_ctx* h, const float* rir, const int* rir_len, long lo
     const int nbh_new = rir_cap > 0 ? ssctx::ceil_div(rir_cap, c.kb) : 1;
     c.rir = rir; c.rir_len = rir_len; c.rir_us = unit_stride; c.rir_cs = chan_stride; c.rir_es = elem_stride;
     c.rir_cap = rir_cap;
+    // the spectral form described the PREVIOUS bank (its entries, its capacity): back to the time-domain kernels until
+    // ss_ctx_set_rir_spectra is called for this one (a swapped / grown bank kept rendering the old spectra)
+    c.hspec = nullptr;
+    c.h_blocks = 0;
     if (nbh_new != nbh_old) {                                  // the set of partition offsets per key changes
         const int nby = c.n_valid > 0 ? ssctx::ceil_div(c.n_valid, c.kb) : 1;
         c.stride = nbh_new + nby - 1;
@@ -597,6 +614,7 @@ int ss_ctx_plan(ss_ctx* h, const ss_units* units, int n, int* unit_desc_out, int
     ssctx::PlanResult res;
     int rc = ssctx::plan_units(h->c, units, n, unit_desc_out, &res);
     if (rc) return rc;
+    if (res.n_new_windows > 0) h->c.plan_only_keys = true;       // keys now in the cache whose spectra nobody computes
     if (flags_out) *flags_out = res.flags;
     if (n_new_windows_out) *n_new_windows_out = res.n_new_windows;
     if (new_windows_out) {
@@ -676,20 +694,44 @@ static int ctx_ensure_pool(ssctx::Context& c, hipStream_t st) {
 
 // One step: plan the units (host), compute the missing source-window spectra, render.  `units` are HOST arrays.
 // audiogoal / spectrogram are DEVICE buffers [n,2,sr] / [n,65,T4,2]; either may be NULL (not both).
-int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
-    if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
-    if (n == 0) return 0;
+// `lane` >= 0: the step runs on internal stream `lane` of the overlap mode (stream == c.lane_stream[lane])
+static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream,
+                          int lane) {
     ssctx::Context& c = h->c;
-    if ((!c.rir && !c.hspec) || !c.rir_len || !c.src_dev) return SS_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (c.plan_only_keys) {                                    // ss_ctx_plan was used on this context: its keys claim
+        ssctx::cache_reset(c);                                 // spectra that were never computed - start from an empty cache
+        c.plan_only_keys = false;
+    }
+    // The window-spectra pool is shared by every step: a step on a NEW stream reads spectra the previous stream wrote
+    // (cache hits) and may overwrite slots it still reads (evictions).  One event orders the new stream behind everything
+    // the old one has been given so far.
+    if (lane >= 0) {
+        // overlap mode: the lanes only need each other's WINDOW SPECTRA (a cache hit on lane B of a key lane A computed);
+        // evictions cannot touch a slot a step in flight reads (guard of a full ring of ticks, ss_context.hpp)
+        for (int o = 0; o < c.n_lanes; ++o) {
+            if (o == lane || c.win_seen[lane][o] >= c.win_seq[o]) continue;
+            e = hipStreamWaitEvent(st, c.ev_win[o], 0);
+            if (e != hipSuccess) return hip_err(e);
+            c.win_seen[lane][o] = c.win_seq[o];
+        }
+    } else if (c.have_last_stream && st != c.last_stream) {
+        if (!c.ev_xstream) {
+            e = hipEventCreateWithFlags(&c.ev_xstream, hipEventDisableTiming);
+            if (e != hipSuccess) return hip_err(e);
+        }
+        e = hipEventRecord(c.ev_xstream, c.last_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c.ev_xstream, 0);
+        if (e != hipSuccess) return hip_err(e);
+    }
     int rc = ctx_ensure_ring(c, n, 0, st);
     if (rc) return rc;
     // Ring slots are released in GROUPS: one completion event per kGroup consecutive steps (recorded after the group's
     // last launch, waited for - on the host - before the group's first slot is written again, a full ring later).  An
     // event record per step puts a marker packet between every two launches (measured: ~2 us of a 26-us step).  A caller
     // that changes streams inside a group closes it on the old stream and starts the next group.
-    hipError_t e;
-    if (c.group_open && (st != c.group_stream || c.ring_k / ssctx::kGroup != c.open_group)) {
+    if (lane < 0 && c.group_open && (st != c.group_stream || c.ring_k / ssctx::kGroup != c.open_group)) {
         e = hipEventRecord(c.ev_done[c.open_group], c.group_stream);     // (also a group a failed step left open)
         if (e != hipSuccess) return hip_err(e);
         c.group_open = false;
@@ -698,12 +740,12 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     const int k = c.ring_k, g = k / ssctx::kGroup;
     if (k % ssctx::kGroup == 0) {
         e = hipEventSynchronize(c.ev_done[g]);                 // every launch that read the group's slots has finished
+        if (e == hipSuccess && lane >= 0) e = hipEventSynchronize(c.ev_done2[g]);   // ... on either lane
         if (e != hipSuccess) return hip_err(e);
-        c.group_open = true;
+        c.group_open = lane < 0;
         c.group_stream = st;
         c.open_group = g;
     }
-    c.ring_k = (k + 1) % ssctx::kRing;
     // Small steps: the kernels read the unit descriptors straight from the pinned ring slot (one 32-byte scalar load per
     // workgroup over the host link) - an upload between two launches on the stream costs a blit kernel plus a barrier on
     // either side of it (measured: ~15 us of idle GPU per 25-us step).  Large steps (several descriptors per workgroup,
@@ -714,23 +756,47 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     int* dd = direct ? hd : c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
     ssctx::PlanResult res;
     rc = ssctx::plan_units(c, units, n, hd, &res);
-    if (rc) return rc;
+    if (rc) return rc;                                         // (refused before the cache or the ring was touched)
+    c.ring_k = (k + 1) % ssctx::kRing;                         // the slot is taken from here on, whatever happens next
+    // The slot's group is released by an event recorded behind the group's last launch (overlap mode: behind each lane's
+    // last launch of the group); a step that fails after this point must still record it, or the group's next round
+    // would be checked against a stale event.
+    auto close_slot = [&]() -> int {
+        hipError_t ee = hipSuccess;
+        if (lane >= 0) {
+            if (k % ssctx::kGroup >= ssctx::kGroup - c.n_lanes) ee = hipEventRecord(lane == 0 ? c.ev_done[g] : c.ev_done2[g], st);
+        } else if (k % ssctx::kGroup == ssctx::kGroup - 1) {
+            ee = hipEventRecord(c.ev_done[g], st);
+            c.group_open = false;
+        }
+        return hip_err(ee);
+    };
+    // ... and take the keys of this plan out of the cache again as long as their spectra have not been computed
+    auto fail = [&](int code) { ssctx::cache_rollback(c); (void)close_slot(); return code; };
     rc = ctx_ensure_pool(c, st);
-    if (rc) return rc;
+    if (rc) return fail(rc);
     if (res.n_new_windows > 0) {
         rc = ctx_ensure_ring(c, n, res.n_new_windows, st);
-        if (rc) return rc;
+        if (rc) return fail(rc);
         int* hw = c.h_win + static_cast<size_t>(k) * c.win_cap * 5;
         int* dw = c.d_win + static_cast<size_t>(k) * c.win_cap * 5;
         std::memcpy(hw, c.new_win.data(), sizeof(int) * 5 * static_cast<size_t>(res.n_new_windows));
         e = hipMemcpyAsync(dw, hw, sizeof(int) * 5 * static_cast<size_t>(res.n_new_windows), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return hip_err(e);
+        if (e != hipSuccess) return fail(hip_err(e));
         rc = launch_windows_scatter(c.src_dev, dw, c.pool, res.n_new_windows, st);
-        if (rc) return rc;
+        if (rc) return fail(rc);
+        if (lane >= 0) {                                       // the other lane's next step may hit these keys
+            e = hipEventRecord(c.ev_win[lane], st);
+            if (e != hipSuccess) return fail(hip_err(e));
+            ++c.win_seq[lane];
+        }
     }
+    c.new_entries.clear();                                     // their spectra are on the stream: the keys are good
+    c.last_stream = st;
+    c.have_last_stream = true;
     if (!direct) {
         e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return hip_err(e);
+        if (e != hipSuccess) return fail(hip_err(e));
     }
     const int nbh_bank = c.hspec ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
     if (spectrogram && !audiogoal && c.out_len > ssk::kB &&
@@ -738,11 +804,11 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
         const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
         if (need > c.ag_cap) {
             e = hipDeviceSynchronize();
-            if (e != hipSuccess) return hip_err(e);
+            if (e != hipSuccess) return fail(hip_err(e));
             if (c.ag_scratch) (void)hipFree(c.ag_scratch);
             c.ag_scratch = nullptr; c.ag_cap = 0;
             e = hipMalloc(reinterpret_cast<void**>(&c.ag_scratch), need * sizeof(float));
-            if (e != hipSuccess) return hip_err(e);
+            if (e != hipSuccess) return fail(hip_err(e));
             c.ag_cap = need;
         }
         audiogoal = c.ag_scratch;
@@ -760,13 +826,72 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     else
         rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
                                      c.n_valid, c.out_len, res.flags, stream);
-    if (rc) return rc;
-    if (k % ssctx::kGroup == ssctx::kGroup - 1) {
-        e = hipEventRecord(c.ev_done[g], st);
+    if (rc) return fail(rc);
+    // (overlap mode: a group's ticks alternate between the lanes; each lane records its half after ITS last tick)
+    return close_slot();
+}
+
+// ---- overlap mode -------------------------------------------------------------------------------------------------
+int ss_ctx_set_overlap(ss_ctx* h, int n_streams) {
+    if (!h || n_streams < 1 || n_streams > ssctx::kLanes) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    hipError_t e = hipDeviceSynchronize();                     // a clean cut between the two regimes
+    if (e != hipSuccess) return hip_err(e);
+    if (n_streams > 1 && !c.lanes_made) {
+        for (int l = 0; l < ssctx::kLanes; ++l) {
+            e = hipStreamCreateWithFlags(&c.lane_stream[l], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_lane[l], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ev_win[l], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_err(e);
+        }
+        e = hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming);
         if (e != hipSuccess) return hip_err(e);
-        c.group_open = false;
+        for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) {
+            e = hipEventCreateWithFlags(&c.ev_done2[k], hipEventDisableTiming);
+            if (e != hipSuccess) return hip_err(e);
+        }
+        c.lanes_made = true;
+    }
+    c.n_lanes = n_streams;
+    c.lane_next = 0;
+    c.ring_k = 0;                                              // groups start afresh (everything has completed)
+    c.group_open = false;
+    c.have_last_stream = false;
+    for (int l = 0; l < ssctx::kLanes; ++l) { c.lane_dirty[l] = false; for (int o = 0; o < ssctx::kLanes; ++o) c.win_seen[l][o] = c.win_seq[o]; }
+    return 0;
+}
+
+int ss_ctx_join(ss_ctx* h, void* stream) {
+    if (!h) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    if (c.n_lanes <= 1) return 0;                              // single-stream mode: the caller's stream IS the work's stream
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int l = 0; l < c.n_lanes; ++l) {
+        if (!c.lane_dirty[l]) continue;
+        hipError_t e = hipEventRecord(c.ev_lane[l], c.lane_stream[l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c.ev_lane[l], 0);
+        if (e != hipSuccess) return hip_err(e);
+        c.lane_dirty[l] = false;
     }
     return 0;
+}
+
+int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
+    if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
+    if (n == 0) return 0;
+    ssctx::Context& c = h->c;
+    if ((!c.rir && !c.hspec) || !c.rir_len || !c.src_dev) return SS_EINVAL;
+    if (c.n_lanes <= 1) return ctx_observe_on(h, units, n, audiogoal, spectrogram, stream, -1);
+    // overlap mode: this step goes to the next internal stream, behind whatever the caller's stream holds right now (the
+    // consumers of the output rows it overwrites, uploads of RIR rows it reads); the caller's stream sees the result after
+    // ss_ctx_join.  Consecutive steps run on different streams: the head of step k+1 (descriptor + row loads, HBM latency,
+    // nothing to compute) overlaps the tail of step k (STFT, no memory traffic).
+    const int lane = c.ring_k % c.n_lanes;                     // tick parity: a refused call does not shift the lanes
+    hipError_t e = hipEventRecord(c.ev_in, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
+    if (e != hipSuccess) return hip_err(e);
+    c.lane_dirty[lane] = true;
+    return ctx_observe_on(h, units, n, audiogoal, spectrogram, c.lane_stream[lane], lane);
 }
 
 

@@ -13,7 +13,7 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_create", "ss_ctx_destroy", "ss_ctx_add_source", "ss_ctx_add_source_len", "ss_ctx_set_rir_bank",
            "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
-           "ss_ctx_sims_units")
+           "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join")
 
 
 class SsSimColumns(ctypes.Structure):
@@ -68,6 +68,8 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe_sims.argtypes = [vp, ctypes.POINTER(SsSimColumns), c_int, vp, vp, vp, vp, vp]
     lib.ss_ctx_sims_units.argtypes = [vp, ctypes.POINTER(SsSimColumns), c_int, vp, vp, vp]
     lib.ss_ctx_set_rir_spectra.argtypes = [vp, vp, c_int]
+    lib.ss_ctx_set_overlap.argtypes = [vp, c_int]
+    lib.ss_ctx_join.argtypes = [vp, vp]
     lib.ss_rir_spectra_f32.argtypes = [vp, vp, c_int, c_ll, c_int, c_int, vp]
     lib.ss_fftconv_binaural_spec_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     lib.ss_audio_obs_spec_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]

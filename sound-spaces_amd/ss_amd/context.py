@@ -112,6 +112,21 @@ class AudioContext:
                        "ss_ctx_set_rir_spectra")
         self._spectra = hspec
 
+    def set_overlap(self, n_streams: int = 2) -> None:
+        """Consecutive observe() calls alternate between ``n_streams`` internal streams (ss_ctx_set_overlap): the load
+        phase of step k+1 overlaps the STFT phase of step k.  Results are visible to a stream after ``join()``."""
+        _lib.check(self.lib.ss_ctx_set_overlap(self._h, int(n_streams)), "ss_ctx_set_overlap")
+        self.overlap = int(n_streams)
+
+    def join(self, stream: Optional[int] = None) -> None:
+        """Make `stream` (default: the current torch stream) wait for every step issued so far (no-op without overlap)."""
+        if getattr(self, "overlap", 1) <= 1:
+            return
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.ss_ctx_join(self._h, stream), "ss_ctx_join")
+
     def set_rir_cap_for_planning(self, cap: int) -> None:
         """plan()-only use without a GPU: the bank capacity decides how many partition blocks a key needs."""
         _lib.check(self.lib.ss_ctx_set_rir_bank(self._h, None, None, 2 * cap, cap, 1, int(cap)), "ss_ctx_set_rir_bank")
@@ -215,7 +230,7 @@ class AudioContext:
         u, n, keep = self._units(sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap)
         desc = np.zeros((n, 8), np.int32)
         flags, nw = ctypes.c_int(0), ctypes.c_int(0)
-        cap = 4 * n + 16
+        cap = 2 * self.stats()["slots_per_key"] * n + 16       # at most two keys (terms) per unit, slots_per_key windows each
         wins = np.zeros((cap, 5), np.int32)
         _lib.check(self.lib.ss_ctx_plan(self._h, ctypes.byref(u), n, desc.ctypes.data, ctypes.addressof(flags),
                                         ctypes.addressof(nw), wins.ctypes.data, cap), "ss_ctx_plan")

@@ -151,7 +151,10 @@ class DeferredResolver:
         held, slots, turn = self._live.setdefault(env, [[None, None], [-1, -1], [0]])
         for k in (0, 1):
             h = held[k]
-            if h is not None and h.shape == rir.shape and np.array_equal(h, rir):
+            if h is not None and (h is rir or (h.shape == rir.shape and np.array_equal(h, rir))):
+                # through the store even on a content match: touches the LRU, marks the slot as used by this batch and
+                # re-uploads the row if the store has meanwhile given the slot to another key
+                slots[k] = self.engine.rir_slot(("live", env, k), lambda: rir, refresh=False)
                 return slots[k]
         k = turn[0]
         if slots[k] == avoid and avoid >= 0:

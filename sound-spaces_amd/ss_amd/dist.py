@@ -121,6 +121,11 @@ class ChunkedSlabExchange:
         i = self._n
         return self._buf[i * self.units:(i + 1) * self.units]
 
+    def will_gather(self) -> bool:
+        """True when the next step_done() completes the chunk, i.e. issues the all-gather (callers with work on streams
+        the exchange does not know - ss_ctx overlap lanes - join them first)."""
+        return self._n + 1 == self.G
+
     def step_done(self, streams=None) -> None:
         self._n += 1
         if self._n == self.G:

@@ -175,8 +175,11 @@ class HipContinuousSimAudio:
     the simulator), so a cross-faded step uploads ONE new RIR, not two, and the two sensors of a step (audiogoal and
     spectrogram both call ``_compute_audiogoal`` in the reference) upload it once."""
 
+    _ids = __import__("itertools").count()
+
     def __init__(self, sim, engine):
         self.sim, self.engine = sim, engine
+        self._env_id = next(HipContinuousSimAudio._ids)   # stable key of this env's live rows (id(sim) can be reused after GC)
         self._held = [None, None]             # the arrays living in this env's two live slots
         self._slots = [-1, -1]
         self._turn = 0
@@ -197,13 +200,15 @@ class HipContinuousSimAudio:
         for k in (0, 1):
             h = self._held[k]
             if h is not None and (h is rir or (h.shape == rir.shape and np.array_equal(h, rir))):
+                # through the store even on a content match: LRU touch, batch guard, re-upload if the slot was evicted
+                self._slots[k] = self.engine.rir_slot(("live", self._env_id, k), lambda: rir, refresh=False)
                 return self._slots[k]
         k = self._turn
         if self._slots[k] == avoid and avoid >= 0:
             k ^= 1
         self._turn = k ^ 1
         self._held[k] = rir
-        self._slots[k] = self.engine.rir_slot(("live", id(self.sim), k), lambda: rir, refresh=True)
+        self._slots[k] = self.engine.rir_slot(("live", self._env_id, k), lambda: rir, refresh=True)
         return self._slots[k]
 
     def unit_request(self) -> UnitRequest:

@@ -267,21 +267,31 @@ class FastVectorAudioObserver:
         silent = (st.step_count > st.duration) | ~known                                              # :610
         multi = clip_len != sr                                                                       # :629
         t0 = np.where(multi, st.audio_index * sr, 0)
-        adv = multi & ~silent
-        if adv.any():
-            st.audio_index[adv] = (st.audio_index[adv] + 1) % (clip_len[adv] // sr)               # :635
         az = (-st.rot) % 360                                                                         # :573
         rir = self.index.lookup(st.scene, st.recv, st.src, az)
+        # pairs that are not resident are resolved (or the step refused) BEFORE anything is advanced, exactly like the
+        # native path (ss_ctx_observe_sims: "nothing launched, nothing advanced")
         if self.miss is not None:
             for i in np.flatnonzero((rir < 0) & ~silent):
                 rir[i] = self.miss(int(i), int(st.recv[i]), int(st.src[i]), int(az[i]))
-        cols = dict(sound=st.sound, t0=t0, rir=np.where(silent, -1, rir))
+        cols = dict(sound=np.where(silent, 0, st.sound), t0=np.where(silent, 0, t0), rir=np.where(silent, -1, rir))
+        bad = (cols["rir"] < 0) & ~silent
         if self.has_distractor:                                                                      # :649-664
+            has_dis = (st.dis_sound >= 0) & ~silent
             dr = self.index.lookup(st.scene, st.recv, st.dis_src, az)
             if self.miss is not None:
-                for i in np.flatnonzero((dr < 0) & ~silent):
+                for i in np.flatnonzero((dr < 0) & has_dis):
                     dr[i] = self.miss(int(i), int(st.recv[i]), int(st.dis_src[i]), int(az[i]))
-            cols.update(dis_sound=st.dis_sound, dis_rir=dr)
+            bad |= (dr < 0) & has_dis
+            # no distractor sound -> no distractor term (the native path sets drir = -1 as well)
+            cols.update(dis_sound=np.where(has_dis, st.dis_sound, 0), dis_rir=np.where(has_dis, dr, -1))
+        if bad.any():
+            i = int(np.flatnonzero(bad)[0])
+            raise KeyError(f"no RIR loaded for env {i}: (scene {int(st.scene[i])}, receiver {int(st.recv[i])}, source "
+                           f"{int(st.src[i])}, azimuth {int(az[i])}) - pass miss= to load pairs on demand")
+        adv = multi & ~silent & (clip_len >= sr)          # (clips shorter than 1 s never advance: len // sr == 0)
+        if adv.any():
+            st.audio_index[adv] = (st.audio_index[adv] + 1) % (clip_len[adv] // sr)               # :635
         return cols
 
     def observe(self, spectrogram_out=None, audiogoal_out=None) -> None:

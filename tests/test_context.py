@@ -141,7 +141,125 @@ def test_planner_rejects_bad_input():
                  last_rir=np.array([1]))
 
 
+def test_refused_step_leaves_no_keys_behind():
+    """plan_units() used to insert cache entries for units 0..i-1 before refusing the step at unit i; the next
+    plan then reported those keys as HITS although no spectra had been computed for them.  Planning is transactional
+    now: a refused step does not touch the cache."""
+    from ss_amd._lib import SsHipError
+    ctx = AudioContext(SR)
+    for i in range(3):
+        ctx.add_source_len(f"s{i}", SR)
+    ctx.set_rir_cap_for_planning(SR)
+    z = lambda *v: np.array(v, np.int32)
+    with pytest.raises(SsHipError):
+        ctx.plan(z(0, 3), z(0, 0), z(0, 0))                                       # unit 0 fine, unit 1: unknown sound
+    with pytest.raises(SsHipError):                                              # unit 0 fine, unit 1: dis + last
+        ctx.plan(z(1, 0), z(0, 0), z(0, 0), dis_sound=z(0, 0), dis_rir=z(-1, 1), last_rir=z(-1, 1))
+    with pytest.raises(SsHipError):                                              # a cross-fade and a distractor in one launch
+        ctx.plan(z(2, 0), z(0, 0), z(0, 0), dis_sound=z(0, 0), dis_rir=z(-1, 1), last_rir=z(1, -1))
+    st = ctx.stats()
+    assert st["resident"] == 0 and st["misses"] == 0 and st["hits"] == 0 and st["steps"] == 0
+    desc, flags, wins = ctx.plan(z(0), z(0), z(0))
+    assert len(wins) == 1 and ctx.stats()["misses"] == 1 and ctx.stats()["hits"] == 0      # a miss, not a poisoned hit
+
+
 # ---- GPU half ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_failed_or_plan_only_steps_do_not_poison_the_window_cache():
+    """(1) a refused ss_ctx_observe, then the same keys must render correctly; (2) ss_ctx_plan on a context that
+    also observes: the planned-only keys have no spectra - the next observe starts from an empty cache; (3) a bank swap
+    drops the spectral form of the old bank (ss_ctx_set_rir_bank resets it)."""
+    import torch
+    from ss_amd._lib import SsHipError
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank, UnitRequest
+    dev = "cuda:0"
+    rng = np.random.default_rng(18)
+    src = O.synth_sources(rng, SR, k=3)
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=4)]
+    bank = RirBank.from_arrays(rirs, dev)
+    r = BatchedAudioRenderer(SR, device=dev)
+    ctx = AudioContext(SR)
+    for i, s_ in enumerate(src):
+        r.add_source(f"s{i}", s_)
+        ctx.add_source(f"s{i}", s_)
+    r.set_rir_bank(bank)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    sg = torch.full((2, 65, 26, 2), float("nan"), device=dev)
+    with pytest.raises(SsHipError):
+        ctx.observe([0, 7], [0, 0], [0, 1], spectrogram_out=sg)                  # unit 1: unknown sound -> nothing launched
+    want = r.render(r.plan([UnitRequest(0, 0, 0), UnitRequest(1, 0, 1)]))[1]
+    ctx.observe([0, 1], [0, 0], [0, 1], spectrogram_out=sg)
+    torch.cuda.synchronize()
+    assert torch.equal(sg, want)
+    ctx.plan([2, 1], [0, 0], [2, 3])                                             # planner only: key (2, 0) gets no spectrum
+    want2 = r.render(r.plan([UnitRequest(2, 0, 2), UnitRequest(0, 0, 3)]))[1]
+    sg.fill_(float("nan"))
+    ctx.observe([2, 0], [0, 0], [2, 3], spectrogram_out=sg)
+    torch.cuda.synchronize()
+    assert torch.equal(sg, want2)
+    # spectral form, then a different bank WITHOUT new spectra: must render the new bank (time-domain kernels)
+    bank.build_spectra()
+    ctx.set_rir_spectra(bank.spectra)
+    ctx.observe([2, 0], [0, 0], [2, 3], spectrogram_out=sg)
+    torch.cuda.synchronize()
+    assert float((sg - want2).abs().max()) <= 2e-6 * float(want2.abs().max())
+    bank2 = RirBank.from_arrays(rirs[::-1], dev)
+    r.set_rir_bank(bank2)
+    ctx.set_rir_bank(bank2.data, bank2.lengths)
+    want3 = r.render(r.plan([UnitRequest(2, 0, 2), UnitRequest(0, 0, 3)]))[1]
+    ctx.observe([2, 0], [0, 0], [2, 3], spectrogram_out=sg)
+    torch.cuda.synchronize()
+    assert torch.equal(sg, want3)
+
+
+@pytest.mark.gpu
+def test_overlap_mode_two_lanes_equal_single_stream():
+    """ss_ctx_set_overlap(2): 90 steps alternate between two internal streams with nothing but ss_ctx_join at the end -
+    cache misses whose spectra the OTHER lane's next step hits, evictions under a small cache, steps of different sizes
+    (descriptors in place and uploaded), a refused step in the middle - every row equal to the single-stream context's."""
+    import torch
+    from ss_amd._lib import SsHipError
+    from ss_amd.renderer import RirBank
+    dev = "cuda:0"
+    rng = np.random.default_rng(28)
+    src = [O.synth_sources(rng, SR, k=1, seconds=s_)[0] for s_ in (1, 1, 3, 6, 9)]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=16)]
+    bank = RirBank.from_arrays(rirs, dev)
+    ctxs = [AudioContext(SR, max_window_sets=4), AudioContext(SR, max_window_sets=4)]
+    for c in ctxs:
+        for i, s_ in enumerate(src):
+            c.add_source(f"s{i}", s_)
+        c.set_rir_bank(bank.data, bank.lengths)
+    ctxs[1].set_overlap(2)
+    steps = []
+    for k in range(90):
+        n = int(rng.choice([3, 40, 300]))
+        sound = rng.integers(0, 5, n)
+        t0 = np.array([0 if len(src[s_]) == SR else int(rng.integers(0, len(src[s_]) // SR)) * SR for s_ in sound])
+        steps.append((sound, t0, rng.integers(-1, 16, n)))
+    outs = [[torch.full((len(s_[0]), 65, 26, 2), float("nan"), device=dev) for s_ in steps] for _ in ctxs]
+    side = torch.cuda.Stream(device=dev)
+    for which, c in enumerate(ctxs):
+        with torch.cuda.stream(side if which else torch.cuda.current_stream()):
+            for k, (sound, t0, rir) in enumerate(steps):
+                if k == 33:
+                    with pytest.raises(SsHipError):
+                        c.observe([99], [0], [0], spectrogram_out=outs[which][k][:1])     # refused: lanes keep their turn
+                c.observe(sound, t0, rir, spectrogram_out=outs[which][k])
+            c.join()
+    torch.cuda.synchronize()
+    for k in range(len(steps)):
+        assert torch.equal(outs[1][k], outs[0][k]), k
+    st = ctxs[1].stats()
+    assert st["misses"] > 10 and st["hits"] > 100
+    ctxs[1].set_overlap(1)                                                       # and back: same results again
+    k = 5
+    o = torch.empty_like(outs[0][k])
+    ctxs[1].observe(*steps[k], spectrogram_out=o)
+    torch.cuda.synchronize()
+    assert torch.equal(o, outs[0][k])
+
+
 @pytest.mark.gpu
 def test_ctx_observe_matches_renderer_and_oracle():
     """ss_ctx_observe (planner + cache + ring in the library) renders the same step as the Python-planned renderer,

@@ -173,3 +173,26 @@ def test_peer_copy_exchange_two_processes_one_gpu():
         p.join(60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`bench.py --gpus N` parsed the flag and ran one rank.  Without a torch.distributed environment it now
+    re-launches itself as N ranks (python -m torch.distributed.run --nproc-per-node N, the shape of the reference's
+    ss_baselines/av_nav/single_node.sh:8-11); --dry-run keeps kernels and GPUs out of it (gloo, CPU tensors): the rank
+    flow, the chunked slab exchange and the one JSON line are the real ones."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "11",
+                          "--gather-every", "4", "--envs", "6"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["gather_ok"] is True and d["gathers"] == 3
+    # under a launcher whose world size contradicts --gpus the script refuses instead of mislabelling the line
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

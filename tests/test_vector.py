@@ -192,18 +192,22 @@ def test_native_state_to_units_equals_numpy_columns(has_distractor):
             for k, v in cols.items():
                 getattr(st, k)[:] = v
         before = b.audio_index.copy()
-        ref = obs.columns()
+        az = (-a.rot) % 360
+        live = ~(a.step_count > a.duration) & (a.sound >= 0)
+        exp_missing = np.flatnonzero(live & ((index.lookup(a.scene, a.recv, a.src, az) < 0) |
+                                             (((index.lookup(a.scene, a.recv, a.dis_src, az) < 0) & (a.dis_sound >= 0))
+                                              if has_distractor else False)))
         got, missing = ctx_b.sims_units(bound)
-        silent = ref["rir"] < 0
-        exp_missing = np.flatnonzero(~(a.step_count > a.duration) & (a.sound >= 0) & (
-            (index.lookup(a.scene, a.recv, a.src, (-a.rot) % 360) < 0) |
-            ((ref["dis_rir"] < 0) if has_distractor else False)))
         if exp_missing.size:
             seen_miss = True
             assert missing.tolist() == exp_missing.tolist()
             assert np.array_equal(b.audio_index, before)                            # nothing advanced
-            a.audio_index[:] = before                                               # (the numpy path has no such protocol)
+            with pytest.raises(KeyError):                                           # the numpy path refuses the step as well,
+                obs.columns()                                                       # before advancing anything
+            assert np.array_equal(a.audio_index, before)
             continue
+        ref = obs.columns()
+        silent = ref["rir"] < 0
         assert missing.size == 0
         assert np.array_equal(got["rir"], ref["rir"])
         assert np.array_equal(got["t0"][~silent], ref["t0"][~silent])
