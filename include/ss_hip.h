@@ -47,6 +47,9 @@ extern "C" {
  * (first step of an episode, `_last_rir is None`) are not blended.  One launch; with ss_audio_obs_f32 the spectrogram
  * is taken from the blended row. */
 #define SS_FLAG_CROSSFADE 2
+/* length-bucketed banks (ss_rir_bucket): every bank index the launch references lies in bucket 0, so the loop-free
+ * kernels may serve it (the context's planner sets it per step) */
+#define SS_FLAG_FIRST_BUCKET 4
 
 /* Geometry constants of the partitioned convolution. */
 int ss_block_len(void);        /* kB = 16384 real samples per partition block                     */
@@ -111,6 +114,32 @@ int ss_fftconv_binaural_spec_f32(const float* spec, const float* hspec, const in
 int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_len, const int* unit_desc,
                           float* audiogoal, float* spectrogram, int n_units, int h_blocks, int n_valid, int out_len,
                           int pad_mode, int flags, void* stream);
+
+/* ---- Length-bucketed RIR bank ------------------------------------------------------------------------
+ * The reference's RIRs are variable-length wav files (soundspaces/README.md:38-42, read at simulator.py:615-618; SS2.0's
+ * ray-traced RIRs run to 4 s).  One capacity for every row means one long RIR reallocates the whole bank, multiplies the
+ * HBM of every slot and pushes every launch off the loop-free kernel.  A bucketed bank keeps entries of similar length
+ * together: bucket b holds bank indices [first, first + n_entries) as planar rows [n_entries, 2, cap] (zero beyond each
+ * entry's length) in an allocation of its own, optionally with its spectral form (ss_rir_spectra_f32 of that bucket).
+ * Buckets are ordered by `first` (bucket 0 starts at 0), ranges disjoint, at most 4; rir_len is ONE device array indexed by
+ * the global bank index.  Unit descriptors are unchanged (they carry global indices).  Launches that promise
+ * SS_FLAG_FIRST_BUCKET (and whose bucket 0 has cap <= kB) run the loop-free kernel. */
+typedef struct ss_rir_bucket {
+    const float* rir;     /* device, [n_entries, 2, cap] */
+    const float* hspec;   /* device, [n_entries, 2, ceil(cap/kB), ss_spec_floats()] or NULL */
+    int first;            /* global bank index of entry 0 of the bucket */
+    int n_entries;
+    int cap;              /* samples per (entry, ear) row, even */
+    int reserved;
+} ss_rir_bucket;
+/* `buckets` is a HOST array of n_buckets descriptors.  The spectral kernels are used when every bucket carries hspec and
+ * the launch is not cross-faded. */
+int ss_fftconv_binaural_buckets_f32(const float* spec, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len,
+                                    const int* unit_desc, float* out, int n_units, int n_valid, int out_len, int flags,
+                                    void* stream);
+int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len,
+                             const int* unit_desc, float* audiogoal, float* spectrogram, int n_units, int n_valid,
+                             int out_len, int pad_mode, int flags, void* stream);
 
 /* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
  * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
@@ -185,6 +214,9 @@ int ss_ctx_set_rir_bank(ss_ctx* ctx, const float* rir, const int* rir_len, long 
 /* Optional spectral form (ss_rir_spectra_f32) of the bank given to ss_ctx_set_rir_bank: steps without a cross-fade then
  * run the *_spec_* kernels.  hspec = NULL: back to the time-domain kernels.  Borrowed pointer. */
 int ss_ctx_set_rir_spectra(ss_ctx* ctx, const float* hspec, int h_blocks);
+/* The bank as length buckets (see ss_rir_bucket; replaces the two calls above for such banks; the descriptor array is copied,
+ * the device pointers are borrowed).  Call again whenever a bucket is (re)allocated. */
+int ss_ctx_set_rir_buckets(ss_ctx* ctx, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len);
 /* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
  * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
 int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);

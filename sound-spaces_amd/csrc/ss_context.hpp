@@ -74,6 +74,7 @@ struct Context {
     int rir_cs = 0, rir_es = 1, rir_cap = 0;
     const float* hspec = nullptr; // spectral form of the same bank (optional, borrowed)
     int h_blocks = 0;
+    std::vector<ss_rir_bucket> buckets;   // length-bucketed bank (ss_ctx_set_rir_buckets); empty: the single bank above
     // window-spectra cache
     int stride = 1;               // pool slots per entry = nbh_max + nby - 1
     int n_entries = 0;            // host bookkeeping (may run ahead of the device pool, see cache_grow)
@@ -258,6 +259,7 @@ inline int plan_units(Context& c, const ss_units* u, int n, int* desc, PlanResul
     c.new_win.clear();
     c.new_entries.clear();
     bool any_dis = false, any_fade = false;
+    int max_rir = -1;                                            // highest bank index a term of this step reads
     for (int i = 0; i < n; ++i) {
         int* d = desc + 8 * i;
         d[0] = -1; d[1] = d[2] = d[3] = 0; d[4] = -1; d[5] = d[6] = d[7] = 0;
@@ -271,6 +273,7 @@ inline int plan_units(Context& c, const ss_units* u, int n, int* desc, PlanResul
         const Entry& x0 = c.entries[e0];
         if (x0.count <= 0) continue;                              // nothing of the clip under this window: silent
         d[0] = u->rir[i]; d[1] = e0 * c.stride; d[2] = x0.m_min; d[3] = x0.count;
+        if (d[0] > max_rir) max_rir = d[0];
         const int last = u->last_rir ? u->last_rir[i] : -1;
         const int dis = u->dis_rir ? u->dis_rir[i] : -1;
         if (last >= 0) {
@@ -279,6 +282,7 @@ inline int plan_units(Context& c, const ss_units* u, int n, int* desc, PlanResul
             const int e1 = cache_get(c, s, t0, w1, nbh_max, nby);
             const Entry& x1 = c.entries[e1];
             d[4] = last; d[5] = e1 * c.stride; d[6] = x1.m_min; d[7] = x1.count;
+            if (last > max_rir) max_rir = last;
             any_fade = true;
         } else if (dis >= 0) {
             if (!u->dis_sound) return SS_EINVAL;
@@ -286,11 +290,15 @@ inline int plan_units(Context& c, const ss_units* u, int n, int* desc, PlanResul
             if (ds < 0 || ds >= n_src) return SS_EINVAL;
             const int e1 = cache_get(c, ds, 0, false, nbh_max, nby);     // whole clip from its start (simulator.py:659-664)
             const Entry& x1 = c.entries[e1];
-            if (x1.count > 0) { d[4] = dis; d[5] = e1 * c.stride; d[6] = x1.m_min; d[7] = x1.count; any_dis = true; }
+            if (x1.count > 0) {
+                d[4] = dis; d[5] = e1 * c.stride; d[6] = x1.m_min; d[7] = x1.count; any_dis = true;
+                if (dis > max_rir) max_rir = dis;
+            }
         }
     }
     if (any_fade && any_dis) return SS_EINVAL;                    // a launch is either cross-faded or has distractors
     res->flags = any_fade ? SS_FLAG_CROSSFADE : (any_dis ? 0 : SS_FLAG_NO_DISTRACTOR);
+    if (c.buckets.size() > 1 && max_rir < c.buckets[1].first) res->flags |= SS_FLAG_FIRST_BUCKET;
     res->n_new_windows = static_cast<int>(c.new_win.size() / 5);
     return 0;
 }

@@ -1,6 +1,7 @@
 // ss_hip.hip — host side of libss_hip.so: table construction and kernel launches (gfx950 only).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -62,7 +63,11 @@ template <bool FUSE>
 int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
     p.nb_y = nb_y;
-    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && !(flags & SS_FLAG_CROSSFADE) && nb_y == 1 && p.rir_cap <= ssk::kB;
+    // the loop-free kernels address bucket 0 only: a bucketed bank qualifies when the caller promises that every index
+    // of the launch lies there (SS_FLAG_FIRST_BUCKET; the context's planner works it out per step)
+    const bool bucket0 = p.n_buckets == 1 || (flags & SS_FLAG_FIRST_BUCKET);
+    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && !(flags & SS_FLAG_CROSSFADE) && nb_y == 1 &&
+                        p.rir_cap <= ssk::kB && bucket0;
     if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
     const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
     // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
@@ -130,7 +135,8 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
     // measured equal at 512 units and 5 % SLOWER at 128 units (profiles/r3/NOTES.md), so it stays an A/B switch.
     static const bool use_stash = getenv("SS_HIP_ROWS_STASH") && atoi(getenv("SS_HIP_ROWS_STASH")) != 0;
     if (!SPECTRAL && p.nb_y > 1 && use_stash) {
-        const int nbh_max = (p.rir_cap + ssk::kB - 1) / ssk::kB;
+        int nbh_max = (p.rir_cap + ssk::kB - 1) / ssk::kB;
+        for (int b = 0; b + 1 < p.n_buckets; ++b) nbh_max = std::max(nbh_max, (p.bk[b].cap + ssk::kB - 1) / ssk::kB);
         p.stash_terms = p.n_terms;                              // no distractor terms: half the stash
         p.stash_nbh = nbh_max;
         const size_t per_wg = static_cast<size_t>(p.stash_terms) * nbh_max * ssk::kSpecComplex * sizeof(ssk::c32);
@@ -219,6 +225,8 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.stash_nbh = 0;
     p.stash_terms = 0;
     p.n_terms = 2;
+    p.n_buckets = 1;
+    for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
 #if defined(SS_LADDER)                                     // profiling builds only (scripts/gpu_ladder.sh compiles with -DSS_LADDER)
     static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
     p.dbg = dbg;
@@ -414,7 +422,8 @@ template <bool FUSE>
 static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags, hipStream_t st, int n_cus = 0) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1) || (flags & SS_FLAG_CROSSFADE)) return SS_EINVAL;
     p.nb_y = nb_y;
-    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1;
+    const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1 &&
+                        (p.n_buckets == 1 || (flags & SS_FLAG_FIRST_BUCKET));
     static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
     if constexpr (!FUSE) {              // more rows than CUs: persistent workgroups prefetching the next row's H'
         if (simple && !no_rows && n_cus > 0 && n_units > n_cus && !(reinterpret_cast<size_t>(p.hspec) & 15)) {
@@ -582,6 +591,7 @@ int ss_ctx_set_rir_bank(ss_ctx* h, const float* rir, const int* rir_len, long lo
     // ss_ctx_set_rir_spectra is called for this one (a swapped / grown bank kept rendering the old spectra)
     c.hspec = nullptr;
     c.h_blocks = 0;
+    c.buckets.clear();
     if (nbh_new != nbh_old) {                                  // the set of partition offsets per key changes
         const int nby = c.n_valid > 0 ? ssctx::ceil_div(c.n_valid, c.kb) : 1;
         c.stride = nbh_new + nby - 1;
@@ -814,7 +824,13 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         audiogoal = c.ag_scratch;
     }
     const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);
-    if (spectrogram && spectral)
+    if (!c.buckets.empty()) {
+        const int nb = static_cast<int>(c.buckets.size());
+        rc = spectrogram ? ss_audio_obs_buckets_f32(c.pool, c.buckets.data(), nb, c.rir_len, dd, audiogoal, spectrogram, n,
+                                                    c.n_valid, c.out_len, c.pad_mode, res.flags, stream)
+                         : ss_fftconv_binaural_buckets_f32(c.pool, c.buckets.data(), nb, c.rir_len, dd, audiogoal, n, c.n_valid,
+                                                           c.out_len, res.flags, stream);
+    } else if (spectrogram && spectral)
         rc = ss_audio_obs_spec_f32(c.pool, c.hspec, c.rir_len, dd, audiogoal, spectrogram, n, c.h_blocks, c.n_valid,
                                    c.out_len, c.pad_mode, res.flags, stream);
     else if (spectrogram)
@@ -880,7 +896,7 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
     if (n == 0) return 0;
     ssctx::Context& c = h->c;
-    if ((!c.rir && !c.hspec) || !c.rir_len || !c.src_dev) return SS_EINVAL;
+    if ((!c.rir && !c.hspec && c.buckets.empty()) || !c.rir_len || !c.src_dev) return SS_EINVAL;
     if (c.n_lanes <= 1) return ctx_observe_on(h, units, n, audiogoal, spectrogram, stream, -1);
     // overlap mode: this step goes to the next internal stream, behind whatever the caller's stream holds right now (the
     // consumers of the output rows it overwrites, uploads of RIR rows it reads); the caller's stream sees the result after
@@ -974,5 +990,121 @@ static int sims_to_units(ss_ctx* h, const ss_sim_columns* sc, int n, int* w, int
     return 0;
 }
 
+// ---- length-bucketed RIR bank ---------------------------------------------------------------------------
+// buckets[0..n): HOST array; bucket b holds bank entries [first_b, first_b + n_entries_b) as planar rows of cap_b samples
+// in an allocation of its own.  Bucket 0 fills the legacy fields of ConvParams, the others p.bk[].
+static int fill_buckets(ssk::ConvParams& p, const ss_rir_bucket* bk, int n_buckets, bool spectral, int* nbh_max) {
+    if (!bk || n_buckets < 1 || n_buckets > ssk::kMaxBuckets) return SS_EINVAL;
+    int hb_max = 1;
+    for (int b = 0; b < n_buckets; ++b) {
+        if (!bk[b].rir || bk[b].cap < 2 || (bk[b].cap & 1) || bk[b].n_entries < 0 || bk[b].first < 0) return SS_EINVAL;
+        if (b && bk[b].first < bk[b - 1].first + bk[b - 1].n_entries) return SS_EINVAL;     // ascending, disjoint ranges
+        if (spectral && !bk[b].hspec) return SS_EINVAL;
+        hb_max = std::max(hb_max, (bk[b].cap + ssk::kB - 1) / ssk::kB);
+    }
+    if (bk[0].first != 0) return SS_EINVAL;
+    p.rir = bk[0].rir;
+    p.rir_unit_stride = 2LL * bk[0].cap;
+    p.rir_chan_stride = bk[0].cap;
+    p.rir_elem_stride = 1;
+    p.rir_cap = bk[0].cap;
+    p.hspec = spectral ? reinterpret_cast<const ssk::f32x4*>(bk[0].hspec) : nullptr;
+    p.h_blocks = spectral ? (bk[0].cap + ssk::kB - 1) / ssk::kB : 0;
+    p.n_buckets = n_buckets;
+    for (int b = 1; b < n_buckets; ++b)
+        p.bk[b - 1] = ssk::BankBucket{bk[b].rir, reinterpret_cast<const ssk::f32x4*>(bk[b].hspec), bk[b].first, bk[b].cap,
+                                      (bk[b].cap + ssk::kB - 1) / ssk::kB, 0};
+    *nbh_max = hb_max;
+    return 0;
+}
+
+static bool buckets_spectral(const ss_rir_bucket* bk, int n_buckets, int flags) {
+    if (!bk || (flags & SS_FLAG_CROSSFADE)) return false;
+    for (int b = 0; b < n_buckets; ++b) if (!bk[b].hspec) return false;
+    return n_buckets > 0;
+}
+
 extern "C" {
+
+int ss_fftconv_binaural_buckets_f32(const float* spec, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len,
+                                    const int* unit_desc, float* out, int n_units, int n_valid, int out_len, int flags,
+                                    void* stream) {
+    if (n_units == 0) return 0;
+    if (!out || n_units < 0 || !buckets || n_buckets < 1) return SS_EINVAL;
+    const bool spectral = buckets_spectral(buckets, n_buckets, flags);
+    ssk::ConvParams p;
+    int n_cus = 1, nbh_max = 1;
+    int rc = fill_conv(p, &n_cus, spec, buckets[0].rir, rir_len, unit_desc, 2LL * buckets[0].cap, buckets[0].cap, 1,
+                       buckets[0].cap, n_valid, out_len);
+    if (rc == 0) rc = fill_buckets(p, buckets, n_buckets, spectral, &nbh_max);
+    if (rc) return rc;
+    p.out = out;
+    const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
+    if (spectral) return launch_conv_spec<false>(p, n_units, nb_y, flags, static_cast<hipStream_t>(stream), n_cus);
+    return launch_conv<false>(p, n_units, nb_y, flags, n_cus, static_cast<hipStream_t>(stream));
+}
+
+int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len,
+                             const int* unit_desc, float* audiogoal, float* spectrogram, int n_units, int n_valid,
+                             int out_len, int pad_mode, int flags, void* stream) {
+    if (n_units == 0) return 0;
+    if (!spectrogram || n_units < 0 || !buckets || n_buckets < 1) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (out_len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    const bool spectral = buckets_spectral(buckets, n_buckets, flags);
+    ssk::ConvParams p;
+    int n_cus = 1, nbh_max = 1;
+    int rc = fill_conv(p, &n_cus, spec, buckets[0].rir, rir_len, unit_desc, 2LL * buckets[0].cap, buckets[0].cap, 1,
+                       buckets[0].cap, n_valid, out_len);
+    if (rc == 0) rc = fill_buckets(p, buckets, n_buckets, spectral, &nbh_max);
+    if (rc) return rc;
+    p.pad_mode = pad_mode;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out_len <= ssk::kB && p.t4 <= 26) {
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return spectral ? launch_conv_spec<true>(p, n_units, 1, flags, st) : launch_conv<true>(p, n_units, 1, flags, n_cus, st);
+    }
+    if (obs_rows_ok(out_len, n_valid, nbh_max, flags)) {
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return spectral ? launch_obs_rows<true>(p, n_units, flags, n_cus, st) : launch_obs_rows<false>(p, n_units, flags, n_cus, st);
+    }
+    if (!audiogoal) return SS_EINVAL;                   // cross-faded long rows hand over through memory
+    rc = ss_fftconv_binaural_buckets_f32(spec, buckets, n_buckets, rir_len, unit_desc, audiogoal, n_units, n_valid, out_len,
+                                         flags, stream);
+    if (rc) return rc;
+    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+}
+
+// The context's bank as length buckets (replaces ss_ctx_set_rir_bank + ss_ctx_set_rir_spectra for such banks; borrowed
+// device pointers, the array itself is copied).  Steps whose units all sit in bucket 0 keep the loop-free kernels.
+int ss_ctx_set_rir_buckets(ss_ctx* h, const ss_rir_bucket* buckets, int n_buckets, const int* rir_len) {
+    if (!h || !buckets || !rir_len || n_buckets < 1 || n_buckets > ssk::kMaxBuckets) return SS_EINVAL;
+    ssk::ConvParams probe;
+    int hb_max = 1;
+    for (auto& b : probe.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
+    int rc = fill_buckets(probe, buckets, n_buckets, false, &hb_max);
+    if (rc) return rc;
+    ssctx::Context& c = h->c;
+    const int nbh_old = c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1;
+    c.buckets.assign(buckets, buckets + n_buckets);
+    c.rir = buckets[0].rir; c.rir_len = rir_len; c.rir_us = 2LL * buckets[0].cap; c.rir_cs = buckets[0].cap; c.rir_es = 1;
+    c.rir_cap = hb_max * c.kb;                                 // planning depth: the longest bucket's blocks
+    c.hspec = nullptr; c.h_blocks = 0;
+    if (hb_max != nbh_old) {                                   // the set of partition offsets per key changes
+        const int nby = c.n_valid > 0 ? ssctx::ceil_div(c.n_valid, c.kb) : 1;
+        c.stride = hb_max + nby - 1;
+        ssctx::cache_reset(c);
+        if (c.pool) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return hip_err(e);
+            (void)hipFree(c.pool);
+            c.pool = nullptr;
+            c.pool_entries = 0;
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -811,6 +811,15 @@ __global__ __launch_bounds__(256) void k_gccphat(GccParams p) {
 // Y_j = sum over (term, RIR block i) of H_i * S_{j-i}; one accumulator per workgroup, so multi-block rows
 // (44.1 kHz: 3 output blocks) re-run the forward FFTs per output block instead of holding 3 accumulators
 // (96 VGPRs) that a 1024-thread workgroup does not have.
+constexpr int kMaxBuckets = 4;
+struct BankBucket {
+    const float* rir;            // planar [n, 2, cap] rows, zero beyond each entry's length
+    const f32x4* hspec;          // spectral form [n][2][h_blocks][8192] f32x4, or nullptr
+    int first;                   // global bank index of the bucket's entry 0
+    int cap;                     // samples per (entry, ear) row (even)
+    int h_blocks;                // ceil(cap / kB)
+    int pad_;
+};
 struct ConvParams {
     const f32x4* spec;          // [slots][8192] f32x4 (kernel order, see k_source_windows)
     const float* rir;            // RIR bank
@@ -839,6 +848,13 @@ struct ConvParams {
     f32x4* stash;
     int stash_nbh, stash_terms;
     int n_terms;                 // k_obs_rows: descriptor terms read per unit (1 under SS_FLAG_NO_DISTRACTOR)
+    // Length-bucketed bank: bank entries [bk[b].first, next bucket's first) live in bucket b + 1, an
+    // allocation of its own with its own row capacity; entries below bk[0].first are bucket 0 = the fields above (rir /
+    // rir_*_stride / rir_cap, hspec / h_blocks).  n_buckets = 1: one bank, as before.  The loop-free kernels (SIMPLE,
+    // k_conv_rows, k_conv_spec_rows) only ever see bucket-0 entries (the launcher checks); the loop kernels resolve the
+    // bucket per term from the wave-uniform bank index (scalar compares, no memory access).
+    int n_buckets;
+    BankBucket bk[kMaxBuckets - 1];
 #if defined(SS_LADDER)
     int dbg;                     // timing experiments only (scripts/gpu_ladder.sh, -DSS_LADDER builds): early exit point
 #endif
@@ -855,10 +871,37 @@ __device__ __forceinline__ int row_slot(int b, int G, int on) {
     return x * q + min(x, r) + (b >> 3);
 }
 
+// Time-domain row of bank entry ridx, ear ch: address, row capacity and element stride (wave-uniform).
+struct BankRow { const float* h; int cap, es; };
+__device__ __forceinline__ BankRow bank_row(const ConvParams& p, int ridx, int ch) {
+    BankRow r{p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride, p.rir_cap, p.rir_elem_stride};
+#pragma unroll
+    for (int b = 0; b < kMaxBuckets - 1; ++b)
+        if (b + 1 < p.n_buckets && ridx >= p.bk[b].first) {
+            r.h = p.bk[b].rir + ((size_t)(ridx - p.bk[b].first) * 2 + ch) * p.bk[b].cap;
+            r.cap = p.bk[b].cap;
+            r.es = 1;
+        }
+    return r;
+}
+// Spectral row of bank entry ridx, ear ch: first block spectrum and the number of blocks stored per row.
+struct BankSpec { const f32x4* hp; int h_blocks; };
+__device__ __forceinline__ BankSpec bank_spec(const ConvParams& p, int ridx, int ch) {
+    BankSpec r{p.hspec + ((size_t)ridx * 2 + ch) * (size_t)p.h_blocks * (kSpecComplex / 2), p.h_blocks};
+#pragma unroll
+    for (int b = 0; b < kMaxBuckets - 1; ++b)
+        if (b + 1 < p.n_buckets && ridx >= p.bk[b].first) {
+            r.hp = p.bk[b].hspec + ((size_t)(ridx - p.bk[b].first) * 2 + ch) * (size_t)p.bk[b].h_blocks * (kSpecComplex / 2);
+            r.h_blocks = p.bk[b].h_blocks;
+        }
+    return r;
+}
+
 // forward FFT of RIR block i of one ear + multiply by the window spectrum `slot` -> acc (= or +=)
 template <bool ACCUMULATE, bool PREFETCH>
-__device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const float* h,
+__device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const BankRow& br,
                                            int L, int i, int slot, c32 (&acc)[2][8]) {
+    const float* h = br.h;
     // PREFETCH = issue the 8 window-spectrum loads (L2/MALL hits) at the start of pass 3 instead of at the item
     // stage, so their latency hides under pass 3.  (Issuing them before pass 1 was measured SLOWER, +1.2 us:
     // 128 KB of L2 reads queue ahead of the RIR's HBM loads on the in-order vmcnt path.)  Only the loop-free
@@ -866,7 +909,7 @@ __device__ __forceinline__ void conv_block(c32* lds, const ConvParams& p, const 
     const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
     f32x4 sv[2][4];
     // bank rows are zero-padded to rir_cap, so the only bound is the row capacity (L is used for block counts)
-    const int lo = i * kB, es = p.rir_elem_stride, cap = p.rir_cap;
+    const int lo = i * kB, es = br.es, cap = br.cap;
     (void)L;
     if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
         const c32* h2 = reinterpret_cast<const c32*>(h + lo);
@@ -1133,7 +1176,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                 present = true;
                 const int L = uniform_load(p.rir_len + ridx);
                 const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
-                const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
+                const BankRow br = bank_row(p, ridx, ch);
                 const int nbh = (L + kB - 1) / kB;
                 for (int i = 0; i < nbh; ++i) {
                     const int m = j - i;
@@ -1143,11 +1186,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                     int tl = t;
                     SSK_OPAQUE1(tl);
                     if (!any) {
-                        conv_block<false, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
+                        conv_block<false, false>(lds, p, tw, tl, br, L, i, spec0 + (m - m_min), acc);
                         any = true;
                     } else {
                         lds_barrier();                   // previous block's item reads of layout B are done
-                        conv_block<true, false>(lds, p, tw, tl, h, L, i, spec0 + (m - m_min), acc);
+                        conv_block<true, false>(lds, p, tw, tl, br, L, i, spec0 + (m - m_min), acc);
                     }
                 }
             }
@@ -1310,14 +1353,15 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
             const int ridx = dw.x;
             if (ridx < 0) continue;
             const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
-            int nbh = p.h_blocks;
+            const BankSpec bs = bank_spec(p, ridx, ch);
+            int nbh = bs.h_blocks;
             if (nbh > 1) nbh = min(nbh, (uniform_load(p.rir_len + ridx) + kB - 1) / kB);
             for (int i = 0; i < nbh; ++i) {
                 const int m = j - i;
                 if (m < m_min || m >= m_min + m_cnt) continue;
                 int tl = t;
                 SSK_OPAQUE1(tl);
-                const f32x4* hp = hspec_base + ((size_t)ridx * 2 + ch) * row_f4 + (size_t)i * (kSpecComplex / 2) + tl;
+                const f32x4* hp = bs.hp + (size_t)i * (kSpecComplex / 2) + tl;
                 spec_block_product(spec_base, tl, hp, spec0 + (m - m_min), any, acc);
                 any = true;
             }
@@ -1631,10 +1675,11 @@ __host__ __device__ constexpr int pooled_blocks_complete(int known) {
 // forward FFT of RIR block i (time-domain bank) -> acc (= or +=) H'_i * S'[slot]; `st` != nullptr: H'_i is also written
 // to the stash (thread t's 8 f32x4 at st[(s*4+h)*1024], the order every consumer load uses)
 template <bool ACCUMULATE>
-__device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const float* h,
+__device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const BankRow& br,
                                                  int i, int slot, f32x4* st, c32 (&acc)[2][8]) {
     const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
-    const int lo = i * kB, es = p.rir_elem_stride, cap = p.rir_cap;
+    const float* h = br.h;
+    const int lo = i * kB, es = br.es, cap = br.cap;
     if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
         const c32* h2 = reinterpret_cast<const c32*>(h + lo);
         const int m_end = (cap - lo) >> 1;
@@ -1761,7 +1806,10 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         int nbh0 = 0, nbh1 = 0;
         if (dws[0].x >= 0) nbh0 = (uniform_load(p.rir_len + dws[0].x) + kB - 1) / kB;
         if (dws[1].x >= 0) nbh1 = (uniform_load(p.rir_len + dws[1].x) + kB - 1) / kB;
-        if (SPECTRAL) { nbh0 = min(nbh0, p.h_blocks); nbh1 = min(nbh1, p.h_blocks); }
+        if (SPECTRAL) {
+            if (dws[0].x >= 0) nbh0 = min(nbh0, bank_spec(p, dws[0].x, 0).h_blocks);
+            if (dws[1].x >= 0) nbh1 = min(nbh1, bank_spec(p, dws[1].x, 0).h_blocks);
+        }
         if (dws[0].x < 0 && dws[1].x < 0) {               // silent unit (simulator.py:610-612): exact zeros, no transforms
             int tz = t;
             SSK_OPAQUE1(tz);                              // nothing of these loops is worth a register outside them
@@ -1800,7 +1848,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                         int ti = tl;
                         SSK_OPAQUE1(ti);
                         if (SPECTRAL) {
-                            const f32x4* hp = p.hspec + (((size_t)ridx * 2 + ch) * p.h_blocks + i) * blk_f4 + ti;
+                            const f32x4* hp = bank_spec(p, ridx, ch).hp + (size_t)i * blk_f4 + ti;
                             spec_block_product(p.spec, ti, hp, slot, true, acc);
                         } else {
                             const int sidx = term * p.stash_nbh + i;
@@ -1812,9 +1860,8 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                                 const bool keep = stash != nullptr && j + 1 < p.nb_y && m + 1 < m_min + m_cnt &&
                                                   !(kRowsAbl & 32) && (!(kRowsAbl & 64) || i == 0);
                                 f32x4* st = keep && !(kRowsAbl & 2) ? stash + (size_t)sidx * blk_f4 : nullptr;
-                                const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
                                 if (lds_used) lds_barrier();          // the previous block's item reads of layout B are done
-                                conv_block_stash<true>(lds, p, tw, ti, h, i, slot, st, acc);
+                                conv_block_stash<true>(lds, p, tw, ti, bank_row(p, ridx, ch), i, slot, st, acc);
                                 lds_used = true;
                                 if (keep) computed |= 1u << sidx;
                             }

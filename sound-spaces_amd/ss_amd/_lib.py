@@ -13,7 +13,14 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_create", "ss_ctx_destroy", "ss_ctx_add_source", "ss_ctx_add_source_len", "ss_ctx_set_rir_bank",
            "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
-           "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join")
+           "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
+           "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets")
+
+
+class SsRirBucket(ctypes.Structure):
+    """struct ss_rir_bucket of include/ss_hip.h."""
+    _fields_ = [("rir", ctypes.c_void_p), ("hspec", ctypes.c_void_p), ("first", ctypes.c_int), ("n_entries", ctypes.c_int),
+                ("cap", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 class SsSimColumns(ctypes.Structure):
@@ -69,6 +76,9 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_sims_units.argtypes = [vp, ctypes.POINTER(SsSimColumns), c_int, vp, vp, vp]
     lib.ss_ctx_set_rir_spectra.argtypes = [vp, vp, c_int]
     lib.ss_ctx_set_overlap.argtypes = [vp, c_int]
+    lib.ss_fftconv_binaural_buckets_f32.argtypes = [vp, vp, c_int, vp, vp, vp, c_int, c_int, c_int, c_int, vp]
+    lib.ss_audio_obs_buckets_f32.argtypes = [vp, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_ctx_set_rir_buckets.argtypes = [vp, vp, c_int, vp]
     lib.ss_ctx_join.argtypes = [vp, vp]
     lib.ss_rir_spectra_f32.argtypes = [vp, vp, c_int, c_ll, c_int, c_int, vp]
     lib.ss_fftconv_binaural_spec_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]

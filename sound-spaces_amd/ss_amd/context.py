@@ -102,6 +102,17 @@ class AudioContext:
         self.rir_cap = int(cap)
         self._spectra = None
 
+    def set_rir_buckets(self, bank, spectral: bool = False) -> None:
+        """A length-bucketed bank (``ss_amd.renderer.BucketedRirBank``; include/ss_hip.h ``ss_ctx_set_rir_buckets``):
+        steps whose units all sit in bucket 0 keep the loop-free kernel, long RIRs live in buckets of their own.
+        ``spectral``: use the buckets' spectral forms (every bucket must have one)."""
+        arr = bank.c_array(bool(spectral))
+        _lib.check(self.lib.ss_ctx_set_rir_buckets(self._h, ctypes.cast(arr, ctypes.c_void_p), len(bank.banks),
+                                                   bank.lengths.data_ptr()), "ss_ctx_set_rir_buckets")
+        self._bank = (bank, arr)
+        self.rir_cap = int(bank.cap)
+        self._spectra = None
+
     def set_rir_spectra(self, hspec) -> None:
         """Spectral form of the bank set by set_rir_bank() (ops.rir_spectra / RirBank.build_spectra): steps without a
         cross-fade then run k_conv_spec.  None switches back to the time-domain kernels."""
@@ -164,6 +175,19 @@ class AudioContext:
             stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(self.lib.ss_ctx_observe(self._h, ctypes.byref(u), n, ag, sg, stream), "ss_ctx_observe")
+
+    def prepare(self, sound, t0, rir, dis_sound=None, dis_rir=None, last_rir=None, wrap=None, last_wrap=None):
+        """Unit columns converted ONCE into the ss_units struct ``observe_prepared`` takes (callers that replay known steps -
+        bench.py, tests - or keep their columns in place and only rewrite the values: the arrays are borrowed)."""
+        u, n, keep = self._units(sound, t0, rir, dis_sound, dis_rir, last_rir, wrap, last_wrap)
+        return dict(u=u, ref=ctypes.byref(u), n=n, keep=keep)
+
+    def observe_prepared(self, prep, spectrogram_ptr, audiogoal_ptr, stream: int) -> None:
+        """``observe`` without the per-call conversions: raw device pointers (int or None) and a raw hipStream_t; the
+        current device must be the context's.  ~3 us of Python per call instead of ~30."""
+        rc = self.lib.ss_ctx_observe(self._h, prep["ref"], prep["n"], audiogoal_ptr, spectrogram_ptr, stream)
+        if rc != 0:
+            _lib.check(rc, "ss_ctx_observe")
 
     def bind_sims(self, state, index, has_distractor: bool = False):
         """Pointers to the int64 state columns (``ss_amd.vector.VectorSimState``) and the RIR index tables, for

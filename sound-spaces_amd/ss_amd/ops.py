@@ -20,6 +20,7 @@ from .planning import KB, SPEC_FLOATS, ceil_div, spectrogram_shape
 PAD_REFLECT, PAD_CONSTANT = 0, 1
 FLAG_NO_DISTRACTOR = 1      # SS_FLAG_NO_DISTRACTOR: every unit descriptor has term 1 absent
 FLAG_CROSSFADE = 2          # SS_FLAG_CROSSFADE: term 1 = previous step's RIR, blended over the first int(0.05*sr)+1 samples
+FLAG_FIRST_BUCKET = 4       # SS_FLAG_FIRST_BUCKET: every bank index of the launch lies in bucket 0 of a bucketed bank
 
 _PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
 
@@ -221,6 +222,48 @@ def audio_obs_spec_into(spec, hspec, rir_len, unit_desc, audiogoal, spectrogram_
                                                      unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N,
                                                      hspec.shape[2], n_valid, out_len, _PAD[pad_mode], flags, _stream()),
                    "ss_audio_obs_spec_f32")
+
+
+# ---- length-bucketed RIR bank ------------------------------------------------------------------------
+def bucket_array(banks, firsts, spectral: bool):
+    """ctypes array of ss_rir_bucket for per-bucket (data [n,2,cap], spectra or None) tensors; keep it alive with the
+    tensors it points to."""
+    arr = (_lib.SsRirBucket * len(banks))()
+    for b, (bank, first) in enumerate(zip(banks, firsts)):
+        _chk(bank.data, torch.float32, "bucket data")
+        arr[b].rir = bank.data.data_ptr()
+        arr[b].hspec = bank.spectra.data_ptr() if (spectral and bank.spectra is not None) else None
+        arr[b].first, arr[b].n_entries, arr[b].cap, arr[b].reserved = int(first), int(bank.data.shape[0]), int(bank.data.shape[2]), 0
+    return arr
+
+
+def audio_obs_buckets_into(spec, buckets, n_buckets: int, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int,
+                           out_len: int, pad_mode="reflect", flags: int = 0) -> None:
+    """``audio_obs_into`` on a length-bucketed bank: ``buckets`` = ``bucket_array(...)``, rir_len int32 [total slots]."""
+    _chk(spec, torch.float32, "spec"); _chk(rir_len, torch.int32, "rir_len"); _chk(unit_desc, torch.int32, "unit_desc")
+    N = unit_desc.shape[0]
+    ag_ptr = sg_ptr = None
+    if audiogoal is not None:
+        _chk(audiogoal, torch.float32, "audiogoal")
+        assert tuple(audiogoal.shape) == (N, 2, out_len)
+        ag_ptr = audiogoal.data_ptr()
+    with torch.cuda.device(spec.device):
+        if spectrogram_out is None:
+            _lib.check(_lib.load().ss_fftconv_binaural_buckets_f32(spec.data_ptr(), ctypes_ref(buckets), n_buckets,
+                                                                   rir_len.data_ptr(), unit_desc.data_ptr(), ag_ptr, N, n_valid,
+                                                                   out_len, flags, _stream()), "ss_fftconv_binaural_buckets_f32")
+            return
+        _chk(spectrogram_out, torch.float32, "spectrogram_out")
+        assert tuple(spectrogram_out.shape) == (N,) + spectrogram_shape(out_len)
+        sg_ptr = spectrogram_out.data_ptr()
+        _lib.check(_lib.load().ss_audio_obs_buckets_f32(spec.data_ptr(), ctypes_ref(buckets), n_buckets, rir_len.data_ptr(),
+                                                        unit_desc.data_ptr(), ag_ptr, sg_ptr, N, n_valid, out_len,
+                                                        _PAD[pad_mode], flags, _stream()), "ss_audio_obs_buckets_f32")
+
+
+def ctypes_ref(arr):
+    import ctypes
+    return ctypes.cast(arr, ctypes.c_void_p)
 
 
 def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:

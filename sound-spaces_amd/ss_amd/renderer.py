@@ -102,6 +102,78 @@ class RirBank:
         return int(self.data.shape[0])
 
 
+class BucketedRirBank:
+    """A RIR bank as LENGTH BUCKETS (include/ss_hip.h ``ss_rir_bucket``): bucket b is a ``RirBank`` of its
+    own (rows of ``cap_b`` samples) holding the global bank indices ``[first_b, first_b + len(bucket b))``; ``lengths`` is
+    ONE int32 tensor over all indices (the buckets' own ``lengths`` are views of it).  A 3-s RIR lands in a long bucket
+    without lengthening - or reallocating - the rows of the short ones, and launches whose units all sit in bucket 0 keep
+    the loop-free kernel."""
+
+    def __init__(self, banks: Sequence[RirBank], lengths: torch.Tensor, firsts: Optional[Sequence[int]] = None):
+        assert 1 <= len(banks) <= 4
+        self.banks = list(banks)
+        self.first = list(firsts) if firsts is not None else list(np.cumsum([0] + [len(b) for b in banks[:-1]]))
+        assert self.first[0] == 0 and all(self.first[b + 1] >= self.first[b] + len(banks[b]) for b in range(len(banks) - 1))
+        self.lengths = lengths
+        self._carr = None                       # (ctypes array, spectral?) cache; refresh() after a bucket was reallocated
+
+    @property
+    def cap(self) -> int:                       # planning depth: the longest bucket
+        return max(b.cap for b in self.banks)
+
+    @property
+    def spectra(self):                          # "every bucket has its spectral form"
+        return all(b.spectra is not None for b in self.banks) or None
+
+    def build_spectra(self) -> None:
+        for b in self.banks:
+            b.build_spectra()
+        self._carr = None
+
+    def refresh(self) -> None:
+        self._carr = None
+
+    def c_array(self, spectral: bool):
+        if self._carr is None or self._carr[1] != spectral or self._carr[2] != [b.data.data_ptr() for b in self.banks]:
+            self._carr = (ops.bucket_array(self.banks, self.first, spectral), spectral, [b.data.data_ptr() for b in self.banks])
+        return self._carr[0]
+
+    def bucket_of(self, index: int) -> int:
+        b = 0
+        while b + 1 < len(self.first) and index >= self.first[b + 1]:
+            b += 1
+        return b
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    @staticmethod
+    def from_arrays(rirs: Sequence[Optional[np.ndarray]], device, caps: Sequence[int]) -> "BucketedRirBank":
+        """rirs[i] as for ``RirBank.from_arrays``; ``caps`` = ascending bucket capacities (the last one must hold the
+        longest RIR).  Entry i keeps GLOBAL index order inside its bucket; returns the bank and sets ``index_of[i]`` =
+        the global bank index of input i."""
+        lens = [0 if (r is None or np.size(r) == 0) else max(np.shape(r)) for r in rirs]
+        caps = [c + (c & 1) for c in caps]
+        which = [next(b for b, c in enumerate(caps) if L <= c) for L in lens]
+        banks, firsts, index_of, first = [], [], [0] * len(rirs), 0
+        for b, cap in enumerate(caps):
+            members = [i for i, w in enumerate(which) if w == b]
+            bank = RirBank.from_arrays([rirs[i] for i in members] or [None], device, cap=cap)
+            for k, i in enumerate(members):
+                index_of[i] = first + k
+            banks.append(bank)
+            firsts.append(first)
+            first += len(bank)
+        lengths = torch.cat([b.lengths for b in banks])
+        off = 0
+        for b in banks:                                            # the buckets' lengths become views of the global tensor
+            b.lengths = lengths[off:off + len(b)]
+            off += len(b)
+        out = BucketedRirBank(banks, lengths, firsts)
+        out.index_of = index_of
+        return out
+
+
 @dataclass
 class UnitRequest:
     """What one env contributes per step (the reference state read by _compute_audiogoal):
@@ -243,7 +315,14 @@ class BatchedAudioRenderer:
                 desc[n] = P.unit_desc_row(u.rir, s0, ws)
         if xfade:
             flags = ops.FLAG_CROSSFADE
+        flags |= self._bucket_flag(max([max(u.rir, u.dis_rir, u.last_rir) for u in units if not u.silent] + [-1]))
         return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), flags)
+
+    def _bucket_flag(self, max_index: int) -> int:
+        """SS_FLAG_FIRST_BUCKET for a launch on a bucketed bank whose highest bank index is `max_index`."""
+        if isinstance(self.rirs, BucketedRirBank) and len(self.rirs.first) > 1 and max_index < self.rirs.first[1]:
+            return ops.FLAG_FIRST_BUCKET
+        return 0
 
     def plan_arrays(self, sound: np.ndarray, t0: np.ndarray, rir: np.ndarray, rotations: int = 1) -> Plan:
         """Vectorised plan() for the common no-distractor case (rir < 0 = silent): the per-step host cost is a handful
@@ -275,7 +354,8 @@ class BatchedAudioRenderer:
             idx = np.flatnonzero(active)[ok]
             desc[idx, 0] = rir[active][ok]
             desc[idx, 1:4] = rows[ok]
-        return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True), ops.FLAG_NO_DISTRACTOR)
+        return Plan(torch.from_numpy(desc).to(self.device, non_blocking=True),
+                    ops.FLAG_NO_DISTRACTOR | self._bucket_flag(int(rir.max()) if rir.size else -1))
 
     # ---- rendering ---------------------------------------------------------------------------------------
     def render(self, plan: Plan, want_audiogoal: bool = False,
@@ -291,7 +371,11 @@ class BatchedAudioRenderer:
         sg = spectrogram_out
         if sg is None:
             sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
-        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        if isinstance(self.rirs, BucketedRirBank):
+            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE)
+            ops.audio_obs_buckets_into(self._spec, self.rirs.c_array(spectral), len(self.rirs.banks), self.rirs.lengths,
+                                       plan.desc, ag, sg, self.n_valid, self.out_len, self.pad_mode, flags=plan.flags)
+        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
             ops.audio_obs_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
                                     self.out_len, self.pad_mode, flags=plan.flags)
         else:
@@ -303,7 +387,11 @@ class BatchedAudioRenderer:
         """AudioGoalSensor-only configurations (soundspaces/tasks/nav.py:37-60)."""
         if out is None:
             out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
-        if self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        if isinstance(self.rirs, BucketedRirBank):
+            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE)
+            ops.audio_obs_buckets_into(self._spec, self.rirs.c_array(spectral), len(self.rirs.banks), self.rirs.lengths,
+                                       plan.desc, out, None, self.n_valid, self.out_len, self.pad_mode, flags=plan.flags)
+        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
             ops.fftconv_binaural_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, out, self.n_valid,
                                            flags=plan.flags)
         else:
@@ -562,6 +650,141 @@ class RirStore:
         return out
 
 
+class BucketedRirStore:
+    """``RirStore`` over a LENGTH-BUCKETED bank: one sub-store per bucket, each with its own fixed row
+    capacity and its own LRU; a key lives in the smallest bucket that holds its (longest) RIR.  Global slot = the
+    bucket's first index + the sub-store's slot, so unit descriptors and ``host_len`` work as with one bank.
+
+    What it fixes against the single-capacity store: a long RIR (an SS2.0 ray-traced 3-s response, one long wav among
+    short ones) no longer reallocates and copies the whole bank at the new capacity in the middle of an episode, does not
+    multiply the HBM of every slot, and launches whose units all sit in bucket 0 keep the loop-free kernel.  Only the
+    LAST bucket may still grow (up to ``max_cap``), and then only its own rows move.
+
+    ``caps`` ascending (samples; bucket 0 <= one partition block keeps the loop-free kernel), ``slots[b]`` entries each."""
+
+    def __init__(self, slots: Sequence[int], caps: Sequence[int], device, truncate_to: Optional[int] = None,
+                 max_cap: int = 1 << 18, on_grow=None, group: int = 1, spectral: bool = False):
+        assert len(slots) == len(caps) and 1 <= len(caps) <= 4 and list(caps) == sorted(caps)
+        self.device = torch.device(device)
+        self.group, self.on_grow, self.spectral = group, on_grow, spectral
+        self.first = [int(v) for v in np.cumsum([0] + list(slots[:-1]))]
+        total = int(sum(slots))
+        lengths = torch.zeros((total,), dtype=torch.int32, device=self.device)
+        self.host_len = np.zeros((total,), np.int32)
+        self.stores: List[RirStore] = []
+        for b, (n, cap) in enumerate(zip(slots, caps)):
+            last = b == len(caps) - 1
+            st = RirStore(n, cap, device, truncate_to=truncate_to, max_cap=max_cap if last else cap + (cap & 1),
+                          on_grow=self._sub_grown, group=group, spectral=spectral)
+            st.bank.lengths = lengths[self.first[b]:self.first[b] + n]        # views of the one global array
+            st.host_len = self.host_len[self.first[b]:self.first[b] + n]
+            self.stores.append(st)
+        self.bank = BucketedRirBank([st.bank for st in self.stores], lengths, self.first)
+        self.slots = total
+        self._where: Dict[object, int] = {}
+
+    # -- the RirStore interface the engine / loaders use
+    @property
+    def truncate_to(self):
+        return self.stores[0].truncate_to
+
+    @truncate_to.setter
+    def truncate_to(self, v):
+        for st in self.stores:
+            st.truncate_to = v
+
+    @property
+    def cap(self) -> int:
+        return max(st.cap for st in self.stores)
+
+    @property
+    def hits(self) -> int:
+        return sum(st.hits for st in self.stores)
+
+    @property
+    def misses(self) -> int:
+        return sum(st.misses for st in self.stores)
+
+    @property
+    def grown(self) -> int:
+        return sum(st.grown for st in self.stores)
+
+    def _sub_grown(self, _bank) -> None:                          # (only the last bucket can: its rows alone moved)
+        self.bank = BucketedRirBank([st.bank for st in self.stores], self.bank.lengths, self.first)
+        if self.on_grow is not None:
+            self.on_grow(self.bank)
+
+    def begin_batch(self) -> None:
+        for st in self.stores:
+            st.begin_batch()
+
+    def clear(self) -> None:
+        for st in self.stores:
+            st.clear()
+        self._where.clear()
+
+    def sync_spectra(self) -> int:
+        return sum(st.sync_spectra() for st in self.stores)
+
+    def _bucket_for(self, loaded) -> int:
+        items = [loaded] if self.group == 1 else (list(loaded) if loaded is not None else [None])
+        n = max([self.stores[0]._kept_len(_planar(r).shape[1]) for r in items] + [0])
+        for b, st in enumerate(self.stores[:-1]):
+            if n <= st.cap:
+                return b
+        return len(self.stores) - 1
+
+    def slot(self, key, loader, refresh: bool = False) -> int:
+        b = self._where.get(key)
+        if b is not None and key not in self.stores[b]._slot_of:  # evicted from its bucket meanwhile
+            b = None
+        if b is not None and not refresh:
+            st = self.stores[b]
+            clipped_reload = st.truncate_to is None and st._clipped[st._slot_of[key]:st._slot_of[key] + self.group].any()
+            if not clipped_reload:
+                return self.first[b] + st.slot(key, loader, False)
+        loaded = loader()                                          # miss, live refresh, or a row that must be re-read whole
+        nb = self._bucket_for(loaded)
+        if b is not None and b != nb:                              # the key changes length class: leave the old bucket
+            old = self.stores[b]
+            old._free.append(old._slot_of.pop(key))
+        self._where[key] = nb
+        st = self.stores[nb]
+        return self.first[nb] + st.slot(key, lambda: loaded, refresh=key in st._slot_of)
+
+    def slot_many(self, keys: Sequence, loaders: Sequence, workers: int = 8) -> List[int]:
+        """Bulk load: files are read in parallel, then routed bucket by bucket through the sub-stores' own ``slot_many``
+        (one H2D block copy per bucket)."""
+        from concurrent.futures import ThreadPoolExecutor
+        out: List[int] = [-1] * len(keys)
+        todo = []
+        for i, key in enumerate(keys):
+            b = self._where.get(key)
+            if b is not None and key in self.stores[b]._slot_of:
+                out[i] = self.first[b] + self.stores[b].slot(key, loaders[i])
+            else:
+                todo.append(i)
+        uniq = list({keys[i]: i for i in reversed(todo)}.values())[::-1]
+        if workers > 1 and len(uniq) > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                loaded = dict(zip(uniq, pool.map(lambda i: loaders[i](), uniq)))
+        else:
+            loaded = {i: loaders[i]() for i in uniq}
+        per_bucket: Dict[int, List[int]] = {}
+        for i in uniq:
+            per_bucket.setdefault(self._bucket_for(loaded[i]), []).append(i)
+        for b, idx in per_bucket.items():
+            got = self.stores[b].slot_many([keys[i] for i in idx], [(lambda i=i: loaded[i]) for i in idx], workers=1)
+            for i, sl in zip(idx, got):
+                self._where[keys[i]] = b
+                out[i] = self.first[b] + sl
+        for i in todo:
+            if out[i] < 0:
+                b = self._where[keys[i]]
+                out[i] = self.first[b] + self.stores[b]._slot_of[keys[i]]
+        return out
+
+
 def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 90, 180, 270), limit: Optional[int] = None,
                     batch: int = 256, workers: int = 8):
     """Bulk pre-load of one scene's binaural RIRs, `<scene_rir_dir>/<azimuth>/<receiver>_<source>.wav`
@@ -593,12 +816,21 @@ class AudioEngine:
     use, longer RIRs grow the bank (RirStore)."""
 
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
-                 rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: bool = False, **renderer_kwargs):
+                 rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: bool = False,
+                 rir_buckets: Optional[Sequence[Tuple[int, int]]] = None, **renderer_kwargs):
         """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec (no
         forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change every step and stay
         on the time-domain kernels."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
+        if rir_buckets:
+            # length-bucketed bank: [(slots, cap samples), ...] ascending, e.g. [(4096, 16000), (256, 49152), (64, 65536)]
+            self.store = BucketedRirStore([b[0] for b in rir_buckets], [b[1] for b in rir_buckets], self.renderer.device,
+                                          truncate_to=None if full else int(sampling_rate), max_cap=rir_max_cap,
+                                          on_grow=self.renderer.set_rir_bank, group=rir_group,
+                                          spectral=rir_spectral and not full)
+            self.renderer.set_rir_bank(self.store.bank)
+            return
         self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device,
                               truncate_to=None if full else int(sampling_rate), max_cap=rir_max_cap,
                               on_grow=self.renderer.set_rir_bank, group=rir_group, spectral=rir_spectral and not full)

@@ -93,6 +93,19 @@ ssk::Tables host_tables() {
 }
 }  // namespace
 
+// a second length bucket for the next hs_conv / hs_obs_rows call (cleared by it): entries >= first live in `rir` [n,2,cap]
+static const float* g_b2_rir = nullptr;
+static int g_b2_first = 0, g_b2_cap = 0;
+static void apply_bucket2(ssk::ConvParams& p) {
+    p.n_buckets = 1;
+    for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
+    if (g_b2_rir) {
+        p.n_buckets = 2;
+        p.bk[0] = ssk::BankBucket{g_b2_rir, nullptr, g_b2_first, g_b2_cap, (g_b2_cap + ssk::kB - 1) / ssk::kB, 0};
+    }
+    g_b2_rir = nullptr;
+}
+
 void hostsim_syncthreads() { barrier_wait(g_block_barrier, g_nthreads); }
 void hostsim_wave_sync() { barrier_wait(g_wave_barrier[g_cur / 64], 64); }
 static float g_xch[16][64];
@@ -106,6 +119,8 @@ float hostsim_lane_read(float v, int src_lane) {
 }
 
 extern "C" {
+
+void hs_set_bucket2(const float* rir, int first, int cap) { g_b2_rir = rir; g_b2_first = first; g_b2_cap = cap; }
 
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
@@ -132,6 +147,7 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
     p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
+    apply_bucket2(p);
     p.fade_len = static_cast<int>(0.05 * out_len);
     const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
     if (xfade) simple = 0;
@@ -204,6 +220,7 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     p.fade_len = 0;
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
     p.h_blocks = h_blocks; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
+    apply_bucket2(p);
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
@@ -249,11 +266,13 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec); p.h_blocks = h_blocks; p.xcd_map = wgs >= 8;
     p.nb_y = n_valid == 0 ? 0 : (n_valid + ssk::kB - 1) / ssk::kB;
     p.n_terms = no_distractor ? 1 : 2;
+    apply_bucket2(p);
     const int n_rows = 2 * n_units, grid = wgs < n_rows ? wgs : n_rows;
     std::vector<float> stash;
     p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
     if (!hspec && p.nb_y > 1 && use_stash) {
         p.stash_nbh = (cap + ssk::kB - 1) / ssk::kB;
+        if (p.n_buckets > 1 && p.bk[0].h_blocks > p.stash_nbh) p.stash_nbh = p.bk[0].h_blocks;
         p.stash_terms = p.n_terms;
         stash.assign(static_cast<size_t>(grid) * p.stash_terms * p.stash_nbh * 2 * ssk::kSpecComplex, 12345.0f);
         p.stash = reinterpret_cast<ssk::f32x4*>(stash.data());

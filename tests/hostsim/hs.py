@@ -33,7 +33,8 @@ def _p(a, t):
 
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
-        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False):
+        interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False,
+        bucket2=None):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -42,6 +43,10 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     rir_bank = np.ascontiguousarray(rir_bank, dtype=np.float32)
     R, _, cap = rir_bank.shape
     nbh_max = max(1, P.ceil_div(cap, P.KB))
+    if bucket2 is not None:                              # length-bucketed bank: bank indices >= R live in a second allocation
+        bucket2 = np.ascontiguousarray(bucket2, dtype=np.float32)          # [R2, 2, cap2]; rir_len covers both buckets
+        assert not spectral and not interleaved and len(rir_len) == R + bucket2.shape[0]
+        nbh_max = max(nbh_max, P.ceil_div(bucket2.shape[2], P.KB))
     nby = max(1, P.ceil_div(n_valid, P.KB))
     offs = np.cumsum([0] + [len(s) for s in sources])
     flat = np.concatenate([np.asarray(s, np.float32) for s in sources]).astype(np.float32)
@@ -86,6 +91,10 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         bank, us, cs, es = rir_bank, 2 * cap, cap, 1
     no_dis = not any(u.get("dis_rir", -1) >= 0 for u in units)
     simple = int(simple and no_dis and cap <= P.KB and nby == 1)
+    if bucket2 is not None:
+        in_b0 = all(max(u.get("rir", -1), u.get("dis_rir", -1), u.get("last_rir", -1)) < R for u in units)
+        simple = int(simple and in_b0)                   # SS_FLAG_FIRST_BUCKET: the loop-free kernel only sees bucket 0
+        L.hs_set_bucket2(_p(bucket2, ctypes.c_float), R, int(bucket2.shape[2]))
     if crossfade:
         simple = 2
     if row_wgs:                                          # k_obs_rows: fused rows of 2-3 blocks, `row_wgs` persistent workgroups

@@ -912,3 +912,111 @@ def test_fused_rows_short_steps_and_context_api_without_waveform():
     _, sg_r = r2.render(r2.plan([UnitRequest(n % 2, 0, n % 4) for n in range(9)]))
     torch.cuda.synchronize()
     assert float((sg_c - sg_r).abs().max()) <= 2e-6 * float(sg_r.abs().max())
+
+
+# ---- length-bucketed RIR bank ------------------------------------------------------------------------------
+def test_bucketed_store_mixes_short_and_3s_rirs_without_reallocating_the_bank():
+    """0.4-s and 3-s RIRs in ONE store, multi-second clips (the steady branch hears the whole 3-s tail: negative partition
+    offsets), through AudioEngine(rir_buckets=...): every unit against the oracle; the short bucket is never reallocated
+    or lengthened (`RirStore._ensure_cap` copied the whole bank at the new capacity mid-episode); a step whose
+    units all sit in the short bucket still runs the loop-free kernel (same bits as a plain short bank); the golden
+    multi_L1.5_* cases (1.5-s RIR, 5-s clip) through the bucketed store."""
+    from ss_amd.renderer import AudioEngine, UnitRequest
+    rng = np.random.default_rng(77)
+    sr = 16000
+    eng = AudioEngine(sr, device=DEV, rir_buckets=[(64, sr), (8, 2 * P.KB), (8, 4 * P.KB)])
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in (1, 5, 3)]
+    sid = [eng.source_id(f"s{i}", s_) for i, s_ in enumerate(src)]              # a multi-second clip: whole RIRs from now on
+    lens = [int(0.4 * sr)] * 10 + [3 * sr] * 4 + [int(1.5 * sr)] * 3
+    rirs = [np.ascontiguousarray((O.synth_rir(rng, sr, length=L, n=1)[0] *
+                                  np.exp(-np.arange(L) / (0.5 * sr))[None, :]).astype(np.float32).T) for L in lens]
+    short_ptr = eng.store.stores[0].bank.data.data_ptr()
+    for rep in range(2):
+        eng.begin_batch()
+        units, refs = [], []
+        for n in range(40):
+            s_, h_ = int(rng.integers(0, 3)), int(rng.integers(0, len(rirs)))
+            idx = int(rng.integers(0, len(src[s_]) // sr))
+            slot = eng.rir_slot(("rir", h_), lambda h_=h_: rirs[h_])
+            assert eng.rir_len(slot) == lens[h_] and eng.store.bank.bucket_of(slot) == (0 if lens[h_] <= sr else 2 if lens[h_] > 2 * P.KB else 1)
+            units.append(UnitRequest(sid[s_], P.window_start_sim(len(src[s_]), sr, idx), slot))
+            refs.append(O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx).astype(np.float32))
+        out = eng.observe(units, want_audiogoal=True)
+        ag, sg = out["audiogoal"].cpu().numpy(), out["spectrogram"].cpu().numpy()
+        for n in range(40):
+            check(ag[n], refs[n])
+            check(sg[n], O.compute_spectrogram(refs[n]))
+    assert eng.store.grown == 0 and eng.store.stores[0].bank.data.data_ptr() == short_ptr and eng.store.stores[0].cap == sr
+    # short-bucket-only step == the same step on a plain short bank, bit for bit (loop-free kernel, SS_FLAG_FIRST_BUCKET)
+    eng.begin_batch()
+    u0 = [UnitRequest(sid[0], 0, eng.rir_slot(("rir", h_), lambda h_=h_: rirs[h_])) for h_ in range(10)]
+    plan = eng.renderer.plan(u0)
+    from ss_amd import ops
+    assert plan.flags == ops.FLAG_NO_DISTRACTOR | ops.FLAG_FIRST_BUCKET
+    sg_b = eng.renderer.render(plan)[1]
+    r1 = make_renderer(sr, [src[0]], rirs[:10])
+    sg_p = r1.render(r1.plan([UnitRequest(0, 0, h_) for h_ in range(10)]))[1]
+    assert torch.equal(sg_b, sg_p)
+    # the reference-run vectors with a 1.5-s RIR and a 5-s clip, RIR in the middle bucket
+    for name in [c for c in golden()[1] if c.startswith("multi_L1.5")]:
+        d = case_inputs(name)
+        ref_a, ref_s, stride = case_outputs(name)
+        e2 = AudioEngine(sr, device=DEV, rir_buckets=[(8, sr), (4, 2 * P.KB)])
+        s0 = e2.source_id("clip", d["source"])
+        slot = e2.rir_slot("r", lambda: d["rir"])
+        assert e2.store.bank.bucket_of(slot) == 1
+        o = e2.observe([UnitRequest(s0, P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0)), slot)], want_audiogoal=True)
+        check(o["audiogoal"][0].cpu().numpy()[:, ::stride], ref_a)
+        check(o["spectrogram"][0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.parametrize("sr,spectral", [(16000, False), (16000, True), (44100, False)])
+def test_bucketed_bank_through_renderer_and_context(sr, spectral):
+    """BucketedRirBank.from_arrays + renderer.plan/render and ss_ctx_set_rir_buckets + ss_ctx_observe against ONE bank at
+    the long capacity: same units (distractor from the other bucket, silent units), spectral buckets, 44.1 kHz fused rows."""
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import BatchedAudioRenderer, BucketedRirBank, RirBank, UnitRequest
+    rng = np.random.default_rng(sr + spectral)
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in (1, 1, 4)]
+    lens = [int(0.3 * sr), int(0.45 * sr), 2 * sr + 77, int(0.2 * sr), int(1.3 * sr), 3 * sr]
+    rirs = [np.ascontiguousarray((O.synth_rir(rng, sr, length=L, n=1)[0] *
+                                  np.exp(-np.arange(L) / (0.6 * sr))[None, :]).astype(np.float32).T) for L in lens]
+    bank = BucketedRirBank.from_arrays(rirs, DEV, caps=[int(0.5 * sr), 3 * sr])
+    one = RirBank.from_arrays(rirs, DEV)
+    if spectral:
+        bank.build_spectra()
+        one.build_spectra()
+    rb, r1 = BatchedAudioRenderer(sr, device=DEV), BatchedAudioRenderer(sr, device=DEV)
+    ctx = AudioContext(sr)
+    for i, s_ in enumerate(src):
+        rb.add_source(f"s{i}", s_); r1.add_source(f"s{i}", s_); ctx.add_source(f"s{i}", s_)
+    rb.set_rir_bank(bank)
+    r1.set_rir_bank(one)
+    ctx.set_rir_buckets(bank, spectral=spectral)
+    cols = dict(sound=[], t0=[], rir=[], dis_sound=[], dis_rir=[])
+    ub, u1 = [], []
+    for n in range(24):
+        s_, h_ = int(rng.integers(0, 3)), int(rng.integers(0, 6))
+        t0 = P.window_start_sim(len(src[s_]), sr, int(rng.integers(0, len(src[s_]) // sr)))
+        dis = int(rng.integers(0, 6)) if n % 3 == 0 else -1
+        silent = n % 11 == 5
+        ub.append(UnitRequest(s_, t0, bank.index_of[h_], silent=silent, dis_sound=0 if dis >= 0 else -1,
+                              dis_rir=bank.index_of[dis] if dis >= 0 else -1))
+        u1.append(UnitRequest(s_, t0, h_, silent=silent, dis_sound=0 if dis >= 0 else -1, dis_rir=dis))
+        cols["sound"].append(s_); cols["t0"].append(t0); cols["rir"].append(-1 if silent else bank.index_of[h_])
+        cols["dis_sound"].append(0); cols["dis_rir"].append(bank.index_of[dis] if dis >= 0 else -1)
+    ag_b, sg_b = rb.render(rb.plan(ub), want_audiogoal=True)
+    ag_1, sg_1 = r1.render(r1.plan(u1), want_audiogoal=True)
+    tol = 2e-6
+    assert float((ag_b - ag_1).abs().max()) <= tol * float(ag_1.abs().max())
+    assert float((sg_b - sg_1).abs().max()) <= tol * float(sg_1.abs().max())
+    t4 = P.spectrogram_shape(sr)[1]
+    sg_c, ag_c = torch.empty((24, 65, t4, 2), device=DEV), torch.empty((24, 2, sr), device=DEV)
+    ctx.observe(spectrogram_out=sg_c, audiogoal_out=ag_c, **cols)
+    torch.cuda.synchronize()
+    assert float((ag_c - ag_1).abs().max()) <= tol * float(ag_1.abs().max())
+    assert float((sg_c - sg_1).abs().max()) <= tol * float(sg_1.abs().max())
+    n0 = 2                                                                        # and one unit against the oracle
+    u = u1[n0]
+    ref = O.compute_audiogoal(src[u.sound], rirs[u.rir], sr, audio_index=u.t0 // sr if len(src[u.sound]) != sr else 0)
+    check(ag_b[n0].cpu().numpy(), ref.astype(np.float32))

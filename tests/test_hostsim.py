@@ -436,3 +436,45 @@ def test_fused_rows_lengths_pads_and_short_steps(out_len, n_valid, pad):
     assert np.abs(sg - s_ref).max() <= 1e-6 * max(1e-30, np.abs(s_ref).max())
     assert not a[0, :, n_valid:].any()
     check(sg[0], O.compute_spectrogram(a_ref[0], pad_mode="constant" if pad else "reflect"))
+
+
+# ---- length-bucketed RIR bank -----------------------------------------------------------------------------
+@pytest.mark.parametrize("sr,fused_rows", [(16000, False), (44100, True)])
+def test_bucketed_bank_short_and_long_rirs_in_one_launch(sr, fused_rows):
+    """Bank entries 0..2 in a short bucket (rows of <= 1 block), entries 3..4 in a long bucket of its own (3-s RIRs: 3 / 9
+    blocks); one launch mixes them (multi-second clips, a distractor from the other bucket, a silent unit).  Against the
+    same units rendered from ONE bank at the long capacity, and the oracle."""
+    rng = np.random.default_rng(sr)
+    srcs = [O.synth_sources(rng, sr, k=1, seconds=s)[0] for s in (1, 4)]
+    short_len, long_len = [int(0.4 * sr), int(0.25 * sr), 7000], [3 * sr, int(2.2 * sr)]
+    cap_s, cap_l = max(short_len) + (max(short_len) & 1), 3 * sr
+    b0 = np.zeros((3, 2, cap_s), np.float32)
+    b1 = np.zeros((2, 2, cap_l), np.float32)
+    for i, L in enumerate(short_len):
+        b0[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
+    for i, L in enumerate(long_len):
+        b1[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0] * np.exp(-np.arange(L) / (0.8 * sr))[None, :].astype(np.float32)
+    lens = short_len + long_len
+    one = np.zeros((5, 2, cap_l), np.float32)
+    one[:3, :, :cap_s] = b0
+    one[3:] = b1
+    units = [dict(sound=0, t0=0, rir=0),
+             dict(sound=1, t0=P.window_start_sim(4 * sr, sr, 3), rir=3),          # steady branch through a 3-s RIR
+             dict(rir=-1),
+             dict(sound=1, t0=P.window_start_sim(4 * sr, sr, 1), rir=4, dis_sound=0, dis_t0=0, dis_rir=1),
+             dict(sound=0, t0=0, rir=2, dis_sound=0, dis_t0=0, dis_rir=4)]
+    kw = dict(row_wgs=3) if fused_rows else dict(fuse=True, simple=False)
+    a_ref, s_ref = hs.run(srcs, one, lens, units, sr, sr, **kw)
+    a, sg = hs.run(srcs, b0, lens, units, sr, sr, bucket2=b1, **kw)
+    np.testing.assert_array_equal(a, a_ref)
+    np.testing.assert_array_equal(sg, s_ref)
+    check(a[1], O.compute_audiogoal(srcs[1], np.ascontiguousarray(b1[0].T), sr, audio_index=3))
+    check(a[4], O.compute_audiogoal(srcs[0], np.ascontiguousarray(b0[2, :, :7000].T), sr, distractor=srcs[0],
+                                    distractor_rir=np.ascontiguousarray(b1[1, :, :long_len[1]].T)))
+    assert not a[2].any() and not sg[2].any()
+    if not fused_rows:                                   # a launch that stays in bucket 0 keeps the loop-free kernel
+        u0 = [dict(sound=0, t0=0, rir=i) for i in range(3)]
+        a0, s0 = hs.run(srcs, b0, lens, u0, sr, sr, fuse=True, bucket2=b1)
+        a1, s1 = hs.run(srcs, b0, short_len, u0, sr, sr, fuse=True)
+        np.testing.assert_array_equal(a0, a1)
+        np.testing.assert_array_equal(s0, s1)

@@ -315,3 +315,48 @@ def test_rir_store_slot_many_matches_one_by_one():
     for k, sl in small._slot_of.items():
         n = min(len(rirs[k]), 100)
         np.testing.assert_array_equal(small.bank.data[sl, :, :n].numpy(), rirs[k][:n].T)
+
+
+def test_bucketed_rir_store_routes_by_length_and_never_reallocates_the_short_bucket():
+    """SURVEY 8(f)2 / VERDICT r2: one capacity for every row meant that ONE long RIR reallocated and copied the whole bank
+    (RirStore._ensure_cap) and lengthened every slot.  BucketedRirStore keeps a sub-store per length class: keys live in
+    the smallest bucket that holds them, each bucket has its own LRU, only the last one can grow (its own rows only)."""
+    from ss_amd.renderer import BucketedRirStore
+    grown = []
+    st = BucketedRirStore(slots=[4, 2, 2], caps=[100, 300, 500], device="cpu", max_cap=1000, on_grow=grown.append)
+    assert st.first == [0, 4, 6] and st.slots == 8
+    mk = lambda n, v=1.0: np.full((n, 2), v, np.float32)
+    s_short = [st.slot(("short", i), lambda i=i: mk(40 + i, i + 1)) for i in range(4)]
+    s_mid = st.slot("mid", lambda: mk(250, 7.0))
+    s_long = st.slot("long", lambda: mk(480, 9.0))
+    assert sorted(s_short) == [0, 1, 2, 3] and s_mid in (4, 5) and s_long in (6, 7)
+    data0 = st.stores[0].bank.data.data_ptr()
+    assert st.stores[0].grown == 0 and st.stores[0].cap == 100                  # the short bucket is untouched
+    assert [int(st.host_len[s]) for s in s_short] == [40, 41, 42, 43] and int(st.host_len[s_mid]) == 250
+    assert st.bank.lengths.tolist()[s_long] == 480 and st.bank.bucket_of(s_long) == 2 and st.bank.bucket_of(3) == 0
+    assert float(st.bank.banks[1].data[s_mid - 4, 0, 249]) == 7.0 and float(st.bank.banks[1].data[s_mid - 4, 0, 250]) == 0.0
+    # hits do not call the loader; each bucket evicts on its own (the 5th short key evicts the LRU short key only)
+    assert st.slot(("short", 1), lambda: 1 / 0) == s_short[1]
+    s5 = st.slot(("short", 9), lambda: mk(10))
+    assert s5 == s_short[0] and st.slot("mid", lambda: 1 / 0) == s_mid and st.slot("long", lambda: 1 / 0) == s_long
+    # a RIR beyond every capacity grows the LAST bucket alone
+    s_huge = st.slot("huge", lambda: mk(900, 3.0))
+    assert st.bank.bucket_of(s_huge) == 2 and st.stores[2].cap >= 900 and st.stores[2].grown == 1 and len(grown) == 1
+    assert st.stores[0].grown == 0 and st.stores[0].bank.data.data_ptr() == data0 and st.stores[1].grown == 0
+    assert st.grown == 1 and isinstance(grown[0], type(st.bank)) and grown[0].banks[2].cap == st.stores[2].cap
+    # a live key (refresh=True) whose RIR changes length class moves to the other bucket and frees its old slot
+    a = st.slot(("live", 0), lambda: mk(50, 5.0), refresh=True)
+    b = st.slot(("live", 0), lambda: mk(280, 6.0), refresh=True)
+    assert st.bank.bucket_of(a) == 0 and st.bank.bucket_of(b) == 1 and ("live", 0) not in st.stores[0]._slot_of
+    assert int(st.host_len[b]) == 280 and float(st.bank.banks[1].data[b - 4, 1, 279]) == 6.0
+    # bulk load: one call, keys spread over the buckets, duplicates load once
+    st2 = BucketedRirStore(slots=[4, 4], caps=[100, 400], device="cpu")
+    calls = []
+    def loader(n):
+        return lambda: (calls.append(n), mk(n, float(n)))[1]
+    keys = ["a", "b", "c", "a", "d"]
+    got = st2.slot_many(keys, [loader(n) for n in (30, 350, 99, 30, 120)], workers=2)
+    assert got[0] == got[3] and sorted(calls) == [30, 99, 120, 350]
+    assert [st2.bank.bucket_of(g) for g in got] == [0, 1, 0, 0, 1]
+    assert [int(st2.host_len[g]) for g in got] == [30, 350, 99, 30, 120]
+    assert st2.slot_many(["b", "d"], [loader(1), loader(2)]) == [got[1], got[4]] and len(calls) == 4
