@@ -326,10 +326,11 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --envs per GPU (default); strong: --envs in total, split over the ranks (BASELINE configs[3]: "
                          "128 envs = 16 per GPU on 8 GPUs)")
-    ap.add_argument("--exchange", choices=["allgather", "peercopy", "none"], default="allgather",
+    ap.add_argument("--exchange", choices=["allgather", "peercopy", "gather", "none"], default="allgather",
                     help="allgather: RCCL all_gather_into_tensor on a side stream; peercopy: every rank copies its slab into the "
                          "peers' buffers over xGMI (HIP IPC mappings, SDMA / blit path: no CUs taken from the kernels), RCCL "
-                         "only for the 4-byte completion barrier; none: no exchange (DD-PPO: each rank consumes its own slab)")
+                         "only for the 4-byte release / completion barriers; gather: peer copies into the LEARNER rank (0) only "
+                         "(1/world of the fabric traffic); none: no exchange (DD-PPO: each rank consumes its own slab)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="steps per all-gather: the learner consumes rollouts, so per-rank slabs are exchanged in chunks of "
                          "this many steps (fewer, larger collectives suit the point-to-point xGMI fabric); the per-step "
@@ -500,8 +501,9 @@ def main():
             ctx.set_overlap(lanes)
         cx = None
         if world > 1 and gather_every > 0:
+            kw = {"learners": [0]} if args.exchange == "gather" else {}
             cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev,
-                                     exchange_cls=PeerCopyExchange if args.exchange == "peercopy" else None)
+                                     exchange_cls=PeerCopyExchange if args.exchange in ("peercopy", "gather") else None, **kw)
         ex = cx.exchange if cx is not None else None
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
         sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S, lanes))]

@@ -43,9 +43,19 @@ class AudioContext:
         _lib.check(self.lib.ss_ctx_create(ctypes.byref(h), self.sr, self.n_valid, _PAD[pad_mode], int(self.wrap),
                                           int(max_window_sets)), "ss_ctx_create")
         self._h = h
+        self.handle = AudioContext._next_handle          # torch.ops.ss_hip.ctx_observe(handle, ...) finds the context by it
+        AudioContext._next_handle += 1
+        AudioContext._by_handle[self.handle] = self
         self._names: Dict[str, int] = {}
         self.lengths = []
         self._bank = None                    # keeps the borrowed tensors alive
+
+    _next_handle = 1
+    _by_handle = __import__("weakref").WeakValueDictionary()
+
+    @staticmethod
+    def from_handle(handle: int) -> "AudioContext":
+        return AudioContext._by_handle[int(handle)]
 
     def close(self):
         if getattr(self, "_h", None):

@@ -106,10 +106,11 @@ class ChunkedSlabExchange:
     right after a gather was ISSUED (consume it on a stream after `exchange.wait()`)."""
 
     def __init__(self, units: int, row_shape, gather_every: int, dtype=torch.float32, device="cuda",
-                 group: Optional[dist.ProcessGroup] = None, exchange_cls=None, gathered=None):
+                 group: Optional[dist.ProcessGroup] = None, exchange_cls=None, gathered=None, **exchange_kwargs):
         self.units, self.G = int(units), max(1, int(gather_every))
         cls = exchange_cls or SlabExchange
-        self.exchange = cls((self.G * self.units,) + tuple(row_shape), dtype=dtype, device=device, group=group)
+        self.exchange = cls((self.G * self.units,) + tuple(row_shape), dtype=dtype, device=device, group=group,
+                            **exchange_kwargs)
         self._buf = None
         self._n = 0
         self.gathered = gathered
@@ -147,24 +148,39 @@ class ChunkedSlabExchange:
 class PeerCopyExchange(SlabExchange):
     """Same interface as ``SlabExchange``, different transport: every rank WRITES its slab straight into the other
     ranks' gathered buffers with device-to-device copies over xGMI (peer memory mapped through HIP IPC), and only the
-    completion barrier is a collective.
+    synchronisation is a collective.
 
     Why: RCCL's all-gather runs as kernels that need CUs with ~20 KB of LDS and ~270 registers per thread; they can
     never share a CU with a ``k_conv`` workgroup (148 KB of LDS, all of the register file), so while a gather is in
     flight a 256-row launch finds fewer than 256 free CUs.  Peer copies are executed by the
     SDMA engines / blit path: no CUs, no LDS.  The slabs are small (1.7 MB per rank and step at 128 envs), every GPU
-    has a direct xGMI link to every other one, so each rank issues world-1 independent copies, one per link.
+    has a direct xGMI link to every other one, so each rank issues one independent copy per destination, one per link.
+
+    ``learners`` (default: every rank = all-gather) restricts the DESTINATIONS: with ``learners=[0]`` the slabs are
+    gathered to rank 0 only (the shape of ``dist.gather``): 1/world of the fabric traffic, and only the learner ingests
+    (world-1) slabs per gather.  Non-learner ranks get ``None`` back from ``gather()``.
+
+    Consumer-release protocol (peers used to write into ``full[i]`` with nothing telling them the local
+    consumer had finished with it).  Buffer i is rewritten by gather k + depth.  Before its copies, that gather
+        1. waits for the LOCAL release of buffer i - an event recorded by ``release()``, or implicitly by the
+           ``next_local()`` call of this round on the compute streams (contract: the tensor returned by gather k may be
+           read by work enqueued on the compute streams BEFORE next_local() of round k + depth is called), then
+        2. runs a 4-byte all-reduce on the side stream (the RELEASE barrier): once it completes on a rank, every rank has
+           passed step 1, i.e. nobody is still reading its buffer i - only then are the peer copies issued, followed by
+        3. the COMPLETION barrier (second 4-byte all-reduce): every rank's copies into every buffer i have landed.
+    With the ``gloo`` control plane of the single-GPU test both barriers are stream-sync + host barrier.
 
     Set-up (once): each rank exports the IPC handle of its ``full`` buffers (``torch`` shares CUDA/HIP storages with
     ``_share_cuda_``; the dmabuf IPC mode needs ``HSA_ENABLE_IPC_MODE_LEGACY=0``, already exported on these boxes) through
-    ``all_gather_object`` on the process group, and opens its peers'.  Per gather: wait for the producer streams, copy
-    the local slab into slot ``rank`` of EVERY rank's buffer on the side stream, then a 4-byte all-reduce on that stream
-    as the completion barrier (with the ``gloo`` control plane used in the single-GPU test: stream sync + host barrier)."""
+    ``all_gather_object`` on the process group, and opens its peers'."""
 
     def __init__(self, slab_shape, dtype=torch.float32, device="cuda", group: Optional[dist.ProcessGroup] = None,
-                 depth: int = 2):
+                 depth: int = 2, learners=None):
         super().__init__(slab_shape, dtype=dtype, device=device, group=group, depth=depth)
         assert self._cuda, "peer copies need device memory"
+        self.learners = sorted(set(range(self.world) if learners is None else learners))
+        assert self.learners and all(0 <= r < self.world for r in self.learners)
+        self.is_learner = self.rank in self.learners
         self._peers = [[None] * self.world for _ in range(depth)]     # [buffer][rank] -> that rank's `full` tensor
         if self.world > 1:
             from torch.multiprocessing.reductions import rebuild_cuda_tensor, reduce_tensor
@@ -173,7 +189,7 @@ class PeerCopyExchange(SlabExchange):
                 assert fn is rebuild_cuda_tensor
                 handles = [None] * self.world
                 dist.all_gather_object(handles, args, group=self.group)
-                for r in range(self.world):
+                for r in self.learners:
                     if r == self.rank:
                         self._peers[i][r] = self.full[i]
                     else:
@@ -185,9 +201,45 @@ class PeerCopyExchange(SlabExchange):
                 self._peers[i][0] = self.full[i]
         self._flag = torch.zeros((1,), dtype=torch.float32, device=self.device)
         self._device_barrier = self.world > 1 and dist.get_backend(self.group) == "nccl"
+        self._released = [None] * depth                               # event: the local consumer is done with full[i]
 
-    def gather(self, streams=None) -> torch.Tensor:
+    def _barrier(self) -> None:
+        """on the side stream (current): every rank has reached this point of ITS side stream"""
+        if self.world <= 1:
+            return
+        if self._device_barrier:
+            dist.all_reduce(self._flag, group=self.group)
+        else:
+            self.stream.synchronize()
+            dist.barrier(group=self.group)
+
+    def release(self, streams=None) -> None:
+        """The local consumer has enqueued its last read of the most recently gathered buffer on `streams` (default: the
+        current stream): peers may overwrite it once every rank has said so (see the class docstring)."""
+        if self._k == 0:
+            return
+        i = (self._k - 1) % self.depth
+        evs = []
+        for st in self._producers(streams):
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        self._released[i] = evs
+
+    def next_local(self, streams=None) -> torch.Tensor:
         i = self._k % self.depth
+        if self._k >= self.depth and self._released[i] is None:       # implicit release of full[i] (see the contract)
+            evs = []
+            for st in self._producers(streams):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
+            self._released[i] = evs
+        return super().next_local(streams)
+
+    def gather(self, streams=None):
+        i = self._k % self.depth
+        first_use = self._k < self.depth
         self._k += 1
         n = self.slab_shape[0]
         for st in self._producers(streams):
@@ -195,13 +247,13 @@ class PeerCopyExchange(SlabExchange):
             ev.record(st)
             self.stream.wait_event(ev)
         with torch.cuda.stream(self.stream):
-            for r in range(self.world):                               # one copy per peer link (and the local one)
+            if not first_use:
+                for ev in (self._released[i] or []):                  # 1. the local consumer is done with full[i]
+                    self.stream.wait_event(ev)
+                self._released[i] = None
+                self._barrier()                                       # 2. ... and so is everybody else
+            for r in self.learners:                                   # one copy per destination link (and the local one)
                 self._peers[i][r][self.rank * n:(self.rank + 1) * n].copy_(self.local[i], non_blocking=True)
-            if self.world > 1:
-                if self._device_barrier:
-                    dist.all_reduce(self._flag, group=self.group)     # every rank's copies are ordered before it
-                else:
-                    self.stream.synchronize()
-                    dist.barrier(group=self.group)
+            self._barrier()                                           # 3. every rank's copies have landed
             self.ready[i].record(self.stream)
-        return self.full[i]
+        return self.full[i] if self.is_learner else None

@@ -308,6 +308,43 @@ def _register():
         return ag, sg
     lib.impl("audio_obs", _audio_obs, "CUDA")
 
+    # spectral RIR bank: the bank builder + the two *_spec entry points
+    lib.define("rir_spectra(Tensor rir_bank) -> Tensor")
+    lib.impl("rir_spectra", rir_spectra, "CUDA")
+    lib.impl("rir_spectra", lambda b: b.new_empty((b.shape[0], 2, ceil_div(b.shape[2], KB), SPEC_FLOATS)), "Meta")
+    lib.define("fftconv_binaural_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+               "int flags=0) -> Tensor")
+
+    def _conv_spec(spec, hspec, rir_len, unit_desc, n_valid, out_len, flags=0):
+        out = torch.empty((unit_desc.shape[0], 2, out_len), dtype=torch.float32, device=spec.device)
+        fftconv_binaural_spec_into(spec, hspec, rir_len, unit_desc, out, n_valid, flags)
+        return out
+    lib.impl("fftconv_binaural_spec", _conv_spec, "CUDA")
+    lib.impl("fftconv_binaural_spec", lambda spec, h, l, d, n_valid, out_len, flags=0: spec.new_empty((d.shape[0], 2, out_len)),
+             "Meta")
+    lib.define("audio_obs_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+               "int pad_mode=0, int flags=0) -> (Tensor, Tensor)")
+
+    def _obs_spec(spec, hspec, rir_len, unit_desc, n_valid, out_len, pad_mode=0, flags=0):
+        N = unit_desc.shape[0]
+        ag = torch.empty((N, 2, out_len), dtype=torch.float32, device=spec.device)
+        sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
+        audio_obs_spec_into(spec, hspec, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, flags)
+        return ag, sg
+    lib.impl("audio_obs_spec", _obs_spec, "CUDA")
+    lib.impl("audio_obs_spec", lambda spec, h, l, d, n_valid, out_len, pad_mode=0, flags=0:
+             (spec.new_empty((d.shape[0], 2, out_len)), spec.new_empty((d.shape[0],) + spectrogram_shape(out_len))), "Meta")
+    # the observe-level op: one vector step through a context (planner + window cache + descriptor ring in the library).
+    # `ctx` = AudioContext.handle (an integer registered by ss_amd.context); unit columns are int32 CPU tensors; the
+    # spectrogram rows are written in place (rollout rows) and returned.
+    lib.define("ctx_observe(int ctx, Tensor sound, Tensor t0, Tensor rir, Tensor(a!) spectrogram) -> Tensor(a!)")
+
+    def _ctx_observe(ctx, sound, t0, rir, spectrogram):
+        from .context import AudioContext
+        AudioContext.from_handle(ctx).observe(sound.numpy(), t0.numpy(), rir.numpy(), spectrogram_out=spectrogram)
+        return spectrogram
+    lib.impl("ctx_observe", _ctx_observe, "CompositeExplicitAutograd")
+
     # shape functions (Meta) so the ops compose with tracing / fake tensors
     lib.impl("source_windows", lambda src, wd: src.new_empty((wd.shape[0], SPEC_FLOATS)), "Meta")
     lib.impl("fftconv_binaural", lambda spec, b, l, d, n_valid, out_len, interleaved=False, flags=0:

@@ -146,7 +146,6 @@ def _peer_worker(rank, world, port, q):
                     blk = full[r * 12:(r + 1) * 12]
                     for i in range(n_steps):
                         ok &= bool((blk[i * 4:(i + 1) * 4] == 1000 * r + (k - n_steps + 1) + i).all())
-                dist.barrier()                    # nobody refills a buffer a peer is still checking
         cx.flush()
         torch.cuda.synchronize()
         full, n_steps = seen.pop()
@@ -156,6 +155,55 @@ def _peer_worker(rank, world, port, q):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _release_worker(rank, world, port, q, learners):
+    """No test-side barrier: rank 1's consumer is SLOW (a long busy kernel in front of every check on its compute stream),
+    rank 0 races ahead; the checks are device-side accumulations, nothing syncs the host until the end.  Without the
+    consumer-release protocol rank 0's copies of round k + 2 land in rank 1's buffer before rank 1 has checked round k."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ss_amd.dist import PeerCopyExchange
+        n = 8
+        ex = PeerCopyExchange((n, 65, 26, 2), device="cuda:0", learners=learners)
+        bad = torch.zeros((), dtype=torch.int32, device="cuda:0")
+        rounds = 24
+        for k in range(rounds):
+            loc = ex.next_local()
+            loc.fill_(float(100 * k + rank))
+            full = ex.gather()
+            ex.wait()
+            if full is not None:
+                if rank == 1:
+                    torch.cuda._sleep(20_000_000)                                 # ~10 ms: the slow consumer
+                for r in range(world):
+                    bad += (full[r * n:(r + 1) * n] != 100 * k + r).any().to(torch.int32)
+            assert (full is None) == (learners is not None and rank not in learners)
+        torch.cuda.synchronize()
+        q.put((rank, int(bad.item())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("learners", [None, [1]])
+def test_peer_copy_consumer_release_without_a_test_side_barrier(learners):
+    """the all-gather the reference never had must at least be safe to consume.  all-gather (every rank a
+    destination) and gather-to-learner (rank 1, the slow one, is the only destination)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_release_worker, args=(r, 2, port, q, learners)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, 0), (1, 0)]
 
 
 @pytest.mark.gpu

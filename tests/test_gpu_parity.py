@@ -1020,3 +1020,33 @@ def test_bucketed_bank_through_renderer_and_context(sr, spectral):
     u = u1[n0]
     ref = O.compute_audiogoal(src[u.sound], rirs[u.rir], sr, audio_index=u.t0 // sr if len(src[u.sound]) != sr else 0)
     check(ag_b[n0].cpu().numpy(), ref.astype(np.float32))
+
+
+def test_torch_ops_spectral_variants_and_observe_level_op():
+    """torch.ops.ss_hip.{rir_spectra, fftconv_binaural_spec, audio_obs_spec, ctx_observe} (the spectral variants
+    and an observe-level op were not registered): same results as the tensor-level entry points / the renderer."""
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(123)
+    sr = 16000
+    src = O.synth_sources(rng, sr, k=2)
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=5)]
+    r = make_renderer(sr, list(src), rirs)
+    units = [UnitRequest(n % 2, 0, n % 5) for n in range(7)]
+    plan = r.plan(units)
+    ag, sg = r.render(plan, want_audiogoal=True)
+    hs = torch.ops.ss_hip.rir_spectra(r.rirs.data)
+    a2 = torch.ops.ss_hip.fftconv_binaural_spec(r._spec, hs, r.rirs.lengths, plan.desc, sr, sr, plan.flags)
+    a3, s3 = torch.ops.ss_hip.audio_obs_spec(r._spec, hs, r.rirs.lengths, plan.desc, sr, sr, 0, plan.flags)
+    scale = float(ag.abs().max())
+    assert float((a2 - ag).abs().max()) <= 2e-6 * scale and float((a3 - ag).abs().max()) <= 2e-6 * scale
+    assert float((s3 - sg).abs().max()) <= 2e-6 * float(sg.abs().max())
+    ctx = AudioContext(sr)
+    for i, s_ in enumerate(src):
+        ctx.add_source(f"s{i}", s_)
+    ctx.set_rir_bank(r.rirs.data, r.rirs.lengths)
+    out = torch.empty_like(sg)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32)
+    got = torch.ops.ss_hip.ctx_observe(ctx.handle, i32([u.sound for u in units]), i32([0] * 7), i32([u.rir for u in units]), out)
+    torch.cuda.synchronize()
+    assert got.data_ptr() == out.data_ptr() and torch.equal(out, sg)

@@ -217,3 +217,41 @@ def test_native_state_to_units_equals_numpy_columns(has_distractor):
             assert np.array_equal(got["dis_sound"][~silent], ref["dis_sound"][~silent])
         assert np.array_equal(a.audio_index, b.audio_index)
     assert seen_miss
+
+
+def test_column_mode_renders_every_step_where_the_reference_pose_cache_freezes_the_window():
+    """The documented difference (deferred.py / vector.py docstrings): the reference memoises observations
+    per (source, receiver, azimuth) and the key ignores `_audio_index` (simulator.py:683-686), so with a multi-second sound
+    an agent standing still gets the window FIRST seen at that pose again and `_audio_index` does not advance on the hit.
+    Eager mode reproduces that; the column observer (like deferred mode) renders the cache-miss path every step: the
+    current window, `_audio_index` advanced once per step.  The first step agrees; the second pins the difference."""
+    n = 1
+    sims, sounds, files, store, index = world(n, seconds=(3,))
+    twin = FakeSim(SR, sounds, files)
+    twin.binaural_rir_dir = sims[0].binaural_rir_dir
+    eng = OracleEngine(SR)
+    eager = sim_audio.HipSimAudio(twin, eng, rir_reader=twin.reader)
+    bank = lambda slot: store.bank.data[slot, :, :int(store.host_len[slot])].numpy().T
+    ctx = OracleContext(SR, bank)
+    state = VectorSimState(n)
+    state.scene[:] = index.scene_id("apartment_0")
+    state.bind(sims[0], 0)
+    obs = FastVectorAudioObserver(ctx, state, index, SR)
+    for s in (sims[0], twin):
+        s._receiver_position_index, s._source_position_index, s._rotation_angle = 1, 2, 90
+    sg = torch.zeros((n, 65, 26, 2))
+    # step 1: same observation, both advance to window 1
+    obs.observe(spectrogram_out=sg)
+    e1 = eager.get_current_spectrogram_observation()
+    assert torch.allclose(sg[0], torch.from_numpy(e1), atol=1e-6) and sims[0]._audio_index == twin._audio_index == 1
+    # step 2, agent did not move: the reference (eager) returns the cached object and leaves the index alone ...
+    e2 = eager.get_current_spectrogram_observation()
+    assert e2 is e1 and twin._audio_index == 1
+    # ... column mode renders window 1 of the clip and advances
+    first = sg.clone()
+    obs.observe(spectrogram_out=sg)
+    assert sims[0]._audio_index == 2 and not torch.allclose(sg, first, atol=1e-3)
+    clip = sounds["snd0"]
+    h = files[f"rirs/replica/apartment_0/{(-90) % 360}/1_2.wav"]
+    ref = O.compute_spectrogram(O.compute_audiogoal(clip, h, SR, audio_index=1))
+    assert O.relerr(sg[0].numpy(), ref) < 1e-5
