@@ -35,7 +35,11 @@
 // dependent round trip at their first use (the asm blocks of the descriptor loads are barriers for its scheduler)
 // (input-only operand: an in/out one would make the pointer's address space unknown to the compiler, i.e. FLAT loads)
 #define SSK_HAVE_S(v) asm volatile("" : : "s"(v))
+// a wave-uniform integer made opaque IN a scalar register: what is derived from it cannot be hoisted out of the enclosing
+// loop (nor be turned into a vector-register copy that then lives - or spills - across the loop body)
+#define SSK_OPAQUE_S(v) asm volatile("" : "+s"(v))
 #else
+#define SSK_OPAQUE_S(v) (void)(v)
 #define SSK_OPAQUE2(v) (void)(v)
 #define SSK_OPAQUE1(v) (void)(v)
 #define SSK_SCHED_BARRIER() (void)0

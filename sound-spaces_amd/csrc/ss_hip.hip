@@ -129,12 +129,9 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
     p.stash_nbh = 0;
     p.stash_terms = 0;
     p.n_terms = (flags & SS_FLAG_NO_DISTRACTOR) ? 1 : 2;
-    // Time-domain bank: a RIR block's spectrum is needed by every later output block of the row.  Default: its forward FFT
-    // is simply re-run there (44.1 kHz: 6 forward FFTs per row instead of 3, no scratch memory at all).  SS_HIP_ROWS_STASH=1
-    // keeps the spectra in a per-stream scratch instead (3 forward FFTs, 640 KiB of L2 / Infinity-Cache traffic per row):
-    // measured equal at 512 units and 5 % SLOWER at 128 units (profiles/r3/NOTES.md), so it stays an A/B switch.
-    static const bool use_stash = getenv("SS_HIP_ROWS_STASH") && atoi(getenv("SS_HIP_ROWS_STASH")) != 0;
-    if (!SPECTRAL && p.nb_y > 1 && use_stash) {
+    // Time-domain bank: the kernel transforms every RIR block once per row and keeps the spectra that are needed again
+    // in a per-workgroup stash (k_obs_rows); 44.1 kHz: 2 x 128 KiB written and 3 x 128 KiB read back per row.
+    if (!SPECTRAL) {
         int nbh_max = (p.rir_cap + ssk::kB - 1) / ssk::kB;
         for (int b = 0; b + 1 < p.n_buckets; ++b) nbh_max = std::max(nbh_max, (p.bk[b].cap + ssk::kB - 1) / ssk::kB);
         p.stash_terms = p.n_terms;                              // no distractor terms: half the stash

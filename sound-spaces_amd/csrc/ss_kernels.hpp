@@ -1633,15 +1633,21 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 // A workgroup owns one CU (the LDS allows one) and walks (unit, ear) rows: row_slot(b) + k * gridDim.x.  Per row it
 // renders the output blocks j = 0 .. nb_rows-1 IN ORDER and streams the STFT behind them:
 //
-//   convolution of block j:  Y_j = sum over (term, RIR block i) of H'_i * S'_{j-i}  (as k_conv / k_conv_spec).
-//     Time-domain bank: the forward FFT of RIR block i is re-run wherever H'_i is needed (44.1 kHz, 1-s clip: 6 per
-//     row).  With a stash (p.stash != nullptr; launcher switch SS_HIP_ROWS_STASH) every block is transformed ONCE: H'_i
-//     is multiplied into Y_j straight from the registers of the forward item stage and, if a later output block needs
-//     it again (H'_0 for j = 1, 2; H'_1 for j = 2), written to the workgroup's private stash in global memory in the
-//     kernels' register order - the on-the-fly equivalent of the spectral bank - and read back with the same coalesced
-//     16-byte loads as the window spectra.  Measured (profiles/r3/NOTES.md): the 3 saved FFTs and the 640 KiB of extra
-//     L2 / Infinity-Cache traffic per row cancel (96.9 vs 91.5 us at 128 units, 359 vs 360 us at 512).
-//     Spectral bank: H'_i comes from the bank, no forward FFT and no stash.
+//   convolution of block j:  Y_j = sum over the PAIRS (term, RIR block i) with a stored window m = j - i of
+//     H'_i * S'_{j-i} (as k_conv / k_conv_spec).  A block spectrum H'_i is either in memory - the spectral bank, or the
+//     workgroup's STASH in global memory, where the time-domain path leaves every spectrum it computes that is needed
+//     again (kernels' register order: the on-the-fly equivalent of the spectral bank, L2 / Infinity-Cache resident) -
+//     or NEW: its forward FFT has not run in this row yet.  Every RIR block is transformed ONCE per row (k_conv re-ran
+//     the forward FFTs per output block: 6 instead of 3 at 44.1 kHz).  A block is then
+//        1. for every new pair but the last: forward FFT -> item stage -> stash            (multi-second clips at j = 0,
+//           distractor terms; never for a 1-s clip, whose block j has exactly one new pair, RIR block j);
+//        2. ONE item stage, item by item and IN PLACE (as in k_conv<SIMPLE>):  v = H'_new from LDS (the last new pair's
+//           forward FFT, if any) -> stash it if a later block needs it -> v *= S'[its window] -> v += sum over the pairs
+//           in memory of H' * S' (two coalesced 16-byte loads per lane and product) -> Hermitian merge + inverse radix-4
+//           -> back into the same LDS slots;
+//        3. inverse passes 3'-2'-1' -> the block's kB samples in registers.
+//     No accumulator exists outside the item stage (the loop kernel carries 32 VGPRs across its forward passes), which is
+//     what lets the first window spectrum of item 0 travel under pass 3.
 //   STFT behind block j:  hann(400) centred in 512 with hop 160: pooled time block b (frames 4b .. 4b+3) needs samples
 //     [640 b - 256, 640 b + 736).  After block j the row is known up to (j+1) kB, so the pooled blocks
 //     b0_j <= b < b1_j = floor((floor(((j+1) kB - 256) / 160) + 1) / 4) are complete (44.1 kHz: 25 + 26 + 18 = 69).
@@ -1653,11 +1659,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 // zeros without any transform) as in k_conv.  SS_FLAG_CROSSFADE is not served here (the launcher keeps the two-kernel
 // path for cross-faded rows longer than one block).
 // timing ablations (scripts/gpu_rows_ladder.sh builds with -DSS_ROWS_ABL=<mask>; results are WRONG, only the time is read):
-//   1 no STFT phase   2 no stash traffic (nothing kept, stashed products skipped)   4 no window-spectrum loads
-//   8 no forward passes (item stage on whatever the LDS holds)   16 no inverse passes
-// and design variants (results CORRECT):  32 no stash at all: every use of a block spectrum re-runs its forward FFT
-//   64 stash RIR block 0 only   128 stash read back with plain (L1/L2-allocating) loads   256 half of the workgroups of an
-//   XCD start ~7 us late (de-synchronises the CUs' memory phases)
+//   1 no STFT phase   2 no products from memory   4 no window-spectrum loads   8 no forward passes 2-3   16 no inverse passes
 #if defined(SS_ROWS_ABL)
 constexpr int kRowsAbl = SS_ROWS_ABL;
 #else
@@ -1666,18 +1668,15 @@ constexpr int kRowsAbl = 0;
 constexpr int kTailFloats = 640;            // context handed from output block j to j+1 (nb_rows <= 3: 640, 384)
 constexpr int kRowsMaxBlocks = 27;          // pooled blocks behind one output block (32768-sample rows: 25 + 27)
 constexpr int kRowsResFloats = kBins4 * kRowsMaxBlocks;
+constexpr int kRowsMaxNbh = 16;             // RIR blocks per term the pair masks can hold (2 terms x 16 bits)
 
 // pooled time blocks that are complete once the row is known up to sample `known` (not the row's end)
 __host__ __device__ constexpr int pooled_blocks_complete(int known) {
     return (known < kNfft / 2) ? 0 : (((known - kNfft / 2) / kHop + 1) / kPool);
 }
 
-// forward FFT of RIR block i (time-domain bank) -> acc (= or +=) H'_i * S'[slot]; `st` != nullptr: H'_i is also written
-// to the stash (thread t's 8 f32x4 at st[(s*4+h)*1024], the order every consumer load uses)
-template <bool ACCUMULATE>
-__device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, const ThreadTw& tw, int t, const BankRow& br,
-                                                 int i, int slot, f32x4* st, c32 (&acc)[2][8]) {
-    const f32x4* sp = p.spec + (size_t)slot * (kSpecComplex / 2) + t;
+// forward passes 1-3 of RIR block i of a time-domain bank row (the item stage follows at the caller)
+__device__ __forceinline__ void rows_forward(c32* lds, const ThreadTw& tw, int t, const BankRow& br, int i) {
     const float* h = br.h;
     const int lo = i * kB, es = br.es, cap = br.cap;
     if (es == 1 && !(cap & 1) && !(reinterpret_cast<size_t>(h) & 7)) {       // planar, 8-byte aligned rows
@@ -1690,40 +1689,35 @@ __device__ __forceinline__ void conv_block_stash(c32* lds, const ConvParams& p, 
             return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
         });
     }
-    if (!(kRowsAbl & 8)) {
-        lds_barrier();
-        pass2<false>(lds, tw.p2, t);
-        lds_barrier();
-        pass3_fwd(lds, t);
-    }
     lds_barrier();
+    pass2<false>(lds, tw.p2, t);
+    lds_barrier();
+}
+
+// v += H'[item s] * S'[item s] for one pair in memory (hp / sp: per-thread pointers of the two block spectra)
+__device__ __forceinline__ void rows_product(const f32x4* hp, const f32x4* sp, int t, int s, c32 (&v)[8]) {
+    f32x4 hv[4], sv[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        f32x4 sv[4];
+    for (int hh = 0; hh < 4; ++hh) { hv[hh] = ld_stream(hp + (s * 4 + hh) * 1024); sv[hh] = sp[(s * 4 + hh) * 1024]; }
+    if (kRowsAbl & 4) {
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) sv[hh] = (kRowsAbl & 4) ? f32x4{1.f, 0.f, 1.f, 0.f} : sp[(s * 4 + hh) * 1024];
-        c32 v[8];
-        item_load_fwd(lds, s ? tw.i1 : tw.i0, t + 1024 * s, v);
-        if (st) {
+        for (int hh = 0; hh < 4; ++hh) sv[hh] = f32x4{1.f, 0.f, 1.f, 0.f};
+    }
+    SSK_SCHED_BARRIER();                                  // all eight loads before the first multiply (see spec_block_product)
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) st[(s * 4 + hh) * 1024 + t] = mk4(v[2 * hh], v[2 * hh + 1]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const c32 w = (e & 1) ? sv[e >> 1].zw : sv[e >> 1].xy;
-            c32 pr = cmul(v[e], w);
-            if (s == 0 && e == 0 && t == 0) pr = mk2(v[0].x * w.x, v[0].y * w.y);   // (X[0], X[16384]) are real
-            if (ACCUMULATE) acc[s][e] += pr;
-            else acc[s][e] = pr;
-        }
+    for (int e = 0; e < 8; ++e) {
+        const c32 h = (e & 1) ? hv[e >> 1].zw : hv[e >> 1].xy, w = (e & 1) ? sv[e >> 1].zw : sv[e >> 1].xy;
+        c32 pr = cmul(h, w);
+        if (s == 0 && e == 0 && t == 0) pr = mk2(h.x * w.x, h.y * w.y);      // (X[0], X[16384]) are real
+        v[e] += pr;
     }
 }
 
 // STFT of the pooled blocks [b0, b1) that output block j completes (see the kernel comment).  y = the block's kB samples
 // (packed pairs t + 1024 a).  `last`: j is the row's last block (right centre padding, frames up to n_frames - 1).
 __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, int j, int b0, int b1,
-                                                bool last, const c32 (&y)[8], const float* s_win, const c32* s_tw512, c32 wq,
-                                                float* s_res, float* s_tail) {
+                                                bool last, const c32 (&y)[8], const float* s_win, const c32* s_tw512,
+                                                const c32* s_wq, float* s_res, float* s_tail) {
     float* buf = reinterpret_cast<float*>(lds);           // buf[k] = row sample 640 b0 - 256 + k
     const int base = kB * j;                              // first sample of this block
     const int ctx = j == 0 ? kNfft / 2 : base - (kHop * kPool * b0 - kNfft / 2);    // even, <= kTailFloats
@@ -1751,6 +1745,7 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     }
     lds_barrier();
     const int lane = t & 63, wv = t >> 6, cnt = b1 - b0;
+    const c32 wq = s_wq[lane & 15];
     // frames relative to the buffer: pooled block b0 + k starts at buf + 640 k; both rounds are pulled into registers
     // before the wave scratches overlay the buffer (see fused_stft_phase)
     c32 x0[16], x1[16];
@@ -1787,16 +1782,20 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
     }
-    c32 wq = p.tb.twM[64 * (t & 15)];
+    // the STFT's 256-point twiddle exp(-2 pi i q / 256), q = lane & 15: parked in LDS, read back at the start of every STFT
+    // phase (two registers that would otherwise be live across the whole row loop of a kernel at the 128-VGPR limit)
+    __shared__ c32 s_wq[16];
+    {
+        const c32 wq0 = p.tb.twM[64 * (t & 15)];
+        if (t < 16) s_wq[t] = wq0;
+    }
     // nothing the compiler tracks may be pending when the row loop starts (see k_conv_rows)
-    SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1); SSK_OPAQUE2(wq);
+    SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1);
     const int G = (int)gridDim.x;
     const int nb_rows = (p.out_len + kB - 1) / kB;
     const size_t blk_f4 = kSpecComplex / 2;               // f32x4 per block spectrum
-#if defined(__HIP_DEVICE_COMPILE__)
-    if ((kRowsAbl & 256) && ((blockIdx.x >> 3) & 1)) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-#endif
-    f32x4* stash = (SPECTRAL || !p.stash) ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
+    // the workgroup's stash: [term][RIR block] block spectra of the row being rendered (time-domain bank only)
+    f32x4* stash = SPECTRAL ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
     for (int row = row_slot(blockIdx.x, G, p.xcd_map); row < n_rows; row += G) {
         const int unit = row >> 1, ch = row & 1;
         i32x4 dws[2];
@@ -1804,8 +1803,8 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         if (p.n_terms < 2) dws[1].x = -1;                 // SS_FLAG_NO_DISTRACTOR: term 1 is ignored, as in k_conv<SIMPLE>
         // (scalars, not arrays indexed by `term`: a dynamically indexed array lives in scratch memory)
         int nbh0 = 0, nbh1 = 0;
-        if (dws[0].x >= 0) nbh0 = (uniform_load(p.rir_len + dws[0].x) + kB - 1) / kB;
-        if (dws[1].x >= 0) nbh1 = (uniform_load(p.rir_len + dws[1].x) + kB - 1) / kB;
+        if (dws[0].x >= 0) nbh0 = min(kRowsMaxNbh, (uniform_load(p.rir_len + dws[0].x) + kB - 1) / kB);
+        if (dws[1].x >= 0) nbh1 = min(kRowsMaxNbh, (uniform_load(p.rir_len + dws[1].x) + kB - 1) / kB);
         if (SPECTRAL) {
             if (dws[0].x >= 0) nbh0 = min(nbh0, bank_spec(p, dws[0].x, 0).h_blocks);
             if (dws[1].x >= 0) nbh1 = min(nbh1, bank_spec(p, dws[1].x, 0).h_blocks);
@@ -1822,69 +1821,132 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
             for (int e = tz; e < kBins4 * p.t4; e += kT) o[2 * e] = 0.f;
             continue;
         }
-        unsigned computed = 0;                            // bit (term * stash_nbh + i): H'_i of the term is in the stash
+        // pair p = term * 16 + i.  in_mem: H'_i of the term can be loaded (spectral bank: always; else: it is in the stash)
+        unsigned in_mem = SPECTRAL ? 0xffffffffu : 0u;
         int b0 = 0;
         for (int j = 0; j < nb_rows; ++j) {
             int tl = t;
             SSK_OPAQUE1(tl);                              // see k_conv: keeps LICM from hoisting the body's addresses
-            c32 acc[2][8];
             c32 y[8];
-            bool any = false, lds_used = false;
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[s][e] = mk2(0.f, 0.f);   // every product accumulates (0 + x is exact)
+            // ---- which pairs does block j use?  (wave-uniform bit masks)
+            unsigned want = 0;
             if (j < p.nb_y) {
+#pragma unroll
                 for (int term = 0; term < 2; ++term) {
                     const i32x4 dw = term ? dws[1] : dws[0];
-                    const int ridx = dw.x, spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
                     const int nb = term ? nbh1 : nbh0;
-                    for (int i = 0; i < nb; ++i) {
-                        const int m = j - i;
-                        if (m < m_min || m >= m_min + m_cnt) continue;
-                        const int slot = spec0 + (m - m_min);
-                        // lane id made opaque per product: otherwise LICM hoists every lane-invariant address of the (large)
-                        // bodies out of the loops and the 128-VGPR budget spills them all (see k_conv)
-                        int ti = tl;
-                        SSK_OPAQUE1(ti);
-                        if (SPECTRAL) {
-                            const f32x4* hp = bank_spec(p, ridx, ch).hp + (size_t)i * blk_f4 + ti;
-                            spec_block_product(p.spec, ti, hp, slot, true, acc);
-                        } else {
-                            const int sidx = term * p.stash_nbh + i;
-                            if ((computed >> sidx) & 1u) {
-                                if (!(kRowsAbl & 2))
-                                    spec_block_product<!(kRowsAbl & 128)>(p.spec, ti, stash + (size_t)sidx * blk_f4 + ti, slot, true, acc);
-                            } else {
-                                // needed again by a later output block of this row?  (m grows with j)
-                                const bool keep = stash != nullptr && j + 1 < p.nb_y && m + 1 < m_min + m_cnt &&
-                                                  !(kRowsAbl & 32) && (!(kRowsAbl & 64) || i == 0);
-                                f32x4* st = keep && !(kRowsAbl & 2) ? stash + (size_t)sidx * blk_f4 : nullptr;
-                                if (lds_used) lds_barrier();          // the previous block's item reads of layout B are done
-                                conv_block_stash<true>(lds, p, tw, ti, bank_row(p, ridx, ch), i, slot, st, acc);
-                                lds_used = true;
-                                if (keep) computed |= 1u << sidx;
-                            }
-                        }
-                        any = true;
-                    }
+                    if (dw.x < 0) continue;
+                    // m = j - i in [m_min, m_min + cnt)  <=>  i in (j - m_min - cnt, j - m_min]
+                    const int i_hi = min(nb - 1, j - dw.z), i_lo = max(0, j - dw.z - dw.w + 1);
+                    if (i_hi >= i_lo) want |= (((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u)) << (16 * term);
                 }
             }
-            if (any && !(kRowsAbl & 16)) {
-                if (lds_used) lds_barrier();
-                items_to_time(lds, tw, tl, acc, y);
+            unsigned fresh = want & ~in_mem;              // pairs whose forward FFT has to run now
+            if (want) {
+                // ---- 1. every new pair but the last: forward FFT -> stash
+                int last_new = -1;                        // the pair whose item stage carries the products
+                while (fresh) {
+                    const int pr = __builtin_ctz(fresh);
+                    fresh &= fresh - 1;
+                    const int term = pr >> 4, i = pr & 15;
+                    int ti = tl;
+                    SSK_OPAQUE1(ti);                      // per transform: see k_conv
+                    const BankRow br = bank_row(p, term ? dws[1].x : dws[0].x, ch);
+                    if (last_new >= 0 || b0 > 0 || j > 0) lds_barrier();      // (the LDS buffer's previous readers are done)
+                    rows_forward(lds, tw, ti, br, i);
+                    if (fresh) {                          // not the last one: its spectrum just goes to the stash
+                        pass3_fwd(lds, ti);
+                        lds_barrier();
+                        f32x4* st = stash + (size_t)(term * p.stash_nbh + i) * blk_f4 + ti;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            c32 v[8];
+                            item_load_fwd(lds, s ? tw.i1 : tw.i0, ti + 1024 * s, v);
+#pragma unroll
+                            for (int hh = 0; hh < 4; ++hh) st[(s * 4 + hh) * 1024] = mk4(v[2 * hh], v[2 * hh + 1]);
+                        }
+                        in_mem |= 1u << pr;
+                    }
+                    last_new = pr;
+                }
+                // ---- 2. the item stage of the block
+                int ti = tl;
+                SSK_OPAQUE1(ti);
+                const bool has_new = last_new >= 0;
+                const int n_term = last_new >> 4, n_i = last_new & 15;
+                const i32x4 ndw = n_term ? dws[1] : dws[0];
+                // the new pair's window spectrum, item 0: under pass 3
+                const f32x4* spn = p.spec + (size_t)(ndw.y + (j - n_i - ndw.z)) * blk_f4 + ti;
+                f32x4 sn[4];
+                if (has_new) {
+#pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) sn[hh] = spn[hh * 1024];
+                    if (!(kRowsAbl & 8)) pass3_fwd(lds, ti);
+                    lds_barrier();
+                }
+                // needed by a later output block of this row?  (m = j - i grows with j)
+                const bool keep = has_new && !SPECTRAL && j + 1 < p.nb_y && (j - n_i) + 1 < ndw.z + ndw.w;
+                const unsigned mem_pairs = (kRowsAbl & 2) ? 0u : (want & in_mem);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    c32 v[8];
+                    if (has_new) {
+                        if (s == 1) {
+#pragma unroll
+                            for (int hh = 0; hh < 4; ++hh) sn[hh] = spn[(4 + hh) * 1024];
+                        }
+                        item_load_fwd(lds, s ? tw.i1 : tw.i0, ti + 1024 * s, v);
+                        if (keep) {
+                            f32x4* st = stash + (size_t)(n_term * p.stash_nbh + n_i) * blk_f4 + ti;
+#pragma unroll
+                            for (int hh = 0; hh < 4; ++hh) st[(s * 4 + hh) * 1024] = mk4(v[2 * hh], v[2 * hh + 1]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const c32 w = (kRowsAbl & 4) ? mk2(1.f, 0.f) : ((e & 1) ? sn[e >> 1].zw : sn[e >> 1].xy);
+                            c32 pr = cmul(v[e], w);
+                            if (s == 0 && e == 0 && ti == 0) pr = mk2(v[0].x * w.x, v[0].y * w.y);   // (X[0], X[16384]) are real
+                            v[e] = pr;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = mk2(0.f, 0.f);
+                    }
+                    unsigned mp = mem_pairs;
+                    while (mp) {
+                        const int pr = __builtin_ctz(mp);
+                        mp &= mp - 1;
+                        const int term = pr >> 4, i = pr & 15;
+                        const i32x4 dw = term ? dws[1] : dws[0];
+                        const f32x4* hp = SPECTRAL ? bank_spec(p, dw.x, ch).hp + (size_t)i * blk_f4
+                                                   : stash + (size_t)(term * p.stash_nbh + i) * blk_f4;
+                        const f32x4* sp = p.spec + (size_t)(dw.y + (j - i - dw.z)) * blk_f4;
+                        rows_product(hp + ti, sp + ti, ti, s, v);
+                    }
+                    item_store_inv(lds, s ? tw.i1 : tw.i0, ti + 1024 * s, v);
+                }
+                if (keep) in_mem |= 1u << last_new;
+                // ---- 3. inverse passes
+                if (!(kRowsAbl & 16)) simple_row_inv(lds, tw, ti, y);
+                else {
+                    lds_barrier();
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) y[a] = lds[ti + 1024 * a];
+                }
             } else {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) y[a] = (kRowsAbl & 16) ? acc[0][a] : mk2(0.f, 0.f);
+                for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
             }
-            if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row, j, y);
+            int row_j = row;                              // (output addresses are rebuilt per block, in scalar registers:
+            SSK_OPAQUE_S(row_j);                          //  hoisted out of the j loop they lived in VGPRs and spilled)
+            if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row_j, j, y);
             const bool last = j == nb_rows - 1;
             const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
             if (kRowsAbl & 1) {
                 if (y[0].x == 123.456f) p.sgram[0] = y[7].y;      // keeps the convolution alive
                 lds_barrier();
             } else
-            rows_stft_phase(lds, p, tl, unit, ch, j, b0, b1, last, y, s_win, s_tw512, wq, s_res, s_tail);
+            rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1, last, y, s_win, s_tw512, s_wq, s_res, s_tail);
             b0 = b1;
         }
         lds_barrier();                                    // s_res / the scratches are reused by the next row

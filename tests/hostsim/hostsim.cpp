@@ -270,7 +270,8 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     const int n_rows = 2 * n_units, grid = wgs < n_rows ? wgs : n_rows;
     std::vector<float> stash;
     p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
-    if (!hspec && p.nb_y > 1 && use_stash) {
+    (void)use_stash;                                    // (the time-domain path always has its stash)
+    if (!hspec) {
         p.stash_nbh = (cap + ssk::kB - 1) / ssk::kB;
         if (p.n_buckets > 1 && p.bk[0].h_blocks > p.stash_nbh) p.stash_nbh = p.bk[0].h_blocks;
         p.stash_terms = p.n_terms;

@@ -356,11 +356,11 @@ def test_randomised_edge_cases(seed):
 
 
 # ---- k_obs_rows: fused observation for rows of 2-3 partition blocks (44.1 kHz) -------------------------------------------
-@pytest.mark.parametrize("spectral,stash", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("spectral,stash", [(False, True), (True, False)])
 def test_fused_rows_44k_vs_reference_vectors(spectral, stash):
     """One launch at the reference's Replica rate: simulator.py:629-632 on 44100-sample rows + nav.py:86-100 -> (65, 69, 2);
-    the waveform is optional.  Time-domain bank (forward FFTs re-run per use, or every RIR block transformed once and its
-    spectrum stashed for the later output blocks) and spectral bank."""
+    the waveform is optional.  Time-domain bank (every RIR block transformed once per row, its spectrum stashed for the
+    later output blocks) and spectral bank."""
     d = case_inputs("clip1s_44k")
     sr = d["sr"]
     ref_a, ref_s, stride = case_outputs("clip1s_44k")
@@ -379,9 +379,9 @@ def test_fused_rows_44k_vs_reference_vectors(spectral, stash):
 @pytest.mark.parametrize("wgs", [1, 3, 64])
 def test_fused_rows_equal_two_kernel_path(wgs):
     """k_obs_rows against k_conv (loop kernel, forward FFTs re-run per output block) + k_spectrogram on the same inputs:
-    multi-second clips in the early and the steady branch (negative partition offsets), a 2-s RIR (6 blocks), ragged and
-    empty RIRs, a distractor, silent units in the middle of a walk - bit-identical waveforms (same products in the same
-    order), spectrograms to rounding."""
+    multi-second clips in the early and the steady branch (negative partition offsets: several new RIR blocks in output
+    block 0, all of them from the stash afterwards), a 2-s RIR (6 blocks), ragged and empty RIRs, a distractor, silent
+    units in the middle of a walk."""
     rng = np.random.default_rng(23)
     sr = 44100
     srcs = [O.synth_sources(rng, sr, k=1, seconds=s)[0] for s in (1, 3, 1)]
@@ -400,10 +400,8 @@ def test_fused_rows_equal_two_kernel_path(wgs):
              dict(sound=1, t0=0, rir=0)]
     a_ref, s_ref = hs.run(srcs, bank, lens, units, sr, sr, fuse=False, want_spectrogram=True)
     a, sg = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs)
-    a_st, sg_st = hs.run(srcs, bank, lens, units, sr, sr, row_wgs=wgs, row_stash=True)      # block spectra stashed
-    np.testing.assert_array_equal(a_st, a)
-    np.testing.assert_array_equal(sg_st, sg)
-    np.testing.assert_array_equal(a, a_ref)
+    # (the products of an output block are summed in a different order than in the loop kernel: equal to rounding)
+    assert np.abs(a - a_ref).max() <= 2e-6 * np.abs(a_ref).max()
     assert np.abs(sg - s_ref).max() <= 1e-6 * np.abs(s_ref).max()
     assert not a[2].any() and not sg[2].any() and not a[4].any() and not sg[4].any()
     # and against the oracle, unit by unit
@@ -432,7 +430,7 @@ def test_fused_rows_lengths_pads_and_short_steps(out_len, n_valid, pad):
     units = [dict(sound=0, t0=777, rir=0, wrap=False)]
     a_ref, s_ref = hs.run([src], bank, [L], units, n_valid, out_len, fuse=False, want_spectrogram=True, pad_mode=pad)
     a, sg = hs.run([src], bank, [L], units, n_valid, out_len, row_wgs=2, pad_mode=pad, interleaved=True)
-    np.testing.assert_array_equal(a, a_ref)
+    assert np.abs(a - a_ref).max() <= 2e-6 * max(1e-30, np.abs(a_ref).max())
     assert np.abs(sg - s_ref).max() <= 1e-6 * max(1e-30, np.abs(s_ref).max())
     assert not a[0, :, n_valid:].any()
     check(sg[0], O.compute_spectrogram(a_ref[0], pad_mode="constant" if pad else "reflect"))
@@ -466,7 +464,7 @@ def test_bucketed_bank_short_and_long_rirs_in_one_launch(sr, fused_rows):
     kw = dict(row_wgs=3) if fused_rows else dict(fuse=True, simple=False)
     a_ref, s_ref = hs.run(srcs, one, lens, units, sr, sr, **kw)
     a, sg = hs.run(srcs, b0, lens, units, sr, sr, bucket2=b1, **kw)
-    np.testing.assert_array_equal(a, a_ref)
+    np.testing.assert_array_equal(a, a_ref)                                      # (same kernel, same order: same bits)
     np.testing.assert_array_equal(sg, s_ref)
     check(a[1], O.compute_audiogoal(srcs[1], np.ascontiguousarray(b1[0].T), sr, audio_index=3))
     check(a[4], O.compute_audiogoal(srcs[0], np.ascontiguousarray(b0[2, :, :7000].T), sr, distractor=srcs[0],
