@@ -1,11 +1,25 @@
 #!/bin/bash
-set -u
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-echo "== 2 ranks, gloo, shared GPU, allgather"
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 --backend gloo --bank-mib 128 2>&1 | tail -3
-echo "== 2 ranks, gloo, exchange none"
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --steps 50 --warmup 5 --backend gloo --bank-mib 128 --exchange none 2>&1 | tail -2
-echo "== 1 rank nccl init path (world 1 via torchrun)"
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --bank-mib 128 2>&1 | tail -1 | cut -c1-300
-echo "== cfg[3] shape, functionally: 8 ranks x 16 envs (strong scaling of 128 envs), gloo, all ranks on the one GPU, chunked gather"
-timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 8 --scaling strong --steps 30 --warmup 5 --backend gloo --bank-mib 64 2>&1 | tail -2 | cut -c1-900
+# The length-bucket mix (scripts/bench_buckets.py) and the multi-rank flows of bench.py exercised on the ONE GPU of a gpurun
+# box: bench.py --gpus N launches its N ranks itself; both / all ranks share the GPU and gloo is the control plane, so this is
+# FUNCTIONAL only (rank flow, every exchange transport incl. the consumer-release protocol, strong scaling of cfg[3]).
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+OUT="$GRAFT_REPO_ROOT/gpurun_out/dist_smoke"; mkdir -p "$OUT"
+timeout 600 python scripts/bench_buckets.py > "$OUT/bench_buckets.json" 2> "$OUT/bench_buckets.err"; echo "buckets rc=$?"; cat "$OUT/bench_buckets.json"; tail -3 "$OUT/bench_buckets.err"
+# multi-rank flows of bench.py on the ONE GPU of the box (functional only: both ranks share the GPU; gloo control plane)
+for EX in allgather peercopy gather none; do
+  timeout 600 python bench.py --gpus 2 --backend gloo --exchange $EX --steps 24 --warmup 4 --spinup-steps 64 --envs 32 --bank-mib 64 --no-secondary > "$OUT/dist2_$EX.json" 2> "$OUT/dist2_$EX.err"; echo "dist $EX rc=$?"
+  python -c "
+import json,sys
+try:
+    d=json.loads(open('$OUT/dist2_$EX.json').read().strip().splitlines()[-1]); print('$EX', d['n_gpus'], d['value'], d['config']['exchange'])
+except Exception as e: print('$EX ERR', e); print(open('$OUT/dist2_$EX.err').read()[-1500:])
+"
+done
+timeout 600 python bench.py --gpus 8 --backend gloo --scaling strong --envs 128 --steps 16 --warmup 4 --spinup-steps 32 --bank-mib 64 --no-secondary > "$OUT/dist8_strong.json" 2> "$OUT/dist8_strong.err"; echo "dist8 rc=$?"
+python -c "
+import json
+try:
+    d=json.loads(open('$OUT/dist8_strong.json').read().strip().splitlines()[-1]); print('strong8', d['n_gpus'], d['value'], d['config']['envs_per_gpu'], d['config']['exchange'])
+except Exception as e: print('strong8 ERR', e); print(open('$OUT/dist8_strong.err').read()[-1500:])
+"

@@ -1249,7 +1249,6 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 // are defined on the time-domain bank, the actual traffic of this kernel is about twice that - reported as such.
 // Same unit descriptors as k_conv (term = {bank entry | -1, first window slot, m_min, count}); rir_len[entry] still
 // says how many blocks of the entry are non-zero.
-template <bool NT = true>
 __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, const f32x4* hp, int slot, bool accumulate,
                                                    c32 (&acc)[2][8]) {
     const f32x4* sp = spec + (size_t)slot * (kSpecComplex / 2) + t;
@@ -1258,17 +1257,9 @@ __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, con
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
-            hv[s][hh] = NT ? ld_stream(hp + (s * 4 + hh) * 1024) : hp[(s * 4 + hh) * 1024];
+            hv[s][hh] = ld_stream(hp + (s * 4 + hh) * 1024);
             sv[s][hh] = sp[(s * 4 + hh) * 1024];
         }
-#if defined(SS_ROWS_ABL)
-    if (SS_ROWS_ABL & 4) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int hh = 0; hh < 4; ++hh) sv[s][hh] = f32x4{1.f, 0.f, 1.f, 0.f};
-    }
-#endif
     // ALL sixteen loads are issued before the first multiply: left alone, the scheduler starts the first product after
     // four loads and puts an s_waitcnt vmcnt(2) in front of it (seen in the ISA) - the wave then sits out one full memory
     // latency with a quarter of its loads in flight before it issues the other twelve
