@@ -58,6 +58,10 @@ int ss_version(void);
 
 /* Build (idempotent) the constant tables for the current HIP device. */
 int ss_init(void);
+/* Rows longer than kB (44.1 kHz) make the library keep a scratch per (device, stream) for the block spectra of the rows in
+ * flight (96 MiB per stream at 44.1 kHz without distractors), allocated by the stream's first such call (not inside a
+ * hipGraph capture: warm the stream up first).  This frees all of them (after a device synchronise). */
+int ss_release_scratch(void);
 
 /* Source-window spectra.  win_desc[w] = {src_offset, src_len, start, wrap} (int32 x4):
  * window w holds samples src[src_offset + start + n], n in [0, 2*kB), zero outside [0, src_len)

@@ -154,6 +154,17 @@ int ss_block_len(void) { return ssk::kB; }
 int ss_spec_floats(void) { return 2 * ssk::kSpecComplex; }
 int ss_version(void) { return 1; }
 
+// Frees the per-(device, stream) scratch k_obs_rows keeps (see get_stash); synchronises the device first.
+int ss_release_scratch(void) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return hip_err(e);
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_stash)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    g_stash.clear();
+    return 0;
+}
+
 int ss_init(void) {
     ssk::Tables tb;
     return get_tables(&tb);

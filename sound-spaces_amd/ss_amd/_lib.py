@@ -14,7 +14,7 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
-           "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets")
+           "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch")
 
 
 class SsRirBucket(ctypes.Structure):
