@@ -106,7 +106,12 @@ class HipSimAudio:
     def _compute(self, want_spectrogram: bool):
         if hasattr(self.engine, "begin_batch"):
             self.engine.begin_batch()
-        out = self.engine.observe([self.unit_request()], want_audiogoal=True, want_spectrogram=want_spectrogram)
+        req = self.unit_request()
+        if req.silent:
+            # simulator.py:610-612: np.zeros((2, sr)) - FLOAT64, and so is the spectrogram nav.py:86-100 makes of it; no launch
+            from .planning import spectrogram_shape
+            return np.zeros((2, self.sr)), (np.zeros(spectrogram_shape(self.sr)) if want_spectrogram else None)
+        out = self.engine.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram)
         ag = out["audiogoal"][0].cpu().numpy()
         sg = out["spectrogram"][0].cpu().numpy() if want_spectrogram else None
         return ag, sg

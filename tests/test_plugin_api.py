@@ -71,7 +71,11 @@ def test_eager_mode_matches_reference_and_caches():
 def test_silent_and_unreadable_rir_give_exact_zeros():
     sim, eng, backend, *_ = make()
     sim._episode_step_count, sim._duration = 501, 500
-    assert not backend.get_current_spectrogram_observation().any()
+    sg0 = backend.get_current_spectrogram_observation()
+    assert not sg0.any() and sg0.dtype == np.float64 and sg0.shape == (65, 26, 2)      # float64 zeros, like simulator.py:612
+    sim._audiogoal_cache, sim._spectrogram_cache = dict(), dict()
+    assert backend.get_current_audiogoal_observation().dtype == np.float64 and eng.calls == 0   # ... and no launch for them
+    sim._audiogoal_cache, sim._spectrogram_cache = dict(), dict()
     sim._episode_step_count = 0
     sim._receiver_position_index = 5                                              # -> 5_7.wav unreadable
     assert not backend.get_current_audiogoal_observation().any()
