@@ -175,6 +175,26 @@ def main():
     y, _ = run_sim(sr2, src44, wav_layout(rir44[0]))
     add("clip1s_44k", y, sr=sr2, src_seed=6, rir_seed=7)
 
+    # ---- 44.1 kHz beyond the 1-s clip (round 3: rows of three partition blocks go through the fused k_obs_rows): a 3-s
+    # source in the early and the steady branch, a 1.5-s RIR (5 blocks), a ragged RIR, a distractor
+    src44_3 = O.synth_sources(np.random.default_rng(10), sr2, k=1, seconds=3)[0]
+    rir44b = O.synth_rir(np.random.default_rng(11), sr2, n=2)
+    for idx in (0, 1, 2):
+        y, nxt = run_sim(sr2, src44_3, wav_layout(rir44b[0]), audio_index=idx)
+        add(f"multi_L1.0_i{idx}_44k", y, sr=sr2, src_seed=10, seconds=3, rir_seed=11, rir_n=2, rir_sel=0, rir_len=sr2,
+            audio_index=idx, next_index=int(nxt))
+    rir44_15 = O.synth_rir(np.random.default_rng(12), sr2, length=66150, n=1)
+    y, nxt = run_sim(sr2, src44_3, wav_layout(rir44_15[0]), audio_index=2)
+    add("multi_L1.5_i2_44k", y, sr=sr2, src_seed=10, seconds=3, rir_seed=12, rir_n=1, rir_sel=0, rir_len=66150,
+        audio_index=2, next_index=int(nxt))
+    rir44_r = O.synth_rir(np.random.default_rng(13), sr2, length=30011, n=1)
+    srcs44 = O.synth_sources(np.random.default_rng(14), sr2, k=2, seconds=1)
+    y, _ = run_sim(sr2, srcs44[0], wav_layout(rir44_r[0]))
+    add("clip1s_ragged_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, rir_seed=13, rir_n=1, rir_sel=0, rir_len=30011)
+    y, _ = run_sim(sr2, srcs44[0], wav_layout(rir44b[0]), distractor=srcs44[1], distractor_rir=wav_layout(rir44b[1]))
+    add("distractor_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, dis_sel=1, rir_seed=11, rir_n=2, rir_sel=0,
+        dis_rir_sel=1)
+
     # ---- A5 continuous simulator
     crossfade = load_fn("soundspaces/continuous_simulator.py", None, "crossfade", {})
     cws = load_fn("soundspaces/continuous_simulator.py", "ContinuousSoundSpacesSim", "_convolve_with_rir", {})
@@ -204,6 +224,14 @@ def main():
                  use_crossfade=True)
     add("cont_crossfade", y, sr=sr, src_seed=1, src_k=3, src_sel=0, rir_seed=8, rir_len=9000, rir_n=2,
         rir_sel=0, last_rir_sel=1, sample_index=20000, step_time=0.25)
+
+    # ---- SS2.0 at 44.1 kHz: 0.25-s steps = 11025 samples of a 44100-sample row (one convolved block, two zero blocks)
+    src3_44 = O.tile_short_source(srcs44[0], sr2)
+    rc44 = O.synth_rir(np.random.default_rng(15), sr2, length=20000, n=1)
+    for name, si in (("early", 3000), ("steady", 50000)):
+        y = run_cont(sr2, src3_44, wav_layout(rc44[0]), si)
+        add(f"cont_{name}_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, rir_seed=15, rir_len=20000, rir_n=1,
+            rir_sel=0, sample_index=si, step_time=0.25)
 
     # ---- early branch running past the clip end (:433-437): a 3.1-s RIR (irTime allows up to 4 s), index < L, and
     # index + num_sample > len(source): the slice source[:index+num_sample] just ends, i.e. ZEROS past the clip end,

@@ -1050,3 +1050,42 @@ def test_torch_ops_spectral_variants_and_observe_level_op():
     got = torch.ops.ss_hip.ctx_observe(ctx.handle, i32([u.sound for u in units]), i32([0] * 7), i32([u.rir for u in units]), out)
     torch.cuda.synchronize()
     assert got.data_ptr() == out.data_ptr() and torch.equal(out, sg)
+
+
+@pytest.mark.parametrize("name", [c for c in golden()[1] if c.endswith("_44k") and not c.startswith("cont_")])
+def test_reference_run_vectors_at_44k_one_launch(name):
+    """Every 44.1 kHz vector produced by running the reference's own _compute_audiogoal (1-s clip, ragged RIR, 3-s clips
+    in both branches, a 1.5-s RIR, a distractor) through renderer -> ss_audio_obs_f32 -> k_obs_rows, time-domain and
+    spectral bank."""
+    from ss_amd.renderer import UnitRequest
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    srcs, rirs = [d["source"]], [d["rir"]]
+    u = UnitRequest(0, P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0)), 0)
+    if "distractor" in d:
+        srcs.append(d["distractor"]); rirs.append(d["distractor_rir"])
+        u.dis_sound, u.dis_rir = 1, 1
+    r = make_renderer(sr, srcs, rirs)
+    ag, sg = r.render(r.plan([u]), want_audiogoal=True)
+    check(ag[0].cpu().numpy()[:, ::stride], ref_a)
+    check(sg[0].cpu().numpy(), ref_s)
+    r.rirs.build_spectra()
+    none, sg2 = r.render(r.plan([u]))
+    assert none is None
+    check(sg2[0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k"])
+def test_continuous_steps_at_44k_one_launch(name):
+    from ss_amd.renderer import UnitRequest
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    r = make_renderer(sr, [O.tile_short_source(d["source"], sr)], [d["rir"]], step_time=d["step_time"], wrap=True)
+    ag, sg = r.render(r.plan([UnitRequest(0, d["sample_index"], 0, wrap=d["sample_index"] - d["rir"].shape[0] >= 0)]),
+                      want_audiogoal=True)
+    ag = ag.cpu().numpy()
+    assert not ag[0][:, int(sr * d["step_time"]):].any()
+    check(ag[0][:, ::stride], ref_a)
+    check(sg[0].cpu().numpy(), ref_s)

@@ -476,3 +476,46 @@ def test_bucketed_bank_short_and_long_rirs_in_one_launch(sr, fused_rows):
         a1, s1 = hs.run(srcs, b0, short_len, u0, sr, sr, fuse=True)
         np.testing.assert_array_equal(a0, a1)
         np.testing.assert_array_equal(s0, s1)
+
+
+SIM_44K = [c for c in golden()[1] if c.endswith("_44k") and c.startswith(("clip1s_ragged", "multi_", "distractor"))]
+
+
+@pytest.mark.parametrize("name", SIM_44K)
+def test_fused_rows_vs_reference_run_vectors_at_44k(name):
+    """k_obs_rows against vectors produced by RUNNING the reference's _compute_audiogoal at 44.1 kHz (make_golden.py, round
+    3): 3-s clips in the early and the steady branch (all three RIR blocks new in output block 0, everything from the
+    stash afterwards), a 1.5-s RIR (5 blocks), a ragged RIR, a distractor."""
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
+    srcs, banks, lens = [d["source"]], [d["rir"]], [d["rir"].shape[0]]
+    u = dict(sound=0, t0=t0, rir=0)
+    if "distractor" in d:
+        srcs.append(d["distractor"]); banks.append(d["distractor_rir"]); lens.append(d["distractor_rir"].shape[0])
+        u.update(dis_sound=1, dis_t0=0, dis_rir=1)
+    cap = max(lens) + (max(lens) & 1)
+    bank = np.concatenate([planar(b, cap) for b in banks])
+    out, sg = hs.run(srcs, bank, lens, [u], sr, sr, row_wgs=2)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+    _, sg_s = hs.run(srcs, bank, lens, [u], sr, sr, row_wgs=2, spectral=True, want_audiogoal=False)
+    check(sg_s[0], ref_s)
+
+
+@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k"])
+def test_fused_rows_continuous_steps_at_44k(name):
+    """SS2.0 0.25-s steps at 44.1 kHz (reference-run: continuous_simulator.py:413-456): 11025 valid samples of a
+    44100-sample row - one convolved block, two blocks of zeros, the spectrogram over the whole row."""
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    wrap = d["sample_index"] - d["rir"].shape[0] >= 0
+    out, sg = hs.run([src3], planar(d["rir"]), [d["rir"].shape[0]],
+                     [dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=wrap)], ns, sr, row_wgs=1)
+    assert not out[0][:, ns:].any()
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
