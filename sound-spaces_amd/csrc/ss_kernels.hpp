@@ -1799,6 +1799,9 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         if (SPECTRAL) {
             if (dws[0].x >= 0) nbh0 = min(nbh0, bank_spec(p, dws[0].x, 0).h_blocks);
             if (dws[1].x >= 0) nbh1 = min(nbh1, bank_spec(p, dws[1].x, 0).h_blocks);
+        } else {                                          // (never more blocks than the entry's row - and the stash - holds)
+            if (dws[0].x >= 0) nbh0 = min(nbh0, min(p.stash_nbh, (bank_row(p, dws[0].x, 0).cap + kB - 1) / kB));
+            if (dws[1].x >= 0) nbh1 = min(nbh1, min(p.stash_nbh, (bank_row(p, dws[1].x, 0).cap + kB - 1) / kB));
         }
         if (dws[0].x < 0 && dws[1].x < 0) {               // silent unit (simulator.py:610-612): exact zeros, no transforms
             int tz = t;

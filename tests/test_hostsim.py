@@ -519,3 +519,26 @@ def test_fused_rows_continuous_steps_at_44k(name):
     assert not out[0][:, ns:].any()
     check(out[0][:, ::stride], ref_a)
     check(sg[0], ref_s)
+
+
+def test_fused_rows_four_second_rir_eleven_blocks():
+    """SS2.0's ray-traced RIRs run to 4 s: 176400 taps = 11 partition blocks at 44.1 kHz.  A 5-s clip in the steady branch
+    (output block 0 finds 11 new RIR blocks: ten stash-only forward FFTs, the eleventh carries the products; blocks 1, 2 are
+    served from the stash alone) and a 0.25-s SS2.0 step with wrap-around, against the oracle."""
+    rng = np.random.default_rng(41)
+    sr, L = 44100, 4 * 44100
+    src = O.synth_sources(rng, sr, k=1, seconds=5)[0]
+    h = O.synth_rir(rng, sr, length=L, n=1)[0] * np.exp(-np.arange(L) / (0.9 * sr))[None, :].astype(np.float32)
+    bank = h[None].astype(np.float32)
+    rir_wav = np.ascontiguousarray(h.T)
+    t0 = P.window_start_sim(len(src), sr, 4)
+    out, sg = hs.run([src], bank, [L], [dict(sound=0, t0=t0, rir=0)], sr, sr, row_wgs=1)
+    ref = O.compute_audiogoal(src, rir_wav, sr, audio_index=4)
+    check(out[0], ref)
+    check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
+    ns = sr // 4
+    out, sg = hs.run([src], bank, [L], [dict(sound=0, t0=P.window_start_continuous(200000), rir=0, wrap=True)], ns, sr,
+                     row_wgs=1)
+    ref = O.convolve_with_rir(src, rir_wav, sr, 200000, 0.25)
+    check(out[0], ref)
+    check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
