@@ -958,7 +958,7 @@ def test_bucketed_store_mixes_short_and_3s_rirs_without_reallocating_the_bank():
     sg_p = r1.render(r1.plan([UnitRequest(0, 0, h_) for h_ in range(10)]))[1]
     assert torch.equal(sg_b, sg_p)
     # the reference-run vectors with a 1.5-s RIR and a 5-s clip, RIR in the middle bucket
-    for name in [c for c in golden()[1] if c.startswith("multi_L1.5")]:
+    for name in [c for c in golden()[1] if c.startswith("multi_L1.5") and not c.endswith("_44k")]:
         d = case_inputs(name)
         ref_a, ref_s, stride = case_outputs(name)
         e2 = AudioEngine(sr, device=DEV, rir_buckets=[(8, sr), (4, 2 * P.KB)])
