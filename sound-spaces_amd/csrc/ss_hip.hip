@@ -59,6 +59,23 @@ int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
 inline int n_frames_of(int len) { return 1 + len / ssk::kHop; }
 inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kPool; }
 
+// The context API knows the unit descriptors of a step on the HOST (it has just planned them): for the duration of its
+// launch call it leaves them here, and loop-free launches of <= kTabUnits units then carry {index, slot} per unit in the
+// kernel arguments (ConvParams::tab).  Callers of the stateless entry points hand over device pointers only: nullptr.
+thread_local const int* g_host_desc = nullptr;
+
+inline void fill_unit_tab(ssk::ConvParams& p, const int* host_desc, int n_units) {
+    p.tab_n = 0;
+    if (!host_desc || n_units > ssk::kTabUnits) return;
+    for (int i = 0; i < n_units; ++i) {
+        const int* d = host_desc + 8 * i;
+        const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;          // window m = 0 of the unit's key is stored
+        p.tab[2 * i] = ok ? d[0] : -1;
+        p.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
+    }
+    p.tab_n = n_units;
+}
+
 template <bool FUSE>
 int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
@@ -81,7 +98,10 @@ int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, 
         }
     }
     if (flags & SS_FLAG_CROSSFADE) hipLaunchKernelGGL((ssk::k_conv<FUSE, false, true>), grid, block, 0, st, p);
-    else if (simple) hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+    else if (simple) {
+        fill_unit_tab(p, g_host_desc, n_units);
+        hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+    }
     else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }
@@ -235,6 +255,7 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.n_terms = 2;
     p.n_buckets = 1;
     for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
+    p.tab_n = 0;
 #if defined(SS_LADDER)                                     // profiling builds only (scripts/gpu_ladder.sh compiles with -DSS_LADDER)
     static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
     p.dbg = dbg;
@@ -440,8 +461,10 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
         }
     }
     const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
-    if (simple) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
+    if (simple) {
+        fill_unit_tab(p, g_host_desc, n_units);
+        hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
+    } else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }
 
@@ -832,6 +855,8 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         audiogoal = c.ag_scratch;
     }
     const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);
+    static const bool no_tab = std::getenv("SS_HIP_NO_UNIT_TAB") != nullptr;         // A/B switch for benchmarking
+    g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
     if (!c.buckets.empty()) {
         const int nb = static_cast<int>(c.buckets.size());
         rc = spectrogram ? ss_audio_obs_buckets_f32(c.pool, c.buckets.data(), nb, c.rir_len, dd, audiogoal, spectrogram, n,
@@ -850,6 +875,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     else
         rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
                                      c.n_valid, c.out_len, res.flags, stream);
+    g_host_desc = nullptr;
     if (rc) return fail(rc);
     // (overlap mode: a group's ticks alternate between the lanes; each lane records its half after ITS last tick)
     return close_slot();

@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void k_gccphat(GccParams p) {
 // (44.1 kHz: 3 output blocks) re-run the forward FFTs per output block instead of holding 3 accumulators
 // (96 VGPRs) that a 1024-thread workgroup does not have.
 constexpr int kMaxBuckets = 4;
+constexpr int kTabUnits = 256;
 struct BankBucket {
     const float* rir;            // planar [n, 2, cap] rows, zero beyond each entry's length
     const f32x4* hspec;          // spectral form [n][2][h_blocks][8192] f32x4, or nullptr
@@ -855,6 +856,12 @@ struct ConvParams {
     // bucket per term from the wave-uniform bank index (scalar compares, no memory access).
     int n_buckets;
     BankBucket bk[kMaxBuckets - 1];
+    // Loop-free kernels, launches of <= kTabUnits units whose descriptors the HOST knows (the context API): the two words a
+    // SIMPLE row needs - {bank index | -1, window-spectrum slot} - ride in the kernel-argument block itself, so the chain in
+    // front of the row's first loads is ONE scalar fetch (arguments) instead of arguments -> descriptor (which for the
+    // context's in-place descriptors is a round trip over the host link) -> length word.  tab_n = 0: read p.desc as before.
+    int tab_n;
+    int tab[2 * kTabUnits];
 #if defined(SS_LADDER)
     int dbg;                     // timing experiments only (scripts/gpu_ladder.sh, -DSS_LADDER builds): early exit point
 #endif
@@ -1110,7 +1117,8 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     c32 y[8];
     bool any = false;
     if (SIMPLE) {
-        const int ridx = __builtin_amdgcn_readfirstlane(d[0]);
+        const bool tab = p.tab_n > 0;                       // (kernel argument: wave-uniform)
+        const int ridx = tab ? p.tab[2 * unit] : __builtin_amdgcn_readfirstlane(d[0]);
         bool active = false;
         if (ridx >= 0) {
             const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
@@ -1124,11 +1132,21 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) hraw[a] = ld_stream(h2 + min(t + 1024 * a, m_end - 1));   // clamped, not
             }                                                   // predicated (see the table loads); masked where consumed
-            const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
-            const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
-            const int m_min = __builtin_amdgcn_readfirstlane(d[2]);
-            const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
-            if (L > 0 && m_min <= 0 && m_min + m_cnt > 0) {
+            // table form: the host has already folded "window 0 is stored" into the index, and an empty RIR needs no length
+            // word: its row is zero up to the capacity, so its convolution comes out as exact zeros (as in k_conv_spec)
+            int slot0 = 0;
+            bool ok = true;
+            if (tab) {
+                slot0 = p.tab[2 * unit + 1];
+            } else {
+                const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
+                const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
+                const int m_min = __builtin_amdgcn_readfirstlane(d[2]);
+                const int m_cnt = __builtin_amdgcn_readfirstlane(d[3]);
+                slot0 = spec0 - m_min;
+                ok = L > 0 && m_min <= 0 && m_min + m_cnt > 0;
+            }
+            if (ok) {
                 if (planar) {
                     const int m_end = cap >> 1;
                     pass1_fwd<true>(lds, tw.p1, t, [&](int m) { return m < m_end ? hraw[(m - t) >> 10] : mk2(0.f, 0.f); });
@@ -1138,7 +1156,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
                         return mk2(n < cap ? h[(size_t)n * es] : 0.f, n + 1 < cap ? h[(size_t)(n + 1) * es] : 0.f);
                     });
                 }
-                simple_row_after_pass1(lds, p, tw, t, spec0 - m_min, y);
+                simple_row_after_pass1(lds, p, tw, t, slot0, y);
                 active = true;
             }
         }
@@ -1320,7 +1338,9 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     bool any = false;
     const size_t row_f4 = (size_t)p.h_blocks * (kSpecComplex / 2);     // f32x4 per (entry, ear)
     if (SIMPLE) {
-        const i32x4 dw = uniform_load4(d);
+        i32x4 dw;
+        if (p.tab_n > 0) dw = i32x4{p.tab[2 * unit], p.tab[2 * unit + 1], 0, 1};    // {index | -1, slot of window 0, m_min, count}
+        else dw = uniform_load4(d);
         const int ridx = dw.x;
         if (ridx >= 0) {
             // The length word is NOT read here: it would be a third dependent scalar round trip (kernel arguments ->

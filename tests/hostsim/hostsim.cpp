@@ -99,6 +99,7 @@ static int g_b2_first = 0, g_b2_cap = 0;
 static void apply_bucket2(ssk::ConvParams& p) {
     p.n_buckets = 1;
     for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
+    p.tab_n = 0;
     if (g_b2_rir) {
         p.n_buckets = 2;
         p.bk[0] = ssk::BankBucket{g_b2_rir, nullptr, g_b2_first, g_b2_cap, (g_b2_cap + ssk::kB - 1) / ssk::kB, 0};
