@@ -100,7 +100,8 @@ int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, 
     if (flags & SS_FLAG_CROSSFADE) hipLaunchKernelGGL((ssk::k_conv<FUSE, false, true>), grid, block, 0, st, p);
     else if (simple) {
         fill_unit_tab(p, g_host_desc, n_units);
-        hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+        if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv<FUSE, true, false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
     }
     else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
@@ -463,7 +464,8 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
     const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
     if (simple) {
         fill_unit_tab(p, g_host_desc, n_units);
-        hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
+        if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
     } else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }

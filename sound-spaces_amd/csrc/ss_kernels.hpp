@@ -859,7 +859,8 @@ struct ConvParams {
     // Loop-free kernels, launches of <= kTabUnits units whose descriptors the HOST knows (the context API): the two words a
     // SIMPLE row needs - {bank index | -1, window-spectrum slot} - ride in the kernel-argument block itself, so the chain in
     // front of the row's first loads is ONE scalar fetch (arguments) instead of arguments -> descriptor (which for the
-    // context's in-place descriptors is a round trip over the host link) -> length word.  tab_n = 0: read p.desc as before.
+    // context's in-place descriptors is a round trip over the host link) -> length word.  Read by the TAB instantiations only
+    // (k_conv<.., SIMPLE, .., TAB>, k_conv_spec<.., SIMPLE, TAB>); tab_n = 0: the launcher picked the plain ones.
     int tab_n;
     int tab[2 * kTabUnits];
 #if defined(SS_LADDER)
@@ -1088,9 +1089,10 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
 // of that result (at most two packed pairs per thread) are kept in registers, then the row is convolved with the
 // current RIR (term 0) and the head of the row becomes prev*(fade-n)/fade + cur*n/fade.  One launch, and in the
 // fused kernel the spectrogram is taken from the blended row without it ever leaving the CU.
-template <bool FUSE, bool SIMPLE, bool XFADE = false>
+template <bool FUSE, bool SIMPLE, bool XFADE = false, bool TAB = false>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
+    static_assert(!TAB || SIMPLE, "the unit table serves the loop-free kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
     // grid (2N rows, nb_y output blocks).  (Putting the blocks of a row next to each other in slot order, as k_conv_spec
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     c32 y[8];
     bool any = false;
     if (SIMPLE) {
-        const bool tab = p.tab_n > 0;                       // (kernel argument: wave-uniform)
+        constexpr bool tab = TAB;                           // (an instantiation of its own: no run-time test in either prologue)
         const int ridx = tab ? p.tab[2 * unit] : __builtin_amdgcn_readfirstlane(d[0]);
         bool active = false;
         if (ridx >= 0) {
@@ -1294,8 +1296,9 @@ __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, con
         }
 }
 
-template <bool FUSE, bool SIMPLE>
+template <bool FUSE, bool SIMPLE, bool TAB = false>
 __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
+    static_assert(!TAB || SIMPLE, "the unit table serves the loop-free kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
     // 1-D grid of 2N * nb_y workgroups.  With several output blocks per row (44.1 kHz: 3) the blocks of one row sit NEXT
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const size_t row_f4 = (size_t)p.h_blocks * (kSpecComplex / 2);     // f32x4 per (entry, ear)
     if (SIMPLE) {
         i32x4 dw;
-        if (p.tab_n > 0) dw = i32x4{p.tab[2 * unit], p.tab[2 * unit + 1], 0, 1};    // {index | -1, slot of window 0, m_min, count}
+        if (TAB) dw = i32x4{p.tab[2 * unit], p.tab[2 * unit + 1], 0, 1};            // {index | -1, slot of window 0, m_min, count}
         else dw = uniform_load4(d);
         const int ridx = dw.x;
         if (ridx >= 0) {
