@@ -538,9 +538,11 @@ def main():
                 ctx.observe_prepared(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream)
 
         def fence():
-            if use_ctx:
-                ctx.join()
+            # (torch.cuda.synchronize() is a DEVICE synchronise: it covers the context's internal streams as well; joining
+            # them into the launch stream first only puts two cross-stream hops in front of it)
             if world > 1:
+                if use_ctx:
+                    ctx.join()
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -590,15 +592,15 @@ def main():
             step(k)
             if evs and per_step_events:
                 evs[k - args.warmup + 1].record(streams[0])
-        if use_ctx:
-            ctx.join()                                             # the launch stream waits for both lanes: the closing
-        if evs and not per_step_events:                            # event then covers all of the region's work
-            evs[1].record(streams[0])
+        if use_ctx and lanes == 1:
+            ctx.join()
+        if evs and not per_step_events and not (use_ctx and lanes > 1):   # (overlapped lanes: wall clock only, no closing event:
+            evs[1].record(streams[0])                                      #  it would need the lanes joined into this stream)
         flush()
         fence()
         elapsed = time.perf_counter() - t_start
         per_step = None
-        if evs:
+        if evs and not (use_ctx and lanes > 1):
             per_step = ([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if per_step_events
                         else [evs[0].elapsed_time(evs[1]) / args.steps])
         if world > 1:
