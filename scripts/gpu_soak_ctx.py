@@ -11,14 +11,20 @@ from ss_amd import ops
 from ss_amd.context import AudioContext
 from ss_amd.renderer import BatchedAudioRenderer, RirBank, UnitRequest
 
-dev, sr = "cuda:0", 16000
+dev = "cuda:0"
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 t_start, n_steps, n_units = time.time(), 0, 0
 worst = [0.0]
 for rnd in range(rounds):
     rng = np.random.default_rng(1000 * seed + rnd)
+    sr = 44100 if rnd % 4 == 3 else 16000                       # every fourth round: the fused-rows kernel (k_obs_rows)
+    overlap = rnd % 5 in (1, 2, 4)                              # overlap mode: consecutive steps on two internal lanes
+    t4 = 69 if sr == 44100 else 26
     secs = [1, 1, 1, 2, 4][:int(rng.integers(2, 6))]
+    many_keys = rnd % 3 == 1                                    # dozens of (sound, second) windows against a small cache:
+    if many_keys:                                               # evictions under the in-flight guard, both lane modes
+        secs = [int(x) for x in rng.integers(1, 7, 14)]
     src = [O.synth_sources(rng, sr, k=1, seconds=s)[0] for s in secs]
     n_rir = int(rng.integers(4, 40))
     long_rir = rnd % 3 == 2
@@ -26,12 +32,13 @@ for rnd in range(rounds):
             for _ in range(n_rir)]
     bank = RirBank.from_arrays(rirs, dev)
     r = BatchedAudioRenderer(sr, device=dev)
-    ctx = AudioContext(sr, max_window_sets=int(rng.choice([4, 8, 64])))
+    ctx = AudioContext(sr, max_window_sets=8 if many_keys else int(rng.choice([4, 8, 64])))
     for i, s in enumerate(src):
         r.add_source(f"s{i}", s)
         ctx.add_source(f"s{i}", s)
     r.set_rir_bank(bank)
     ctx.set_rir_bank(bank.data, bank.lengths)
+    ctx.set_overlap(2 if overlap else 1)
     spectral = rnd % 2 == 1
     if spectral:
         spectra = ops.rir_spectra(bank.data)
@@ -44,21 +51,24 @@ for rnd in range(rounds):
         steps, outs = [], []
         torch.cuda.synchronize()
         for k in range(40):
-            n = int(rng.choice([1, 2, 5, 17, 64, 128, 129, 256, 257, 400]))
+            n = int(rng.choice([1, 2, 3, 5] if many_keys else [1, 2, 5, 17, 64, 128, 129, 256, 257, 400] if sr == 16000
+                               else [1, 2, 5, 17, 64, 128, 130]))
             sound = rng.integers(0, len(src), n)
             t0 = np.array([int(rng.integers(0, secs[s])) * sr if secs[s] > 1 else 0 for s in sound])
             rir = rng.integers(-1, n_rir, n)
             cols = dict(sound=sound, t0=t0, rir=rir)
             if distract:
-                cols.update(dis_sound=rng.integers(0, 3, n), dis_rir=np.where(rng.random(n) < 0.7, rng.integers(0, n_rir, n), -1))
+                cols.update(dis_sound=rng.integers(0, min(3, len(src)), n), dis_rir=np.where(rng.random(n) < 0.7, rng.integers(0, n_rir, n), -1))
             if rng.random() < 0.3:
                 which ^= 1
             want_ag = rng.random() < 0.4
-            sg = torch.empty((n, 65, 26, 2), device=dev)
+            sg = torch.empty((n, 65, t4, 2), device=dev)
             ag = torch.empty((n, 2, sr), device=dev) if want_ag else None
             with torch.cuda.stream(streams[which]):
                 ctx.observe(spectrogram_out=sg, audiogoal_out=ag, **cols)
             steps.append(cols); outs.append((sg, ag))
+        if overlap:
+            ctx.join()
         torch.cuda.synchronize()
         for cols, (sg, ag) in zip(steps, outs):
             n = len(cols["sound"])
@@ -79,5 +89,5 @@ for rnd in range(rounds):
                 same(ag, ag2, "audiogoal")
             same(sg, sg2, "spectrogram")
             n_steps += 1; n_units += n
-    print(f"round {rnd}: spectral={spectral} distract={distract} long_rir={long_rir} ok; cache {ctx.stats()}", flush=True)
+    print(f"round {rnd}: sr={sr} overlap={overlap} many_keys={many_keys} spectral={spectral} distract={distract} long_rir={long_rir} ok; cache {ctx.stats()}", flush=True)
 print(f"SOAK OK: {n_steps} steps, {n_units} units, worst non-identical relerr {worst[0]:.2e}, {time.time() - t_start:.1f} s")
