@@ -1,4 +1,7 @@
 #!/bin/bash
+# build the reference library first (here, no GPU needed): check the previous commit out into a scratch worktree and
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I<worktree>/include <worktree>/sound-spaces_amd/csrc/ss_hip.hip -o gpurun_in/libss_hip_old.so
+# (gpurun_in/ is git-ignored and travels to the GPU box with the snapshot)
 # same-box A/B of two builds of libss_hip.so: gpurun_in/libss_hip_old.so (built from the previous commit) vs the in-tree one
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
