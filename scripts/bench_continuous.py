@@ -3,7 +3,7 @@
 from the ray tracer (host memory -> HBM over PCIe), a new sample index (no window-spectrum reuse), 0.25-s steps, CROSSFADE
 with the previous step's RIR - all inside the timed region.  Prints one JSON object.
 
-    python scripts/bench_continuous.py [--envs 128] [--rir-len 16000] [--steps 100]
+    python scripts/bench_continuous.py [--sr 16000|44100] [--envs 128] [--rir-len <sr>] [--steps 100]
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,11 +14,13 @@ from ss_amd.context import AudioContext
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=128)
-ap.add_argument("--rir-len", type=int, default=16000)
+ap.add_argument("--sr", type=int, default=16000, help="44100 = the reference's Replica rate (k_obs_rows, one launch per step)")
+ap.add_argument("--rir-len", type=int, default=0, help="taps of the live RIRs (default: one second)")
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=40)
 a = ap.parse_args()
-sr, N, L = 16000, a.envs, a.rir_len
+sr, N, L = a.sr, a.envs, a.rir_len or a.sr
+from ss_amd.planning import spectrogram_shape
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 ctx = AudioContext(sr, step_time=0.25, wrap=True, max_window_sets=8 * N)
@@ -37,9 +39,9 @@ pool = torch.from_numpy(O.synth_rir(rng, sr, length=L, n=64))                   
 stage = [torch.zeros((N, 2, cap), dtype=torch.float32).pin_memory() for _ in range(8)]
 for b in stage:
     b[:, :, :L] = pool[torch.from_numpy(rng.integers(0, 64, N))]
-sg = [torch.empty((N, 65, 26, 2), dtype=torch.float32, device=dev) for _ in range(3)]
+sg = [torch.empty((N,) + spectrogram_shape(sr), dtype=torch.float32, device=dev) for _ in range(3)]
 sound = rng.integers(0, 16, N)
-idx = rng.integers(0, 4000, N)
+idx = rng.integers(0, sr // 4, N)
 total = a.warmup + a.steps
 picks = rng.integers(0, 64, (total, N))
 copy_stream = torch.cuda.Stream()
@@ -68,7 +70,7 @@ def step(k, host_us=None):
     wrap = (idx - L >= 0).astype(np.uint8)
     ctx.observe(sound, idx, cur, spectrogram_out=sg[par], last_rir=last, wrap=wrap, last_wrap=wrap)
     done[par].record(torch.cuda.current_stream())
-    idx = (idx + 4000) % (3 * sr)                                                  # continuous_simulator.py:389-390
+    idx = (idx + sr // 4) % (3 * sr)                                                  # continuous_simulator.py:389-390
     if host_us is not None:
         host_us.append(1e6 * (time.perf_counter() - t0))
         tracer_us.append(1e6 * (t1 - t0))
@@ -83,7 +85,7 @@ for k in range(a.warmup, total):
     step(k, host)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"workload": f"SS2.0: {N} envs, 0.25-s steps, live {L}-tap RIRs uploaded per step (pinned H2D), CROSSFADE, "
+print(json.dumps({"workload": f"SS2.0 @{sr} Hz: {N} envs, 0.25-s steps, live {L}-tap RIRs uploaded per step (pinned H2D), CROSSFADE, "
                               "new sample index per step (one source-window FFT per env and step)",
                   "env_steps_per_s": round(N * a.steps / dt, 1), "ms_per_step": round(1e3 * dt / a.steps, 4),
                   "host_us_per_step": {"median": round(float(np.median(host)), 1), "mean": round(float(np.mean(host)), 1),

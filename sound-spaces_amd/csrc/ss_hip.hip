@@ -135,10 +135,15 @@ int get_stash(hipStream_t st, size_t bytes, float** out) {
     return 0;
 }
 
-// can k_obs_rows serve this shape?  (rows of 2 or 3 blocks, no cross-fade, stash mask of 32 bits)
-inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags) {
-    return out_len > ssk::kB && out_len <= 3 * ssk::kB && n_valid <= out_len && !(flags & SS_FLAG_CROSSFADE) &&
-           nbh_max >= 1 && nbh_max <= 16;
+// should k_obs_rows serve this shape?  (rows of 2 or 3 blocks, stash mask of 32 bits.)  Cross-faded rows: only when the
+// caller has no waveform buffer (time-domain bank, ramp inside what the kernel parks of block 0) - with one, the loop
+// kernel + k_spectrogram (told where the zeros of a short step begin) is 20 % faster: 92.7 vs 117.8 us per 128 units at
+// 44.1 kHz (the rows kernel renders block 0 twice through its stash; profiles/r3/NOTES.md section 8)
+inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags, bool spectral = false, bool have_waveform_buffer = false) {
+    if ((flags & SS_FLAG_CROSSFADE) && have_waveform_buffer) return false;
+    if ((flags & SS_FLAG_CROSSFADE) &&
+        (spectral || static_cast<int>(0.05 * out_len) < 1 || static_cast<int>(0.05 * out_len) > 2 * ssk::kPrevPairs - 2)) return false;
+    return out_len > ssk::kB && out_len <= 3 * ssk::kB && n_valid <= out_len && nbh_max >= 1 && nbh_max <= 16;
 }
 
 template <bool SPECTRAL>
@@ -150,6 +155,8 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
     p.stash_nbh = 0;
     p.stash_terms = 0;
     p.n_terms = (flags & SS_FLAG_NO_DISTRACTOR) ? 1 : 2;
+    const bool xfade = (flags & SS_FLAG_CROSSFADE) != 0;
+    if (xfade && (SPECTRAL || p.n_terms != 2)) return SS_EINVAL;
     // Time-domain bank: the kernel transforms every RIR block once per row and keeps the spectra that are needed again
     // in a per-workgroup stash (k_obs_rows); 44.1 kHz: 2 x 128 KiB written and 3 x 128 KiB read back per row.
     if (!SPECTRAL) {
@@ -162,6 +169,12 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
         int rc = get_stash(st, per_wg * static_cast<size_t>(grid), &buf);
         if (rc) return rc;
         p.stash = reinterpret_cast<ssk::f32x4*>(buf);
+    }
+    if constexpr (!SPECTRAL) {
+        if (xfade) {
+            hipLaunchKernelGGL((ssk::k_obs_rows<false, true>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
+            return hip_err(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
     return hip_err(hipGetLastError());
@@ -279,7 +292,14 @@ int ss_fftconv_binaural_f32(const float* spec, const float* rir, const int* rir_
     return launch_conv<false>(p, n_units, nb_y, flags, n_cus, static_cast<hipStream_t>(stream));
 }
 
+// n_valid: samples from n_valid on are KNOWN to be zero (rows this library rendered itself); len: nothing known
+static int spectrogram_of_rows(const float* x, float* out, int n_units, int len, int n_valid, int pad_mode, void* stream);
+
 int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad_mode, void* stream) {
+    return spectrogram_of_rows(x, out, n_units, len, len, pad_mode, stream);
+}
+
+static int spectrogram_of_rows(const float* x, float* out, int n_units, int len, int n_valid, int pad_mode, void* stream) {
     if (n_units == 0) return 0;
     if (!x || !out || n_units < 0 || len < ssk::kNfft / 2 + 1) return SS_EINVAL;   // reflect pad needs len > 256
     if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
@@ -292,6 +312,7 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
     p.n_frames = n_frames_of(len);
     p.t4 = t4_of(len);
     p.pad_mode = pad_mode;
+    p.live = ssk::live_blocks(n_valid, len, p.t4);
     const int groups = (p.t4 + 3) / 4;                      // 4 pooled time blocks x 2 ears per round of a workgroup
     // large batches: one workgroup walks several groups (tables staged once, next segment prefetched under the math);
     // small batches keep one group per workgroup so that the launch still fills 256 CUs x 2 workgroups
@@ -375,7 +396,7 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
         p.sgram = spectrogram;
         return launch_conv<true>(p, n_units, 1, flags, n_cus, static_cast<hipStream_t>(stream));
     }
-    if (obs_rows_ok(out_len, n_valid, (rir_cap + ssk::kB - 1) / ssk::kB, flags)) {   // rows of 2-3 blocks: fused as well
+    if (obs_rows_ok(out_len, n_valid, (rir_cap + ssk::kB - 1) / ssk::kB, flags, false, audiogoal != nullptr)) {   // rows of 2-3 blocks: fused as well
         p.out = audiogoal;
         p.sgram = spectrogram;
         return launch_obs_rows<false>(p, n_units, flags, n_cus, static_cast<hipStream_t>(stream));
@@ -384,7 +405,7 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
     rc = ss_fftconv_binaural_f32(spec, rir, rir_len, unit_desc, audiogoal, n_units, rir_unit_stride,
                                  rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, flags, stream);
     if (rc) return rc;
-    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+    return spectrogram_of_rows(audiogoal, spectrogram, n_units, out_len, n_valid, pad_mode, stream);
 }
 
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream) {
@@ -507,7 +528,7 @@ int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_
         p.sgram = spectrogram;
         return launch_conv_spec<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
     }
-    if (obs_rows_ok(out_len, n_valid, h_blocks, flags)) {
+    if (obs_rows_ok(out_len, n_valid, h_blocks, flags, true, audiogoal != nullptr)) {
         p.out = audiogoal;
         p.sgram = spectrogram;
         return launch_obs_rows<true>(p, n_units, flags, n_cus, static_cast<hipStream_t>(stream));
@@ -516,7 +537,7 @@ int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_
     rc = ss_fftconv_binaural_spec_f32(spec, hspec, rir_len, unit_desc, audiogoal, n_units, h_blocks, n_valid, out_len,
                                       flags, stream);
     if (rc) return rc;
-    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+    return spectrogram_of_rows(audiogoal, spectrogram, n_units, out_len, n_valid, pad_mode, stream);
 }
 
 // ---- context API (include/ss_hip.h): planner + window-spectra cache + descriptor ring inside the library --------------
@@ -841,9 +862,10 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return fail(hip_err(e));
     }
-    const int nbh_bank = c.hspec ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
+    const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);       // (cross-faded steps take the time-domain rows)
+    const int nbh_bank = spectral ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
     if (spectrogram && !audiogoal && c.out_len > ssk::kB &&
-        !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags)) {  // only cross-faded long rows still hand over through memory
+        !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags, spectral, true)) {  // cross-faded / very long rows hand over through memory (the context's own buffer)
         const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
         if (need > c.ag_cap) {
             e = hipDeviceSynchronize();
@@ -856,7 +878,6 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         }
         audiogoal = c.ag_scratch;
     }
-    const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);
     static const bool no_tab = std::getenv("SS_HIP_NO_UNIT_TAB") != nullptr;         // A/B switch for benchmarking
     g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
     if (!c.buckets.empty()) {
@@ -1101,7 +1122,7 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
         p.sgram = spectrogram;
         return spectral ? launch_conv_spec<true>(p, n_units, 1, flags, st) : launch_conv<true>(p, n_units, 1, flags, n_cus, st);
     }
-    if (obs_rows_ok(out_len, n_valid, nbh_max, flags)) {
+    if (obs_rows_ok(out_len, n_valid, nbh_max, flags, spectral, audiogoal != nullptr)) {
         p.out = audiogoal;
         p.sgram = spectrogram;
         return spectral ? launch_obs_rows<true>(p, n_units, flags, n_cus, st) : launch_obs_rows<false>(p, n_units, flags, n_cus, st);
@@ -1110,7 +1131,7 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
     rc = ss_fftconv_binaural_buckets_f32(spec, buckets, n_buckets, rir_len, unit_desc, audiogoal, n_units, n_valid, out_len,
                                          flags, stream);
     if (rc) return rc;
-    return ss_spectrogram_f32(audiogoal, spectrogram, n_units, out_len, pad_mode, stream);
+    return spectrogram_of_rows(audiogoal, spectrogram, n_units, out_len, n_valid, pad_mode, stream);
 }
 
 // The context's bank as length buckets (replaces ss_ctx_set_rir_bank + ss_ctx_set_rir_spectra for such banks; borrowed

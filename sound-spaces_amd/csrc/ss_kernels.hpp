@@ -337,7 +337,17 @@ struct SpecParams {
     Tables tb;
     int len, n_frames, t4, pad_mode;
     int gpw;              // groups (of 4 pooled time blocks) handled per workgroup
-};
+    int live;             // pooled blocks >= live are KNOWN to be zero (rows rendered up to n_valid < len: see live_blocks);
+};                        // t4 when nothing is known about the rows
+
+// pooled time blocks that can be non-zero when a row of `len` samples is zero from sample n_valid on: block b is exactly
+// zero once all of its frames start behind the rendered samples (640 b - 256 >= n_valid) - provided the right centre
+// padding mirrors zeros as well (n_valid <= len - 512); |STFT| of zeros is 0 and log1p(0) = 0
+__host__ __device__ constexpr int live_blocks(int n_valid, int len, int t4) {
+    return n_valid <= len - kNfft ? ((n_valid + kNfft / 2 + kHop * kPool - 1) / (kHop * kPool) < t4
+                                         ? (n_valid + kNfft / 2 + kHop * kPool - 1) / (kHop * kPool) : t4)
+                                  : t4;
+}
 
 // stand-alone spectrogram: 512 threads = 8 waves = {ear 0, ear 1} x 4 consecutive pooled time blocks of one unit.
 // (Ablation of the previous one-wave-per-block layout, profiles/r1/NOTES.md: 58 of 200 us were the per-lane frame
@@ -402,7 +412,17 @@ __global__ __launch_bounds__(512) void k_spectrogram(SpecParams p) {
     __shared__ c32 s_tw512[kTw512Lds];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int groups = (p.t4 + 3) >> 2, chunks = (groups + p.gpw - 1) / p.gpw;
-    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
+    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1_all = min(groups, g0 + p.gpw);
+    // groups whose four pooled blocks are all known to be zero are written, not computed (SS2.0 steps: 0.25 s of a 1-s row)
+    const int g1 = min(g1_all, (p.live + 3) >> 2);
+    for (int g = max(g0, g1); g < g1_all; ++g) {
+        if (t < kBins4 * 4) {
+            const int b = t >> 2, c2 = t & 3;
+            if (4 * g + c2 < p.t4)
+                *reinterpret_cast<c32*>(p.out + ((size_t)unit * kBins4 + b) * p.t4 * 2 + 8 * g + 2 * c2) = mk2(0.f, 0.f);
+        }
+    }
+    if (g0 >= g1) return;                                   // (workgroup-uniform, before any barrier)
     const int ch = wv >> 2, tbl = wv & 3;                   // this wave: ear, local pooled block
     const float* row0 = p.x + (size_t)unit * 2 * p.len;
     f32x4* seg4 = reinterpret_cast<f32x4*>(sc);             // seg[c][i] = padded y_c[160*16*g - 256 + i]
@@ -1063,15 +1083,18 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     // registers; after one barrier the row is dead and each wave runs its two blocks back to back in its private
     // scratch with wave-scope synchronisation only (no workgroup barrier, waves free-running).
     c32 x0[16], x1[16];
-    const bool two = wv + 16 < p.t4;
+    // Short steps (SS2.0: 0.25 s of a 1-s row): pooled blocks that are exactly zero (live_blocks) are written, not computed
+    // (16 kHz, 0.25 s: 7 live blocks of 26).  live == t4 otherwise.
+    const int live = live_blocks(p.n_valid, len, p.t4);
+    const bool one = wv < live, two = wv + 16 < live;
     const float* padded = reinterpret_cast<const float*>(lds);   // frame tf = floats [160 tf, 160 tf + 512)
-    stft_load_padded(padded, 4 * wv + (lane >> 4), wv < p.t4 ? p.n_frames : 0, lane & 15, s_win, x0);
+    stft_load_padded(padded, 4 * wv + (lane >> 4), one ? p.n_frames : 0, lane & 15, s_win, x0);
     stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
     lds_barrier();
     // The pooled values of this ear are collected in LDS and leave together: written straight from the blocks, lane r
     // stores row r of out[unit][r][block][ear] - 64 lanes, 64 different cache lines, 4 bytes each, 26 times per workgroup.
-    // From s_res, consecutive threads write consecutive (row, block) elements: every other float of a contiguous range.
-    if (wv < p.t4)
+    // From s_res, 32 threads per pooled row write its blocks: every other float of a contiguous range.
+    if (one)
         stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * p.t4 + wv] = v; });
     if (two) {
         wave_sync();
@@ -1079,7 +1102,9 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     }
     lds_barrier();
     float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
-    for (int e = t; e < kBins4 * p.t4; e += kT) o[2 * e] = s_res[e];
+    const int k = t & 31;                                   // (t4 <= 26 on this path)
+    if (k < p.t4)
+        for (int b = t >> 5; b < kBins4; b += kT / 32) o[2 * (b * p.t4 + k)] = k < live ? s_res[b * p.t4 + k] : 0.f;
 }
 
 // SIMPLE: the caller guarantees one output block (nb_y == 1), RIR capacity <= kB and no distractor term,
@@ -1670,8 +1695,10 @@ __global__ __launch_bounds__(1024) void k_conv_spec_rows(ConvParams p, int n_row
 //     right padding, and the pooled blocks run exactly as in the one-block kernels (fused_stft_phase): two rounds of
 //     16 waves, wave-private scratch overlaying the row buffer.
 // Unit descriptors, silent units, distractor term, n_valid < out_len (0.25-s SS2.0 steps: blocks beyond n_valid are
-// zeros without any transform) as in k_conv.  SS_FLAG_CROSSFADE is not served here (the launcher keeps the two-kernel
-// path for cross-faded rows longer than one block).
+// zeros without any transform) as in k_conv.  SS_FLAG_CROSSFADE (XFADE instantiation, time-domain bank; continuous_simulator.py:47-53,
+// 422-424): term 1 is the previous step's RIR and only shapes samples 0..fade_len, all in block 0 - block 0 is rendered
+// twice, first from term 1's pairs alone (its head parks in LDS, in the space s_res / s_tail do not use before the
+// block's STFT phase), then from term 0's, and blended exactly as in k_conv<XFADE>; later blocks see term 0 only.
 // timing ablations (scripts/gpu_rows_ladder.sh builds with -DSS_ROWS_ABL=<mask>; results are WRONG, only the time is read):
 //   1 no STFT phase   2 no products from memory   4 no window-spectrum loads   8 no forward passes 2-3   16 no inverse passes
 #if defined(SS_ROWS_ABL)
@@ -1781,13 +1808,19 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     }
 }
 
-template <bool SPECTRAL>
+template <bool SPECTRAL, bool XFADE = false>
 __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
+    static_assert(!(SPECTRAL && XFADE), "cross-faded rows are rendered from the time-domain bank");
     __shared__ c32 lds[16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     __shared__ float s_win[kNfft];
     __shared__ c32 s_tw512[kTw512Lds];
-    __shared__ float s_res[kRowsResFloats];
-    __shared__ float s_tail[kTailFloats];
+    // pooled results of an STFT phase | context handed from block j to j+1; before block 0's STFT phase both are free and
+    // hold the head of the cross-faded row convolved with the previous RIR (kPrevPairs packed pairs)
+    __shared__ __attribute__((aligned(8))) float s_rt[kRowsResFloats + kTailFloats + 1];
+    static_assert((kRowsResFloats + kTailFloats) * sizeof(float) >= kPrevPairs * sizeof(c32), "s_prev overlay");
+    float* s_res = s_rt;
+    float* s_tail = s_rt + kRowsResFloats + (kRowsResFloats & 1);        // (even offset: 8-byte aligned packed reads)
+    c32* s_prev = reinterpret_cast<c32*>(s_rt);
     const int t = threadIdx.x;
     ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
     {   // the STFT's tables, staged once per workgroup (unconditional clamped loads: see k_conv)
@@ -1858,6 +1891,12 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                     if (i_hi >= i_lo) want |= (((2u << i_hi) - 1u) & ~((1u << i_lo) - 1u)) << (16 * term);
                 }
             }
+            // cross-fade: block 0 twice - round 0 from the previous RIR's pairs (term 1), round 1 from the current one's;
+            // the previous RIR plays no part in later blocks
+            const bool xf = XFADE && dws[1].x >= 0;       // (an instantiation of its own: the plain rows pay nothing for it)
+            const unsigned want_all = (xf && j > 0) ? (want & 0xffffu) : want;
+            for (int round = (xf && j == 0) ? 0 : 1; round < 2; ++round) {
+            want = (xf && j == 0) ? (round == 0 ? (want_all & 0xffff0000u) : (want_all & 0xffffu)) : want_all;
             unsigned fresh = want & ~in_mem;              // pairs whose forward FFT has to run now
             if (want) {
                 // ---- 1. every new pair but the last: forward FFT -> stash
@@ -1954,16 +1993,53 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
 #pragma unroll
                 for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
             }
+            if (xf && j == 0) {
+                if (round == 0) {                         // head of the row through the previous RIR: own slots, no barrier
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if (tl + 1024 * a < kPrevPairs) s_prev[tl + 1024 * a] = y[a];
+                    lds_barrier();                        // pass-1' reads of the buffer are over before round 1 writes it
+                } else {
+                    // crossfade(): x1[:, :n+1] * flip(arange(n+1)/n) + x2[:, :n+1] * (arange(n+1)/n), n = fade_len
+                    const float fl = (float)p.fade_len;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const int m = tl + 1024 * a, n0 = 2 * m;
+                        if (n0 <= p.fade_len) {
+                            const c32 yp = s_prev[m];
+                            y[a].x = yp.x * ((float)(p.fade_len - n0) / fl) + y[a].x * ((float)n0 / fl);
+                            if (n0 + 1 <= p.fade_len)
+                                y[a].y = yp.y * ((float)(p.fade_len - n0 - 1) / fl) + y[a].y * ((float)(n0 + 1) / fl);
+                        }
+                    }
+                }
+            }
+            }                                             // round
             int row_j = row;                              // (output addresses are rebuilt per block, in scalar registers:
             SSK_OPAQUE_S(row_j);                          //  hoisted out of the j loop they lived in VGPRs and spilled)
             if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row_j, j, y);
             const bool last = j == nb_rows - 1;
             const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
+            // Short steps (SS2.0: 0.25 s of a 1-s row): pooled blocks that are exactly zero (live_blocks) are written, not
+            // computed (at 44.1 kHz a 0.25-s step has 18 live pooled blocks of 69; the other 51 were three quarters of the STFT work).
+            const int b_zero = live_blocks(p.n_valid, p.out_len, p.t4);
+            const int b1c = min(b1, max(b0, b_zero));     // [b0, b1c) computed, [b1c, b1) zero
             if (kRowsAbl & 1) {
                 if (y[0].x == 123.456f) p.sgram[0] = y[7].y;      // keeps the convolution alive
                 lds_barrier();
-            } else
-            rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1, last, y, s_win, s_tw512, s_wq, s_res, s_tail);
+            } else if (b1c > b0) {
+                rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1c, last && b1c == b1, y, s_win, s_tw512, s_wq, s_res, s_tail);
+            } else {
+                lds_barrier();                            // (the phase's entry barrier: pass-1' reads of the buffer are over)
+            }
+            if (b1c < b1) {
+                float* o = p.sgram + ((size_t)(row_j >> 1) * kBins4 * p.t4) * 2 + (row_j & 1);
+                const int nz = b1 - b1c;
+                for (int e = tl; e < kBins4 * nz; e += kT) {
+                    const int b = e / nz, k = b1c + (e - b * nz);
+                    o[((size_t)b * p.t4 + k) * 2] = 0.f;
+                }
+            }
             b0 = b1;
         }
         lds_barrier();                                    // s_res / the scratches are reused by the next row

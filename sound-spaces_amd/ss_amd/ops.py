@@ -143,8 +143,8 @@ def gccphat(x: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="ref
 
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
                    pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
-    """Fused observation.  ``audiogoal`` may be None (the waveform then never leaves the CU) unless the rows are longer
-    than one partition block AND cross-faded (SS_FLAG_CROSSFADE) - the one shape that still runs as two kernels."""
+    """Fused observation.  ``audiogoal`` may be None (the waveform then never leaves the CU).  Cross-faded rows longer
+    than one partition block run as two launches when a buffer is given (faster), as one without."""
     _chk(spec, torch.float32, "spec"); _chk(rir_bank, torch.float32, "rir_bank"); _chk(rir_len, torch.int32, "rir_len")
     _chk(unit_desc, torch.int32, "unit_desc"); _chk(spectrogram_out, torch.float32, "spectrogram_out")
     N = unit_desc.shape[0]

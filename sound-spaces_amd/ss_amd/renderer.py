@@ -360,8 +360,9 @@ class BatchedAudioRenderer:
     # ---- rendering ---------------------------------------------------------------------------------------
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
-        """One launch on the current stream (two only for cross-faded rows longer than one partition block, which hand
-        the waveform over through memory).  Returns (audiogoal [N,2,sr] or None, spectrogram [N,65,T4,2])."""
+        """One launch on the current stream; two - convolution, then spectrogram, the waveform handed over through memory -
+        for cross-faded rows longer than one partition block (measured faster than the one-launch form the library
+        falls back to without a buffer) and rows longer than three.  Returns (audiogoal [N,2,sr] or None, spectrogram)."""
         N = len(plan)
         need_ag = (want_audiogoal or audiogoal_out is not None or
                    (self.out_len > P.KB and (bool(plan.flags & ops.FLAG_CROSSFADE) or self.out_len > 3 * P.KB)))

@@ -233,6 +233,14 @@ def main():
         add(f"cont_{name}_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, rir_seed=15, rir_len=20000, rir_n=1,
             rir_sel=0, sample_index=si, step_time=0.25)
 
+    # ---- ... and cross-faded (round 3, late: k_obs_rows renders block 0 twice and blends on the CU): previous RIR = the
+    # bank's second entry, ramp of int(0.05 * 44100) + 1 = 2206 samples
+    rc44x = O.synth_rir(np.random.default_rng(16), sr2, length=20000, n=2)
+    y = run_cont(sr2, src3_44, wav_layout(rc44x[0]), 50000, last_rir=wav_layout(rc44x[1]).astype(np.float64),
+                 use_crossfade=True)
+    add("cont_crossfade_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, rir_seed=16, rir_len=20000, rir_n=2, rir_sel=0,
+        last_rir_sel=1, sample_index=50000, step_time=0.25)
+
     # ---- early branch running past the clip end (:433-437): a 3.1-s RIR (irTime allows up to 4 s), index < L, and
     # index + num_sample > len(source): the slice source[:index+num_sample] just ends, i.e. ZEROS past the clip end,
     # not the wrap-around of the steady branch

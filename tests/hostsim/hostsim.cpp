@@ -94,6 +94,7 @@ ssk::Tables host_tables() {
 }  // namespace
 
 // a second length bucket for the next hs_conv / hs_obs_rows call (cleared by it): entries >= first live in `rir` [n,2,cap]
+static int g_spec_n_valid = -1;
 static const float* g_b2_rir = nullptr;
 static int g_b2_first = 0, g_b2_cap = 0;
 static void apply_bucket2(ssk::ConvParams& p) {
@@ -122,6 +123,8 @@ float hostsim_lane_read(float v, int src_lane) {
 extern "C" {
 
 void hs_set_bucket2(const float* rir, int first, int cap) { g_b2_rir = rir; g_b2_first = first; g_b2_cap = cap; }
+// the next hs_spectrogram call: rows are known to be zero from sample n_valid on (the library's own two-launch path)
+void hs_set_spec_n_valid(int n_valid) { g_spec_n_valid = n_valid; }
 
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
@@ -253,7 +256,7 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
 // k_obs_rows: `wgs` persistent workgroups walk the (unit, ear) rows; hspec != nullptr selects the spectral-bank variant
 int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const int* rir_len, const int* desc, float* out,
                 float* sgram, int n_units, long long us, int cs, int es, int cap, int h_blocks, int n_valid, int out_len,
-                int pad_mode, int wgs, int no_distractor, int use_stash) {
+                int pad_mode, int wgs, int no_distractor, int use_stash, int crossfade) {
     if (out_len <= ssk::kB || out_len > 3 * ssk::kB || !sgram) return -1;
     ssk::ConvParams p;
     p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
@@ -263,7 +266,8 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     p.n_frames = 1 + out_len / ssk::kHop;
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
-    p.fade_len = 0;
+    p.fade_len = static_cast<int>(0.05 * out_len);
+    if (crossfade && (hspec || no_distractor || p.fade_len > 2 * ssk::kPrevPairs - 2)) return -2;
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec); p.h_blocks = h_blocks; p.xcd_map = wgs >= 8;
     p.nb_y = n_valid == 0 ? 0 : (n_valid + ssk::kB - 1) / ssk::kB;
     p.n_terms = no_distractor ? 1 : 2;
@@ -283,7 +287,9 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     for (int b = 0; b < grid; ++b) {
         blockIdx = dim3{(unsigned)b, 0, 0};
         int rc = run_block(ssk::kT, [&] {
-            if (hspec) ssk::k_obs_rows<true>(p, n_rows); else ssk::k_obs_rows<false>(p, n_rows);
+            if (hspec) ssk::k_obs_rows<true>(p, n_rows);
+            else if (crossfade) ssk::k_obs_rows<false, true>(p, n_rows);
+            else ssk::k_obs_rows<false>(p, n_rows);
         });
         if (rc) return rc;
     }
@@ -294,6 +300,8 @@ int hs_spectrogram(const float* x, float* out, int n_units, int len, int pad_mod
     ssk::SpecParams p;
     p.x = x; p.out = out; p.tb = host_tables();
     p.len = len; p.n_frames = 1 + len / ssk::kHop; p.t4 = (p.n_frames + 3) / 4; p.pad_mode = pad_mode;
+    p.live = g_spec_n_valid >= 0 ? ssk::live_blocks(g_spec_n_valid, len, p.t4) : p.t4;
+    g_spec_n_valid = -1;
     const int groups = (p.t4 + 3) / 4;
     p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
     const int chunks = (groups + p.gpw - 1) / p.gpw;

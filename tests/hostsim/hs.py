@@ -98,7 +98,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     if crossfade:
         simple = 2
     if row_wgs:                                          # k_obs_rows: fused rows of 2-3 blocks, `row_wgs` persistent workgroups
-        assert not crossfade and out_len > P.KB
+        assert out_len > P.KB and not (crossfade and spectral)
         hb, hspec = 0, None
         if spectral:
             assert not interleaved
@@ -109,7 +109,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         rc = L.hs_obs_rows(_p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(hspec, ctypes.c_float) if spectral else None,
                            _p(rl, ctypes.c_int), _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
                            _p(sg, ctypes.c_float), int(N), ctypes.c_longlong(us), int(cs), int(es), int(cap), int(hb), int(n_valid),
-                           int(out_len), int(pad_mode), int(row_wgs), int(no_dis), int(row_stash))
+                           int(out_len), int(pad_mode), int(row_wgs), int(no_dis and not crossfade), int(row_stash), int(crossfade))
         assert rc == 0, rc
         return (out if want_audiogoal else None), sg
     if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)
@@ -123,6 +123,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
                             N, hb, n_valid, out_len, pad_mode, persist)
         assert rc == 0, rc
         if want_spectrogram and not fuse:
+            L.hs_set_spec_n_valid(int(n_valid))             # (as the library's two-launch path: rows known zero from n_valid on)
             rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
             assert rc == 0, rc
         return out, (sg if (fuse or want_spectrogram) else None)
@@ -131,6 +132,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
                    N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len, pad_mode, persist)
     assert rc == 0, rc
     if want_spectrogram and not fuse:
+        L.hs_set_spec_n_valid(int(n_valid))
         rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
         assert rc == 0, rc
     return out, (sg if (fuse or want_spectrogram) else None)

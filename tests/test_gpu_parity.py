@@ -1089,3 +1089,75 @@ def test_continuous_steps_at_44k_one_launch(name):
     assert not ag[0][:, int(sr * d["step_time"]):].any()
     check(ag[0][:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step_time,len_prev,sample_index", [(0.25, 20000, 50000), (0.25, 40000, 9000), (1.0, 30000, 70000)])
+def test_crossfaded_rows_at_44k_both_forms(step_time, len_prev, sample_index):
+    """SS2.0 CROSSFADE at the reference's Replica rate (continuous_simulator.py:47-53, 413-426) against the oracle: the
+    two-launch form the renderer and the context use (loop kernel, k_spectrogram told where a short step's zeros begin)
+    and the ONE-launch form of ss_audio_obs_f32 without a waveform buffer (k_obs_rows<XFADE>); previous RIR of 1-3
+    blocks in either branch; a unit without a previous RIR in the same launch."""
+    from ss_amd import ops
+    from ss_amd.renderer import UnitRequest
+    from ss_amd.context import AudioContext
+    sr = 44100
+    rng = np.random.default_rng(77)
+    src3 = O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=1)[0], sr)
+    cur = np.ascontiguousarray(O.synth_rir(rng, sr, length=20000, n=1)[0].T)
+    prev = np.ascontiguousarray(O.synth_rir(rng, sr, length=len_prev, n=1)[0].T)
+    r = make_renderer(sr, [src3], [cur, prev], step_time=step_time, wrap=True)
+    wrap_cur, wrap_prev = sample_index - 20000 >= 0, sample_index - len_prev >= 0
+    units = [UnitRequest(0, sample_index, 0, wrap=wrap_cur, last_rir=1, last_wrap=wrap_prev),
+             UnitRequest(0, sample_index, 0, wrap=wrap_cur)]
+    ref = O.compute_audiogoal_continuous(src3, cur, sr, sample_index, step_time, last_rir=prev, use_crossfade=True)
+    plain = O.convolve_with_rir(src3, cur, sr, sample_index, step_time)
+    ref_s, plain_s = O.compute_spectrogram(ref.astype(np.float32)), O.compute_spectrogram(plain.astype(np.float32))
+    none, sg = r.render_crossfaded(units, want_audiogoal=False)
+    assert none is None
+    check(sg[0].cpu().numpy(), ref_s)
+    check(sg[1].cpu().numpy(), plain_s)
+    plan = r.plan(units)
+    sg1 = torch.full_like(sg, float("nan"))                              # one launch, no waveform anywhere
+    ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg1, r.n_valid, r.out_len, r.pad_mode,
+                       flags=plan.flags)
+    check(sg1[0].cpu().numpy(), ref_s)
+    check(sg1[1].cpu().numpy(), plain_s)
+    ag, sg2 = r.render_crossfaded(units, want_audiogoal=True)
+    check(ag[0].cpu().numpy(), ref)
+    check(ag[1].cpu().numpy(), plain)
+    assert torch.equal(sg, sg2)
+    n = int(0.05 * sr)
+    assert torch.equal(ag[0][:, n + 1:], ag[1][:, n + 1:])                # beyond the ramp: the current RIR alone
+    # context API: the same step from unit columns
+    ctx = AudioContext(sr, step_time=step_time, wrap=True)
+    ctx.add_source("s", src3)
+    ctx.set_rir_bank(r.rirs.data, r.rirs.lengths)
+    sg3 = torch.empty_like(sg)
+    ctx.observe(np.array([0, 0]), np.array([sample_index] * 2), np.array([0, 0]), spectrogram_out=sg3,
+                last_rir=np.array([1, -1]), wrap=np.array([wrap_cur] * 2, np.uint8),
+                last_wrap=np.array([wrap_prev, False], np.uint8))
+    torch.cuda.synchronize()
+    check(sg3[0].cpu().numpy(), ref_s)
+    check(sg3[1].cpu().numpy(), plain_s)
+
+
+@pytest.mark.gpu
+def test_crossfade_44k_reference_run_vector_both_forms():
+    """cont_crossfade_44k (the reference's own _compute_audiogoal with CROSSFADE on, 44.1 kHz): renderer (two launches) and
+    ss_audio_obs_f32 without a waveform buffer (k_obs_rows<XFADE>, one launch)."""
+    from ss_amd.renderer import UnitRequest
+    d = case_inputs("cont_crossfade_44k")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("cont_crossfade_44k")
+    r = make_renderer(sr, [O.tile_short_source(d["source"], sr)], [d["rir"], d["last_rir"]], step_time=d["step_time"], wrap=True)
+    u = [UnitRequest(0, d["sample_index"], 0, wrap=True, last_rir=1, last_wrap=True)]
+    from ss_amd import ops
+    ag, sg = r.render_crossfaded(u, want_audiogoal=True)
+    check(ag[0].cpu().numpy()[:, ::stride], ref_a)
+    check(sg[0].cpu().numpy(), ref_s)
+    plan = r.plan(u)
+    sg1 = torch.full_like(sg, float("nan"))                              # k_obs_rows<XFADE>: one launch, no waveform
+    ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg1, r.n_valid, r.out_len, r.pad_mode,
+                       flags=plan.flags)
+    check(sg1[0].cpu().numpy(), ref_s)

@@ -542,3 +542,74 @@ def test_fused_rows_four_second_rir_eleven_blocks():
     ref = O.convolve_with_rir(src, rir_wav, sr, 200000, 0.25)
     check(out[0], ref)
     check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
+
+
+@pytest.mark.parametrize("step_time,len_prev,sample_index", [(0.25, 20000, 50000), (0.25, 40000, 9000), (1.0, 30000, 70000)])
+def test_fused_rows_crossfade_at_44k(step_time, len_prev, sample_index):
+    """SS_FLAG_CROSSFADE in k_obs_rows (continuous_simulator.py:47-53, 413-426 at the reference's Replica rate): block 0 is
+    rendered twice - previous RIR (term 1), then current - and blended over int(0.05 sr) + 1 samples; a 1-s step (three
+    rendered blocks) keeps the previous RIR out of blocks 1-2; a 40000-tap previous RIR (3 RIR blocks, early branch: it is
+    longer than the sample index) against a 20000-tap current one (steady); a unit without a previous RIR in the same launch."""
+    sr = 44100
+    rng = np.random.default_rng(77)
+    src3 = O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=1)[0], sr)
+    cur = np.ascontiguousarray(O.synth_rir(rng, sr, length=20000, n=1)[0].T)
+    prev = np.ascontiguousarray(O.synth_rir(rng, sr, length=len_prev, n=1)[0].T)
+    ns = int(sr * step_time)
+    cap = max(20000, len_prev)
+    bank = np.concatenate([planar(cur, cap), planar(prev, cap)])
+    wrap_cur, wrap_prev = sample_index - 20000 >= 0, sample_index - len_prev >= 0
+    t0 = P.window_start_continuous(sample_index)
+    units = [dict(sound=0, t0=t0, rir=0, wrap=wrap_cur, last_rir=1, last_wrap=wrap_prev), dict(sound=0, t0=t0, rir=0, wrap=wrap_cur)]
+    out, sg = hs.run([src3], bank, [20000, len_prev], units, ns, sr, crossfade=True, row_wgs=3, want_spectrogram=True)
+    ref = O.compute_audiogoal_continuous(src3, cur, sr, sample_index, step_time, last_rir=prev, use_crossfade=True)
+    plain = O.convolve_with_rir(src3, cur, sr, sample_index, step_time)
+    check(out[0], ref)
+    check(out[1], plain)
+    check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
+    check(sg[1], O.compute_spectrogram(plain.astype(np.float32)))
+    n = int(0.05 * sr)
+    assert np.abs(out[0][:, n + 1:] - out[1][:, n + 1:]).max() == 0.0          # beyond the ramp: the current RIR alone
+    assert np.abs(out[0][:, :n] - out[1][:, :n]).max() > 0.0
+    assert not out[0][:, ns:].any()
+
+
+def test_fused_rows_crossfade_44k_reference_run_vector():
+    """cont_crossfade_44k: produced by running the reference's ContinuousSoundSpacesSim._compute_audiogoal with CROSSFADE
+    on at 44.1 kHz (tests/golden/make_golden.py)."""
+    d = case_inputs("cont_crossfade_44k")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("cont_crossfade_44k")
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    bank = np.concatenate([planar(d["rir"]), planar(d["last_rir"])])
+    t0 = P.window_start_continuous(d["sample_index"])
+    out, sg = hs.run([src3], bank, [d["rir"].shape[0], d["last_rir"].shape[0]],
+                     [dict(sound=0, t0=t0, rir=0, wrap=True, last_rir=1)], ns, sr, crossfade=True, row_wgs=2)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+@pytest.mark.parametrize("sr,n_valids", [(16000, [1, 383, 384, 385, 1024, 4000, 15487, 15488, 15489, 15999]),
+                                         (44100, [11025, 16384, 16385, 27000, 43588, 43589])])
+def test_zero_pooled_blocks_are_written_not_computed_at_any_step_length(sr, n_valids):
+    """Steps shorter than the row (n_valid < out_len): the pooled blocks behind the rendered samples are exact zeros and the
+    kernels write them without running their STFT - on both sides of every boundary of that rule (640 b - 256 >= n_valid;
+    right padding mirrors zeros only while n_valid <= out_len - 512), fused 16 kHz kernel and k_obs_rows."""
+    rng = np.random.default_rng(5)
+    src3 = O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=1)[0], sr)
+    rir = np.ascontiguousarray(O.synth_rir(rng, sr, length=9000, n=1)[0].T)
+    idx = 20000
+    full = O.convolve_with_rir(src3, rir, sr, idx, 1.0)                    # steady branch, no wrap: idx + sr < 3 sr
+    t0 = P.window_start_continuous(idx)
+    for nv in n_valids:
+        ref = full.copy()
+        ref[:, nv:] = 0
+        ref_s = O.compute_spectrogram(ref.astype(np.float32))
+        # fused kernel of the rate | the two-launch formulation (loop kernel, then k_spectrogram told where the zeros begin)
+        for kw in ((dict(row_wgs=2) if sr > P.KB else dict(fuse=True)), dict(fuse=False, simple=False)):
+            out, sg = hs.run([src3], planar(rir), [9000], [dict(sound=0, t0=t0, rir=0, wrap=True)], nv, sr,
+                             want_spectrogram=True, **kw)
+            check(out[0], ref)
+            check(sg[0], ref_s)
+            assert (sg[0][ref_s == 0] == 0).all()                         # the written zeros are exact
