@@ -49,7 +49,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 out = sys.argv[1]
 names = {"k_conv<true, true, false, false>": "k_conv<FUSE=true>", "k_conv<true, true, false, true>": "k_conv<FUSE=true>",
-         "k_obs_rows<false>": "k_obs_rows<SPECTRAL=false>"}        # (the TAB instantiation moves the same bytes)
+         "k_obs_rows<false>": "k_obs_rows<SPECTRAL=false>", "k_obs_rows<false, false>": "k_obs_rows<SPECTRAL=false>"}        # (the TAB instantiation moves the same bytes)
 kernels = {}
 for cfg in ("headline", "cfg2"):
     d = os.path.join(out, "pmc_" + cfg)
