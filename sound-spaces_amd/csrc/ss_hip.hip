@@ -135,12 +135,13 @@ int get_stash(hipStream_t st, size_t bytes, float** out) {
     return 0;
 }
 
-// should k_obs_rows serve this shape?  (rows of 2 or 3 blocks, stash mask of 32 bits.)  Cross-faded rows: only when the
-// caller has no waveform buffer (time-domain bank, ramp inside what the kernel parks of block 0) - with one, the loop
-// kernel + k_spectrogram (told where the zeros of a short step begin) is 20 % faster: 92.7 vs 117.8 us per 128 units at
-// 44.1 kHz (the rows kernel renders block 0 twice through its stash; profiles/r3/NOTES.md section 8)
+// should k_obs_rows serve this shape?  (rows of 2 or 3 blocks, stash mask of 32 bits.)  Rows with ONE rendered block
+// (n_valid <= kB: SS2.0 steps at 44.1 kHz) and cross-faded rows: only when the caller has no waveform buffer.  With one,
+// the loop kernel (block spectra accumulated in registers: every one is used once, the rows kernel's stash is pure overhead
+// there) + k_spectrogram (told where the zeros of a short step begin) is faster - per 128 units at 44.1 kHz: plain steps
+// 61.6 vs 72.5 us (66.3 without the waveform written), cross-faded 92.7 vs 117.8 us (profiles/r3/NOTES.md section 8)
 inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags, bool spectral = false, bool have_waveform_buffer = false) {
-    if ((flags & SS_FLAG_CROSSFADE) && have_waveform_buffer) return false;
+    if (have_waveform_buffer && ((flags & SS_FLAG_CROSSFADE) || n_valid <= ssk::kB)) return false;
     if ((flags & SS_FLAG_CROSSFADE) &&
         (spectral || static_cast<int>(0.05 * out_len) < 1 || static_cast<int>(0.05 * out_len) > 2 * ssk::kPrevPairs - 2)) return false;
     return out_len > ssk::kB && out_len <= 3 * ssk::kB && n_valid <= out_len && nbh_max >= 1 && nbh_max <= 16;

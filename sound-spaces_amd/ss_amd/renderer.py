@@ -361,11 +361,13 @@ class BatchedAudioRenderer:
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
         """One launch on the current stream; two - convolution, then spectrogram, the waveform handed over through memory -
-        for cross-faded rows longer than one partition block (measured faster than the one-launch form the library
-        falls back to without a buffer) and rows longer than three.  Returns (audiogoal [N,2,sr] or None, spectrogram)."""
+        for rows longer than one partition block that are cross-faded or have one rendered block (SS2.0 steps at 44.1 kHz:
+        measured faster than the one-launch form the library falls back to without a buffer) and for rows longer than
+        three blocks.  Returns (audiogoal [N,2,sr] or None, spectrogram)."""
         N = len(plan)
         need_ag = (want_audiogoal or audiogoal_out is not None or
-                   (self.out_len > P.KB and (bool(plan.flags & ops.FLAG_CROSSFADE) or self.out_len > 3 * P.KB)))
+                   (self.out_len > P.KB and (bool(plan.flags & ops.FLAG_CROSSFADE) or self.n_valid <= P.KB
+                                             or self.out_len > 3 * P.KB)))
         ag = audiogoal_out
         if need_ag and ag is None:
             ag = torch.empty((N, 2, self.out_len), dtype=torch.float32, device=self.device)

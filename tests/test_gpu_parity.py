@@ -1077,7 +1077,7 @@ def test_reference_run_vectors_at_44k_one_launch(name):
 
 
 @pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k"])
-def test_continuous_steps_at_44k_one_launch(name):
+def test_continuous_steps_at_44k_both_forms(name):
     from ss_amd.renderer import UnitRequest
     d = case_inputs(name)
     sr = d["sr"]
@@ -1089,6 +1089,13 @@ def test_continuous_steps_at_44k_one_launch(name):
     assert not ag[0][:, int(sr * d["step_time"]):].any()
     check(ag[0][:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
+    # ... and the one-launch form the library uses when the caller has no waveform buffer (k_obs_rows, zero pooled blocks
+    # written, not computed); the renderer itself takes two launches for rows with one rendered block (measured faster)
+    from ss_amd import ops
+    plan = r.plan([UnitRequest(0, d["sample_index"], 0, wrap=d["sample_index"] - d["rir"].shape[0] >= 0)])
+    sg1 = torch.full_like(sg, float("nan"))
+    ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg1, r.n_valid, r.out_len, r.pad_mode, flags=plan.flags)
+    check(sg1[0].cpu().numpy(), ref_s)
 
 
 @pytest.mark.gpu
