@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Where the eager (reference-semantics, one env per call) boundary mode spends its time: cProfile over 2000 calls of
+SpectrogramSensor.get_observation on the cache-miss path (one stand-in simulator, RIR resident in the HBM store)."""
+import cProfile, pstats, os, sys, types, time, io
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sound-spaces_amd")]
+import numpy as np, torch
+from ss_amd import sensors, sim_audio
+from ss_amd.renderer import AudioEngine
+sr = 16000
+rng = np.random.default_rng(0)
+NS = types.SimpleNamespace
+sounds = {"s": rng.standard_normal(sr).astype(np.float32) * 0.1}
+files = {"rirs/%d/%d_%d.wav" % (az, r, s): (rng.standard_normal((sr, 2)).astype(np.float32) * 0.05)
+         for r in range(8) for s in range(8) for az in (0, 90, 180, 270)}
+
+
+class Sim:
+    def __init__(self):
+        self.config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, HAS_DISTRACTOR_SOUND=False), USE_RENDERED_OBSERVATIONS=True)
+        self._source_sound_dict = sounds
+        self.binaural_rir_dir = "rirs"
+        self.current_scene_name = "x"
+        self._current_sound = "s"
+        self._source_position_index, self._receiver_position_index, self._rotation_angle = 0, 1, 0
+        self._audio_index, self._episode_step_count, self._duration = 0, 0, 500
+        self._is_episode_active = True
+        self._audiogoal_cache, self._spectrogram_cache = {}, {}
+        self.azimuth_angle = 0
+
+    @property
+    def current_source_sound(self):
+        return self._source_sound_dict[self._current_sound]
+
+
+eng = AudioEngine(sr, device="cuda:0", rir_slots=512)
+sim = Sim()
+try:
+    sim_audio.attach(sim, eng, rir_reader=lambda path: files[path])
+except Exception as e:
+    print("attach failed:", e); raise
+sen = sensors.SpectrogramSensor(sim=sim, config=NS())
+k = [0]
+
+
+def call():
+    k[0] += 1
+    sim._receiver_position_index = k[0] % 8
+    sim._source_position_index = (k[0] // 8) % 8
+    sim.azimuth_angle = 90 * (k[0] % 4)
+    sim._spectrogram_cache.clear(); sim._audiogoal_cache.clear()
+    return sen.get_observation(observations=None, episode=None)
+
+
+for _ in range(600):
+    call()
+t0 = time.perf_counter()
+for _ in range(2000):
+    call()
+print("eager: %.1f us per call" % (1e6 * (time.perf_counter() - t0) / 2000))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(2000):
+    call()
+pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:6000])

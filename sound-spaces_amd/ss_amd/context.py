@@ -145,7 +145,7 @@ class AudioContext:
             return
         if stream is None:
             import torch
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
         _lib.check(self.lib.ss_ctx_join(self._h, stream), "ss_ctx_join")
 
     def set_rir_cap_for_planning(self, cap: int) -> None:
@@ -182,7 +182,7 @@ class AudioContext:
         if dev is None:
             raise ValueError("observe: pass spectrogram_out and / or audiogoal_out")
         if stream is None:
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
         with torch.cuda.device(dev):
             _lib.check(self.lib.ss_ctx_observe(self._h, ctypes.byref(u), n, ag, sg, stream), "ss_ctx_observe")
 
@@ -248,7 +248,7 @@ class AudioContext:
                     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape
             bound["dev"] = dev
         if stream is None:
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
         if torch.cuda.current_device() == dev.index:
             rc = self.lib.ss_ctx_observe_sims(self._h, *bound["c_args"], ag, sg, *bound["c_miss"], stream)
         else:

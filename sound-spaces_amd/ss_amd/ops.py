@@ -25,8 +25,12 @@ FLAG_FIRST_BUCKET = 4       # SS_FLAG_FIRST_BUCKET: every bank index of the laun
 _PAD = {"reflect": PAD_REFLECT, "constant": PAD_CONSTANT, 0: 0, 1: 1}
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: "torch.Tensor" = None) -> int:
+    """Raw handle of the current stream of ``t``'s device (of the current device without ``t``).  Not
+    ``torch.cuda.current_stream(None).cuda_stream``: that is ~10 us of device-index plumbing and object construction per call,
+    a tenth of an eager (batch-1) observation."""
+    idx = t.device.index if (t is not None and t.device.index is not None) else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def _chk(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
@@ -60,7 +64,7 @@ def source_windows_into(src: torch.Tensor, win_desc: torch.Tensor, spec_out: tor
     assert win_desc.shape == (W, 4) and spec_out.numel() >= W * SPEC_FLOATS
     with torch.cuda.device(src.device):
         _lib.check(_lib.load().ss_source_windows_f32(src.data_ptr(), win_desc.data_ptr(), spec_out.data_ptr(), W,
-                                                     _stream()), "ss_source_windows_f32")
+                                                     _stream(src)), "ss_source_windows_f32")
 
 
 def source_windows(src: torch.Tensor, win_desc: torch.Tensor) -> torch.Tensor:
@@ -79,7 +83,7 @@ def fftconv_binaural_into(spec, rir_bank, rir_len, unit_desc, out, n_valid: int,
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().ss_fftconv_binaural_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
                                                        unit_desc.data_ptr(), out.data_ptr(), N, us, cs, es, cap,
-                                                       n_valid, out_len, flags, _stream()), "ss_fftconv_binaural_f32")
+                                                       n_valid, out_len, flags, _stream(spec)), "ss_fftconv_binaural_f32")
 
 
 def fftconv_binaural(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, interleaved: bool = False,
@@ -94,7 +98,7 @@ def spectrogram_into(x: torch.Tensor, out: torch.Tensor, pad_mode="reflect") -> 
     N, two, n = x.shape
     assert two == 2 and tuple(out.shape) == (N,) + spectrogram_shape(n)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().ss_spectrogram_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], _stream()),
+        _lib.check(_lib.load().ss_spectrogram_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], _stream(x)),
                    "ss_spectrogram_f32")
 
 
@@ -115,7 +119,7 @@ def logmel_into(x: torch.Tensor, out: torch.Tensor, mel_start: torch.Tensor, mel
     assert two == 2 and mel_start.shape == (n_mels,) and tuple(out.shape) == (N, n_mels, 1 + n // 160, 2)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ss_logmel_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], mel_start.data_ptr(),
-                                             mel_w.data_ptr(), n_mels, max_len, float(eps), _stream()), "ss_logmel_f32")
+                                             mel_w.data_ptr(), n_mels, max_len, float(eps), _stream(x)), "ss_logmel_f32")
 
 
 def logmel(x: torch.Tensor, mel_start: torch.Tensor, mel_w: torch.Tensor, eps: float = 1e-6, pad_mode="reflect"):
@@ -132,7 +136,7 @@ def gccphat_into(x: torch.Tensor, out: torch.Tensor, max_lag: int = 32, eps: flo
     assert two == 2 and tuple(out.shape) == (N, 2 * max_lag + 1, 1 + n // 160)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ss_gccphat_f32(x.data_ptr(), out.data_ptr(), N, n, _PAD[pad_mode], int(max_lag),
-                                              float(eps), _stream()), "ss_gccphat_f32")
+                                              float(eps), _stream(x)), "ss_gccphat_f32")
 
 
 def gccphat(x: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="reflect") -> torch.Tensor:
@@ -158,7 +162,7 @@ def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_ou
     with torch.cuda.device(spec.device):
         _lib.check(_lib.load().ss_audio_obs_f32(spec.data_ptr(), rir_bank.data_ptr(), rir_len.data_ptr(),
                                                 unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N, us, cs,
-                                                es, cap, n_valid, out_len, _PAD[pad_mode], flags, _stream()),
+                                                es, cap, n_valid, out_len, _PAD[pad_mode], flags, _stream(spec)),
                    "ss_audio_obs_f32")
 
 
@@ -184,7 +188,7 @@ def rir_spectra_into(rir_bank: torch.Tensor, hspec: torch.Tensor, first: int = 0
     assert 0 <= first and first + count <= R
     with torch.cuda.device(rir_bank.device):
         _lib.check(_lib.load().ss_rir_spectra_f32(rir_bank[first:].data_ptr(), hspec[first:].data_ptr(), count, 2 * cap, cap,
-                                                  cap, _stream()), "ss_rir_spectra_f32")
+                                                  cap, _stream(rir_bank)), "ss_rir_spectra_f32")
 
 
 def rir_spectra(rir_bank: torch.Tensor) -> torch.Tensor:
@@ -202,7 +206,7 @@ def fftconv_binaural_spec_into(spec, hspec, rir_len, unit_desc, out, n_valid: in
     with torch.cuda.device(out.device):
         _lib.check(_lib.load().ss_fftconv_binaural_spec_f32(spec.data_ptr(), hspec.data_ptr(), rir_len.data_ptr(),
                                                             unit_desc.data_ptr(), out.data_ptr(), N, hspec.shape[2],
-                                                            n_valid, out_len, flags, _stream()),
+                                                            n_valid, out_len, flags, _stream(spec)),
                    "ss_fftconv_binaural_spec_f32")
 
 
@@ -220,7 +224,7 @@ def audio_obs_spec_into(spec, hspec, rir_len, unit_desc, audiogoal, spectrogram_
     with torch.cuda.device(spec.device):
         _lib.check(_lib.load().ss_audio_obs_spec_f32(spec.data_ptr(), hspec.data_ptr(), rir_len.data_ptr(),
                                                      unit_desc.data_ptr(), ag_ptr, spectrogram_out.data_ptr(), N,
-                                                     hspec.shape[2], n_valid, out_len, _PAD[pad_mode], flags, _stream()),
+                                                     hspec.shape[2], n_valid, out_len, _PAD[pad_mode], flags, _stream(spec)),
                    "ss_audio_obs_spec_f32")
 
 
@@ -251,14 +255,14 @@ def audio_obs_buckets_into(spec, buckets, n_buckets: int, rir_len, unit_desc, au
         if spectrogram_out is None:
             _lib.check(_lib.load().ss_fftconv_binaural_buckets_f32(spec.data_ptr(), ctypes_ref(buckets), n_buckets,
                                                                    rir_len.data_ptr(), unit_desc.data_ptr(), ag_ptr, N, n_valid,
-                                                                   out_len, flags, _stream()), "ss_fftconv_binaural_buckets_f32")
+                                                                   out_len, flags, _stream(spec)), "ss_fftconv_binaural_buckets_f32")
             return
         _chk(spectrogram_out, torch.float32, "spectrogram_out")
         assert tuple(spectrogram_out.shape) == (N,) + spectrogram_shape(out_len)
         sg_ptr = spectrogram_out.data_ptr()
         _lib.check(_lib.load().ss_audio_obs_buckets_f32(spec.data_ptr(), ctypes_ref(buckets), n_buckets, rir_len.data_ptr(),
                                                         unit_desc.data_ptr(), ag_ptr, sg_ptr, N, n_valid, out_len,
-                                                        _PAD[pad_mode], flags, _stream()), "ss_audio_obs_buckets_f32")
+                                                        _PAD[pad_mode], flags, _stream(spec)), "ss_audio_obs_buckets_f32")
 
 
 def ctypes_ref(arr):
@@ -274,7 +278,7 @@ def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:
     assert two == 2
     out = torch.empty((N,), dtype=torch.float32, device=audiogoal.device)
     with torch.cuda.device(audiogoal.device):
-        _lib.check(_lib.load().ss_intensity_f32(audiogoal.data_ptr(), out.data_ptr(), N, n, num_frame, _stream()),
+        _lib.check(_lib.load().ss_intensity_f32(audiogoal.data_ptr(), out.data_ptr(), N, n, num_frame, _stream(audiogoal)),
                    "ss_intensity_f32")
     return out
 
