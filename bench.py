@@ -239,6 +239,85 @@ def measure_plugin_path(torch, np, dev, sr, n_envs, bank, n_sounds, sources, ste
     return out
 
 
+def measure_deferred_path(torch, np, dev, sr, n_envs, bank, sources, steps, warmup):
+    """The reference's DEFAULT env arrangement (habitat.VectorEnv: one worker process per env,
+    ss_baselines/common/env_utils.py:91-107) through ss_amd.deferred: every env's sensor returns an AudioRequest (worker
+    half: runs inside the env processes, N-way parallel in real use), the trainer turns the N requests of the step into unit
+    columns and ONE ss_ctx_observe into the rollout rows (trainer half: what the learner process pays).  RIR 'files' are rows
+    of the headline's HBM bank served through a reader on first touch; steady-state steps find every pose resident."""
+    import types
+    from ss_amd import planning as P
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.renderer import AudioEngine
+    from ss_amd.rollout import RolloutStorage
+    R = bank.shape[0]
+    n_nodes = min(int(np.sqrt(R // 4)), 24)                   # 24 x 24 pairs x 4 azimuths = 2304 poses: 288 MiB of store
+    rng = np.random.default_rng(6)
+    sounds = {"sound%d" % i: c for i, c in enumerate(sources)}
+    NS = types.SimpleNamespace
+
+    class DSim(SyntheticSim):
+        config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, HAS_DISTRACTOR_SOUND=False), USE_RENDERED_OBSERVATIONS=True)
+        binaural_rir_dir = "bank"
+        azimuth_angle = property(lambda self: -(self._rotation_angle + 0) % 360)
+        current_source_sound = property(lambda self: self._source_sound_dict[self._current_sound])
+        _audio_length = property(lambda self: self.current_source_sound.shape[0] // sr)
+
+    def reader(path):                                         # "bank/<azimuth>/<recv>_<src>.wav" -> a row of the device bank
+        _, az, name = path.split("/")
+        r_, s_ = name[:-4].split("_")
+        row = 4 * (int(r_) * n_nodes + int(s_)) + int(az) // 90
+        return bank[row].t().contiguous().cpu().numpy()
+    eng = AudioEngine(sr, device=dev, rir_slots=4 * n_nodes * n_nodes)
+    res = DeferredResolver(eng, rir_reader=reader, fast=True)
+    sims = [DSim(sounds, n_nodes, rng) for _ in range(n_envs)]
+    for s_ in sims:
+        s_._duration = 10 ** 9
+    for i, sim in enumerate(sims):
+        attach_deferred(sim, env_rank=i)
+    T = 16
+    space = NS(spaces={"spectrogram": NS(shape=P.spectrogram_shape(sr))})
+
+    class ActionSpace:
+        pass
+    rollouts = RolloutStorage(T, n_envs, space, ActionSpace(), 8, device=dev)
+    total = warmup + steps
+    acts = rng.integers(0, 3, (total, n_envs))
+    nodes = rng.integers(0, n_nodes, (total, n_envs))
+    out = {}
+    for name, replace in (("trainer_rollout_rows", False), ("trainer_rollout_rows_and_per_env_views", True)):
+        w_us, t_us = [], []
+        for k in range(total):
+            if k == warmup:
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+            a, nd = acts[k], nodes[k]
+            for i, sim in enumerate(sims):
+                sim.move(a[i], int(nd[i]))
+            t0 = time.perf_counter()
+            observations = [{"spectrogram": sim.get_current_spectrogram_observation(None)} for sim in sims]
+            t1 = time.perf_counter()
+            res.resolve_observations(observations, rollouts, replace=replace)
+            rollouts.step = (rollouts.step + 1) % T
+            t2 = time.perf_counter()
+            if k >= warmup:
+                w_us.append(1e6 * (t1 - t0)); t_us.append(1e6 * (t2 - t1))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_start
+        tm = float(np.median(t_us))
+        out[name] = {"trainer_half_us_per_step": round(tm, 2), "trainer_half_env_steps_per_s": round(n_envs / (tm * 1e-6), 1),
+                     "worker_half_us_per_step_all_envs": round(float(np.median(w_us)), 1),
+                     "both_halves_serial_env_steps_per_s": round(n_envs * steps / dt, 1)}
+    out["resident_pairs"] = int(res._pair_keys.shape[0])
+    out["column_steps"], out["walk_steps"] = res.column_steps, res.walk_steps
+    out["note"] = ("AudioRequest per env (packed record: CRC keys of sound / RIR directory, receiver, source, clip window) -> "
+                   "DeferredResolver._columns (numpy: searchsorted over resident pairs) -> AudioEngine.observe_columns -> "
+                   "ss_ctx_observe (C++ planner, window cache, descriptor ring, launch) into rollouts.observations['spectrogram']"
+                   "[step+1].  The worker half runs in the env processes (here: serially, in this process); "
+                   "'..._and_per_env_views' also replaces the request in each env's observation dict by its row view.")
+    return out
+
+
 def dist_of(ms):
     """median / p10 / p90 of per-step durations (ms)."""
     import numpy as np
@@ -750,6 +829,9 @@ def main():
             # included); `columns` - a struct-of-arrays vector env the reference does not have - is the ceiling
             out["plugin_path"]["headline"] = dict(out["plugin_path"]["bound_sims"], mode="bound_sims")
             out["plugin_path"]["ceiling"] = dict(out["plugin_path"]["columns"], mode="columns")
+            # the reference's default arrangement: worker processes + one resolver in the trainer (ss_amd/deferred.py)
+            out["plugin_path"]["deferred"] = measure_deferred_path(torch, np, dev, sr, n_env, bank, srcs,
+                                                                   min(args.steps, 200), min(args.warmup, 20))
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)

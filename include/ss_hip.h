@@ -147,6 +147,18 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
                              const int* unit_desc, float* audiogoal, float* spectrogram, int n_units, int n_valid,
                              int out_len, int pad_mode, int flags, void* stream);
 
+/* ---- The loop-free case on the 512-thread FFT core (round 4; csrc/ss_fft_core32.hpp) ------------------------------------
+ * Rows of ONE partition block from a time-domain bank of rir_cap <= kB, no distractor / cross-fade terms - SoundSpaces 1.0
+ * with 1-s clips (simulator.py:629-632) - on a 512-thread / 32-values-per-thread transform (16384 = 32*32*16: two LDS
+ * exchanges per transform instead of three, half the workgroup barriers).  Window spectra for it come from
+ * ss_source_windows32_f32 (same descriptors and size as ss_source_windows_f32, that core's own register order: the two
+ * formats are not interchangeable).  audiogoal or spectrogram may be NULL (not both).  Results equal ss_audio_obs_f32's to
+ * fp32 rounding.  Measured A/B against the 1024-thread kernels: profiles/r4/NOTES.md section 1. */
+int ss_source_windows32_f32(const float* src, const int* win_desc, float* spec_out, int n_windows, void* stream);
+int ss_audio_obs32_f32(const float* spec32, const float* rir, const int* rir_len, const int* unit_desc, float* audiogoal,
+                       float* spectrogram, int n_units, long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
+                       int rir_cap, int n_valid, int out_len, int pad_mode, void* stream);
+
 /* av_wan Intensity sensor (ss_baselines/av_wan/avwan_sensors.py:91-100) on audiogoal [n_units, 2, len]:
  * onset = min over ears of the first sample > 0.1*max, out[n] = mean(x[:, onset:onset+num_frame]**2). */
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream);
@@ -266,6 +278,30 @@ int ss_ctx_observe_sims(ss_ctx* ctx, const ss_sim_columns* cols, int n, float* a
 /* The state -> unit columns step of ss_ctx_observe_sims alone (host only, needs no GPU; advances audio_index the same
  * way): units_out int32 [5, n] = sound, t0, rir, dis_sound, dis_rir. */
 int ss_ctx_sims_units(ss_ctx* ctx, const ss_sim_columns* cols, int n, int* units_out, int* miss_out, int* n_miss);
+/* One step from the packed REQUEST RECORDS of a multi-process vector env (ss_amd/deferred.py: every worker-side sensor
+ * returns an AudioRequest whose `rec` is SS_REQ_WORDS int64 words; the trainer concatenates the N records of the step).  Does
+ * in C++ what DeferredResolver._columns does in numpy: names travel as CRC-32 keys, ids and resident RIR files are found by
+ * binary search in the caller's SORTED tables; reference: what _compute_audiogoal reads per env, simulator.py:608-666.
+ *   words: [0] silent  [1] sound key  [2] t0  [3] RIR table key (= directory/azimuth)  [4] receiver  [5] source
+ *          [6] distractor sound key or -1  [7] distractor source  [8] env  [9] reserved
+ * A request that names an unknown sound / table, a pair that is not resident, or a row flagged stale is a MISS: their
+ * indices go to miss_out (capacity n), *n_miss > 0, nothing is launched and the call returns 0 - register / load, call again. */
+#define SS_REQ_WORDS 10
+typedef struct ss_request_tables {
+    const long long* sound_keys;   /* sorted */
+    const long long* sound_ids;
+    const long long* table_keys;   /* sorted */
+    const long long* table_ids;
+    const long long* pair_keys;    /* sorted: table id << 40 | receiver << 20 | source */
+    const long long* pair_slots;   /* bank slot of the pair's RIR */
+    const unsigned char* stale;    /* optional, [n_slots]: != 0 = the row must be reloaded before it is used */
+    int n_sounds, n_tables, n_pairs, n_slots;
+} ss_request_tables;
+int ss_ctx_observe_requests(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, float* audiogoal,
+                            float* spectrogram, int* miss_out, int* n_miss, void* stream);
+/* The records -> unit columns step alone (host only, needs no GPU): units_out int32 [5, n] = sound, t0, rir, dis_sound, dis_rir. */
+int ss_ctx_requests_units(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, int* units_out,
+                          int* miss_out, int* n_miss);
 /* The planner alone (host only, needs no GPU): unit_desc_out int32 [n,8] as ss_fftconv_binaural_f32 takes them,
  * *flags_out the SS_FLAG_* of the launch, *n_new_windows_out the source windows whose spectra would be computed,
  * new_windows_out (optional, int32 [cap,5]) = {src_offset, src_len, start, wrap, pool slot} of those windows. */

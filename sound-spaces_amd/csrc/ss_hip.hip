@@ -12,6 +12,7 @@
 #include "../../include/ss_hip.h"
 #include "ss_context.hpp"
 #include "ss_kernels.hpp"
+#include "ss_kernels32.hpp"
 #include "ss_tables.hpp"
 
 namespace {
@@ -45,6 +46,8 @@ int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
         d.tb.twItem = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwItemOff);
         d.tb.tw512 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTw512Off);
         d.tb.win = dev_buf + ssk_host::kWinOff;
+        d.tb.twG = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwGOff);
+        d.tb.twP2 = reinterpret_cast<const ssk::c32*>(dev_buf + ssk_host::kTwP2Off);
         int cus = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);   // slow call: once per device
         if (e != hipSuccess) { (void)hipFree(dev_buf); return hip_err(e); }
@@ -178,6 +181,15 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
         }
     }
     hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
+    return hip_err(hipGetLastError());
+}
+
+template <bool FUSE>
+int launch_conv32(ssk::ConvParams& p, int n_units, hipStream_t st) {
+    const dim3 grid(2 * n_units), block(ssk::kT32);
+    fill_unit_tab(p, g_host_desc, n_units);
+    if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv32<FUSE, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((ssk::k_conv32<FUSE, false>), grid, block, 0, st, p);
     return hip_err(hipGetLastError());
 }
 
@@ -407,6 +419,47 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
                                  rir_chan_stride, rir_elem_stride, rir_cap, n_valid, out_len, flags, stream);
     if (rc) return rc;
     return spectrogram_of_rows(audiogoal, spectrogram, n_units, out_len, n_valid, pad_mode, stream);
+}
+
+// ---- 512-thread FFT core (ss_kernels32.hpp): loop-free rows only; spectra in that core's own register order ----------
+int ss_source_windows32_f32(const float* src, const int* win_desc, float* spec_out, int n_windows, void* stream) {
+    if (n_windows == 0) return 0;
+    if (!src || !win_desc || !spec_out || n_windows < 0) return SS_EINVAL;
+    ssk::SrcParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.src = src;
+    p.desc = win_desc;
+    p.spec = reinterpret_cast<ssk::f32x4*>(spec_out);
+    p.desc_stride = 4;
+    p.scale = ssk::kWindowScale;
+    hipLaunchKernelGGL(ssk::k_source_windows32, dim3(n_windows), dim3(ssk::kT32), 0, static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
+// Rows of ONE block from a time-domain bank of rir_cap <= kB without distractor / cross-fade terms (the loop-free case of
+// ss_audio_obs_f32 / ss_fftconv_binaural_f32); spectrogram may be NULL (audiogoal only) or audiogoal may be NULL.
+int ss_audio_obs32_f32(const float* spec32, const float* rir, const int* rir_len, const int* unit_desc, float* audiogoal,
+                       float* spectrogram, int n_units, long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,
+                       int rir_cap, int n_valid, int out_len, int pad_mode, void* stream) {
+    if (n_units == 0) return 0;
+    if ((!spectrogram && !audiogoal) || n_units < 0) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (n_valid > ssk::kB || rir_cap > ssk::kB || out_len < ssk::kNfft / 2 + 1) return SS_EINVAL;
+    ssk::ConvParams p;
+    int n_cus = 1;
+    int rc = fill_conv(p, &n_cus, spec32, rir, rir_len, unit_desc, rir_unit_stride, rir_chan_stride, rir_elem_stride,
+                       rir_cap, n_valid, out_len);
+    if (rc) return rc;
+    p.pad_mode = pad_mode;
+    p.nb_y = 1;
+    p.out = audiogoal;
+    p.sgram = spectrogram;
+    if (spectrogram) {
+        if (out_len > ssk::kB || p.t4 > 26) return SS_EINVAL;
+        return launch_conv32<true>(p, n_units, static_cast<hipStream_t>(stream));
+    }
+    return launch_conv32<false>(p, n_units, static_cast<hipStream_t>(stream));
 }
 
 int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, int num_frame, void* stream) {
@@ -1047,6 +1100,82 @@ static int sims_to_units(ss_ctx* h, const ss_sim_columns* sc, int n, int* w, int
     }
     return 0;
 }
+
+// ---- request records of a multi-process vector env (ss_amd/deferred.py) -> unit columns ------------------------------
+static long long find_key(const long long* keys, const long long* vals, int n, long long q) {
+    if (!keys || n <= 0) return -1;
+    const long long* p = std::lower_bound(keys, keys + n, q);
+    return (p != keys + n && *p == q) ? vals[p - keys] : -1;
+}
+
+static int requests_to_units(ss_ctx* h, const long long* recs, int n, const ss_request_tables* tb, int* w, int* miss_out,
+                             int* n_miss) {
+    if (!h || !recs || !tb || n < 0 || !n_miss || tb->n_sounds < 0 || tb->n_tables < 0 || tb->n_pairs < 0) return SS_EINVAL;
+    ssctx::Context& c = h->c;
+    *n_miss = 0;
+    const int n_src = static_cast<int>(c.src_len.size());
+    int* sound = w; int* t0 = sound + n; int* rir = t0 + n; int* dsound = rir + n; int* drir = dsound + n;
+    int misses = 0;
+    auto slot_of = [&](long long table, long long recv, long long src) -> int {
+        if (recv < 0 || src < 0 || recv >= (1 << 20) || src >= (1 << 20)) return -1;
+        const long long s = find_key(tb->pair_keys, tb->pair_slots, tb->n_pairs, (table << 40) | (recv << 20) | src);
+        if (s < 0 || (tb->stale && s < tb->n_slots && tb->stale[s])) return -1;
+        return static_cast<int>(s);
+    };
+    for (int i = 0; i < n; ++i) {
+        const long long* r = recs + static_cast<size_t>(i) * SS_REQ_WORDS;
+        sound[i] = 0; t0[i] = 0; rir[i] = -1; dsound[i] = 0; drir[i] = -1;
+        if (r[0] != 0) continue;                               // silent (simulator.py:610-612)
+        const long long sid = find_key(tb->sound_keys, tb->sound_ids, tb->n_sounds, r[1]);
+        const long long tid = find_key(tb->table_keys, tb->table_ids, tb->n_tables, r[3]);
+        bool miss = sid < 0 || sid >= n_src || tid < 0 || r[2] < 0 || r[2] > 0x7fffffffLL;
+        if (!miss) {
+            sound[i] = static_cast<int>(sid);
+            t0[i] = static_cast<int>(r[2]);
+            rir[i] = slot_of(tid, r[4], r[5]);
+            miss = rir[i] < 0;
+            if (r[6] >= 0) {                                   // distractor (simulator.py:649-664): whole clip, own RIR
+                const long long did = find_key(tb->sound_keys, tb->sound_ids, tb->n_sounds, r[6]);
+                if (did < 0 || did >= n_src) miss = true;
+                else {
+                    dsound[i] = static_cast<int>(did);
+                    drir[i] = slot_of(tid, r[4], r[7]);
+                    miss = miss || drir[i] < 0;
+                }
+            }
+        }
+        if (miss && miss_out && misses < n) miss_out[misses] = i;
+        misses += miss;
+    }
+    *n_miss = misses;
+    return 0;
+}
+
+extern "C" {
+
+int ss_ctx_requests_units(ss_ctx* h, const long long* recs, int n, const ss_request_tables* tb, int* units_out, int* miss_out,
+                          int* n_miss) {
+    if (!units_out) return SS_EINVAL;
+    return requests_to_units(h, recs, n, tb, units_out, miss_out, n_miss);
+}
+
+int ss_ctx_observe_requests(ss_ctx* h, const long long* recs, int n, const ss_request_tables* tb, float* audiogoal,
+                            float* spectrogram, int* miss_out, int* n_miss, void* stream) {
+    if (!h || n < 0) return SS_EINVAL;
+    std::vector<int>& w = h->c.sim_scratch;
+    w.resize(static_cast<size_t>(n) * 5 + 1);
+    const int rc = requests_to_units(h, recs, n, tb, w.data(), miss_out, n_miss);
+    if (rc != 0 || n == 0 || *n_miss) return rc;
+    ss_units u;
+    std::memset(&u, 0, sizeof u);
+    u.sound = w.data(); u.t0 = u.sound + n; u.rir = u.t0 + n;
+    bool any_dis = false;
+    for (int i = 0; i < n && !any_dis; ++i) any_dis = u.rir[n + n + i] >= 0;     // dis_rir column
+    if (any_dis) { u.dis_sound = u.rir + n; u.dis_rir = u.dis_sound + n; }
+    return ss_ctx_observe(h, &u, n, audiogoal, spectrogram, stream);
+}
+
+}  // extern "C"
 
 // ---- length-bucketed RIR bank ---------------------------------------------------------------------------
 // buckets[0..n): HOST array; bucket b holds bank entries [first_b, first_b + n_entries_b) as planar rows of cap_b samples

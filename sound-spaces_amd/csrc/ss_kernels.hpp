@@ -100,6 +100,8 @@ struct Tables {
     const c32* twItem;   // [2048]  exp(-2 pi i gA(q) / 32768)
     const c32* tw512;    // [256]   exp(-2 pi i k / 512)
     const float*  win;      // [512]   hann(400, periodic) centred in 512
+    const c32* twG;      // [512]   exp(-2 pi i q / 32768)             (512-thread core, ss_fft_core32.hpp)
+    const c32* twP2;     // [512]   exp(-2 pi i c k2 / 512) at [c * 32 + k2]   (its pass-2 twiddles)
 };
 
 // ---------------------------------------------------------------------------------------------

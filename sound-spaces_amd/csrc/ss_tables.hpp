@@ -1,5 +1,5 @@
 // ss_tables.hpp — host-side construction of the constant tables the kernels read (double precision -> f32).
-// Layout of the returned buffer (floats): twM[2*1024] | twItem[2*2048] | tw512[2*256] | win[512].
+// Layout of the returned buffer (floats): twM[2*1024] | twItem[2*2048] | tw512[2*256] | win[512] | twG[2*512] | twP2[2*512].
 #pragma once
 #include <cmath>
 #include <vector>
@@ -10,7 +10,9 @@ constexpr int kTwMOff = 0;
 constexpr int kTwItemOff = 2 * 1024;
 constexpr int kTw512Off = kTwItemOff + 2 * 2048;
 constexpr int kWinOff = kTw512Off + 2 * 256;
-constexpr int kTableFloats = kWinOff + 512;
+constexpr int kTwGOff = kWinOff + 512;
+constexpr int kTwP2Off = kTwGOff + 2 * 512;
+constexpr int kTableFloats = kTwP2Off + 2 * 512;
 
 inline std::vector<float> build_tables() {
     const double two_pi = 6.283185307179586476925286766559;
@@ -41,6 +43,19 @@ inline std::vector<float> build_tables() {
         const int j = n - 56;
         win[n] = (j >= 0 && j < 400) ? static_cast<float>(0.5 - 0.5 * std::cos(two_pi * j / 400.0)) : 0.f;
     }
+    float* twG = host.data() + kTwGOff;
+    float* twP2 = host.data() + kTwP2Off;
+    for (int q = 0; q < 512; ++q) {                        // exp(-2 pi i q / 32768): Hermitian stage of the 512-thread core
+        const double a = -two_pi * q / 32768.0;
+        twG[2 * q] = static_cast<float>(std::cos(a));
+        twG[2 * q + 1] = static_cast<float>(std::sin(a));
+    }
+    for (int c = 0; c < 16; ++c)                           // exp(-2 pi i c k2 / 512): its pass-2 twiddles
+        for (int k2 = 0; k2 < 32; ++k2) {
+            const double a = -two_pi * (c * k2) / 512.0;
+            twP2[2 * (c * 32 + k2)] = static_cast<float>(std::cos(a));
+            twP2[2 * (c * 32 + k2) + 1] = static_cast<float>(std::sin(a));
+        }
     return host;
 }
 

@@ -14,7 +14,8 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_observe", "ss_ctx_plan", "ss_ctx_stats", "ss_ctx_set_rir_spectra",
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
-           "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch")
+           "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
+           "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units")
 
 
 class SsRirBucket(ctypes.Structure):
@@ -28,6 +29,13 @@ class SsSimColumns(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("sound", "audio_index", "step_count", "duration", "recv", "src", "rot", "scene",
                                               "dis_sound", "dis_src", "index_flat", "index_off", "index_dim")] + \
                [("n_scenes", ctypes.c_int), ("azimuths", ctypes.c_int)]
+
+
+class SsRequestTables(ctypes.Structure):
+    """struct ss_request_tables of include/ss_hip.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("sound_keys", "sound_ids", "table_keys", "table_ids", "pair_keys", "pair_slots",
+                                              "stale")] + \
+               [(n, ctypes.c_int) for n in ("n_sounds", "n_tables", "n_pairs", "n_slots")]
 
 
 class SsUnits(ctypes.Structure):
@@ -83,6 +91,10 @@ def load() -> ctypes.CDLL:
     lib.ss_rir_spectra_f32.argtypes = [vp, vp, c_int, c_ll, c_int, c_int, vp]
     lib.ss_fftconv_binaural_spec_f32.argtypes = [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp]
     lib.ss_audio_obs_spec_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_source_windows32_f32.argtypes = [vp, vp, vp, c_int, vp]
+    lib.ss_audio_obs32_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_ctx_observe_requests.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp]
+    lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib

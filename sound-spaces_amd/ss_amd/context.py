@@ -32,11 +32,12 @@ _NO_MISS = np.zeros((0,), np.int32)
 
 class AudioContext:
     def __init__(self, sampling_rate: int, step_time: Optional[float] = None, wrap: bool = False,
-                 pad_mode="reflect", max_window_sets: int = 256):
-        """step_time None: SoundSpaces 1.0 (1-s observations); step_time = STEP_TIME with wrap=True: SoundSpaces 2.0."""
+                 pad_mode="reflect", max_window_sets: int = 256, n_valid: Optional[int] = None):
+        """step_time None: SoundSpaces 1.0 (1-s observations); step_time = STEP_TIME with wrap=True: SoundSpaces 2.0
+        (n_valid: the samples per step given directly instead of as a fraction of a second)."""
         self.lib = _lib.load()
         self.sr = int(sampling_rate)
-        self.n_valid = self.sr if step_time is None else int(self.sr * step_time)
+        self.n_valid = int(n_valid) if n_valid is not None else (self.sr if step_time is None else int(self.sr * step_time))
         self.wrap = bool(wrap)
         self.spectrogram_shape = spectrogram_shape(self.sr)
         h = ctypes.c_void_p()
@@ -258,6 +259,39 @@ class AudioContext:
             _lib.check(rc, "ss_ctx_observe_sims")
         k = bound["n_miss"].value
         return bound["miss"][:min(k, bound["n"])] if k else _NO_MISS
+
+    # ---- request records of a multi-process vector env (ss_amd/deferred.py) ------------------------------------------
+    @staticmethod
+    def request_tables(sound_keys, sound_ids, table_keys, table_ids, pair_keys, pair_slots, stale=None):
+        """The sorted lookup tables of ``ss_ctx_observe_requests`` as its C struct (int64 numpy arrays, borrowed: the
+        returned dict keeps them alive; rebuild it whenever one of them is replaced)."""
+        arrs = [np.ascontiguousarray(a, np.int64) for a in (sound_keys, sound_ids, table_keys, table_ids, pair_keys, pair_slots)]
+        t = _lib.SsRequestTables()
+        for name, a in zip(("sound_keys", "sound_ids", "table_keys", "table_ids", "pair_keys", "pair_slots"), arrs):
+            setattr(t, name, a.ctypes.data if a.shape[0] else None)
+        t.n_sounds, t.n_tables, t.n_pairs = int(arrs[0].shape[0]), int(arrs[2].shape[0]), int(arrs[4].shape[0])
+        if stale is not None:
+            assert stale.dtype in (np.bool_, np.uint8) and stale.flags.c_contiguous
+            t.stale, t.n_slots = stale.ctypes.data, int(stale.shape[0])
+        return dict(t=t, ref=ctypes.byref(t), keep=(arrs, stale))
+
+    def observe_requests(self, recs: bytes, n: int, tables, spectrogram_ptr, audiogoal_ptr, stream: int, miss) -> int:
+        """One step from the concatenated request records (n x SS_REQ_WORDS int64, as bytes): lookups, planning and the
+        launch in ONE C call.  `miss` = dict(buf=int32[n] array, n=ctypes.c_int) reused across calls.  Returns the number
+        of requests that could not be resolved (then nothing was launched; their indices are in miss['buf'])."""
+        rc = self.lib.ss_ctx_observe_requests(self._h, recs, n, tables["ref"], audiogoal_ptr, spectrogram_ptr,
+                                              miss["ptr"], miss["n_ptr"], stream)
+        if rc != 0:
+            _lib.check(rc, "ss_ctx_observe_requests")
+        return miss["n"].value
+
+    def requests_units(self, recs: bytes, n: int, tables):
+        """Host only: the unit columns ``observe_requests`` would render -> (dict of int32 columns, missing request indices)."""
+        out = np.zeros((5, max(n, 1)), np.int32)
+        miss, n_miss = np.zeros((max(n, 1),), np.int32), ctypes.c_int(0)
+        _lib.check(self.lib.ss_ctx_requests_units(self._h, recs, n, tables["ref"], out.ctypes.data, miss.ctypes.data,
+                                                  ctypes.addressof(n_miss)), "ss_ctx_requests_units")
+        return dict(zip(("sound", "t0", "rir", "dis_sound", "dis_rir"), out[:, :n])), miss[:min(n_miss.value, n)].copy()
 
     def plan(self, sound, t0, rir, dis_sound=None, dis_rir=None, last_rir=None, wrap=None, last_wrap=None):
         """The planner alone (host only): -> (unit descriptors int32 [n,8], launch flags, new windows int32 [w,5])."""

@@ -23,6 +23,7 @@ window first seen at a pose)."""
 from __future__ import annotations
 
 import os
+import zlib
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -48,6 +49,23 @@ class AudioRequest:
     last_rir: Optional[np.ndarray] = None         # SS2.0 CROSSFADE: the previous step's RIR
     wrap: Optional[bool] = None
     last_wrap: Optional[bool] = None
+    # SS1.0 requests against RIR files: the same facts as REC_N packed int64 words (bytes), so that the trainer turns the
+    # N requests of a vector step into unit COLUMNS with a dozen numpy operations instead of a Python walk (see
+    # DeferredResolver._columns).  Names travel as CRC-32 keys; the strings above stay for first-use registration.
+    rec: Optional[bytes] = None
+
+
+# layout of AudioRequest.rec (int64 words)
+REC_SILENT, REC_SOUND, REC_T0, REC_TABLE, REC_RECV, REC_SRC, REC_DIS_SOUND, REC_DIS_SRC, REC_ENV, REC_RESERVED = range(10)
+REC_N = 10                                    # = SS_REQ_WORDS of include/ss_hip.h
+_SILENT_REC = np.zeros((REC_N,), np.int64)
+_SILENT_REC[REC_SILENT] = 1
+_SILENT_REC[REC_DIS_SOUND] = -1
+
+
+def name_key(name: str) -> int:
+    """CRC-32 of a sound name / RIR directory: the same integer in every process without a registry round trip."""
+    return zlib.crc32(name.encode("utf-8"))
 
 
 class DeferredSimAudio:
@@ -56,6 +74,13 @@ class DeferredSimAudio:
     def __init__(self, sim, env_rank: int = 0, continuous: bool = False):
         self.sim, self.env, self.continuous = sim, env_rank, continuous
         self._sent = set()                        # sounds whose clip the trainer already has
+        self._keys: Dict[str, int] = {}           # name -> CRC-32 (sounds, "<rir dir>/<azimuth>" tables)
+
+    def _key(self, name: str) -> int:
+        k = self._keys.get(name)
+        if k is None:
+            k = self._keys[name] = name_key(name)
+        return k
 
     def _clip_once(self, name, clip):
         if name in self._sent:
@@ -82,7 +107,9 @@ class DeferredSimAudio:
         sim = self.sim
         sr = int(sim.config.AUDIO.RIR_SAMPLING_RATE)
         if sim._episode_step_count > sim._duration:                                  # simulator.py:610 / cont. :415
-            return AudioRequest(env=self.env, kind=kind, silent=True)
+            rec = _SILENT_REC.copy()
+            rec[REC_ENV] = self.env
+            return AudioRequest(env=self.env, kind=kind, silent=True, rec=rec.tobytes())
         name, clip = sim._current_sound, sim.current_source_sound
         req = AudioRequest(env=self.env, kind=kind, sound=name, clip=self._clip_once(name, clip))
         if self.continuous:
@@ -110,6 +137,17 @@ class DeferredSimAudio:
             req.dis_clip = self._clip_once(dn, sim._source_sound_dict[dn])
             req.dis_rir_key = os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle),
                                            "{}_{}.wav".format(sim._receiver_position_index, sim._distractor_position_index))
+        if req.rir_key is not None:                       # RIR files: (directory/azimuth, receiver, source) are integers
+            rec = np.zeros((REC_N,), np.int64)
+            rec[REC_SOUND] = self._key(name)
+            rec[REC_T0] = req.t0
+            rec[REC_TABLE] = self._key(os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle)))
+            rec[REC_RECV] = sim._receiver_position_index
+            rec[REC_SRC] = sim._source_position_index
+            rec[REC_DIS_SOUND] = self._key(req.dis_sound) if req.dis_sound is not None else -1
+            rec[REC_DIS_SRC] = sim._distractor_position_index if req.dis_sound is not None else 0
+            rec[REC_ENV] = self.env
+            req.rec = rec.tobytes()
         return req
 
     def get_current_audiogoal_observation(self):
@@ -133,12 +171,36 @@ class DeferredResolver:
     """Trainer side: N requests -> one launch.  ``engine`` = ``ss_amd.renderer.AudioEngine`` (an SS2.0 one for
     continuous simulators); ``rir_reader(path) -> [L, 2] array or None`` as in ``sim_audio.wav_rir_reader``."""
 
-    def __init__(self, engine, rir_reader: Optional[Callable[[str], Optional[np.ndarray]]] = None):
+    def __init__(self, engine, rir_reader: Optional[Callable[[str], Optional[np.ndarray]]] = None,
+                 fast: Optional[bool] = None):
+        """fast: None = use the column path when the engine has one and every request of the step carries `rec`;
+        False = always walk the requests (per-unit Python planner); True = require the column path."""
         from .sim_audio import wav_rir_reader
         self.engine = engine
         self.rir_reader = rir_reader or wav_rir_reader
         self._clips: Dict[str, np.ndarray] = {}
         self._live: Dict[int, list] = {}          # env -> [held arrays, slots, turn] (see HipContinuousSimAudio)
+        # column path (engines that own a C++ context: ss_amd.renderer.AudioEngine on a GPU).  CRC keys -> ids through
+        # sorted arrays (np.searchsorted), RIR slots through dense (table, receiver, source) tables
+        store = getattr(engine, "store", None)
+        self.columns_ok = (fast is not False and hasattr(engine, "observe_columns") and store is not None
+                           and getattr(store, "group", 0) == 1 and hasattr(store, "touch_slots"))
+        if fast is True and not self.columns_ok:
+            raise ValueError("DeferredResolver(fast=True): the engine has no column path (AudioEngine, rir_group=1)")
+        self._sound_keys = np.zeros((0,), np.int64)
+        self._sound_ids = np.zeros((0,), np.int64)
+        self._key_names: Dict[int, str] = {}
+        self._table_keys = np.zeros((0,), np.int64)
+        self._table_ids = np.zeros((0,), np.int64)
+        self._table_dirs: List[str] = []
+        self.column_steps = self.walk_steps = 0
+        # resident RIR files: sorted composite keys (table << 40 | receiver << 20 | source) -> store slot
+        self._pair_keys = np.zeros((0,), np.int64)
+        self._pair_slots = np.zeros((0,), np.int64)
+        self._tables = None                       # the arrays above as the C struct of ss_ctx_observe_requests (rebuilt on change)
+        self.native_steps = 0
+        if self.columns_ok and store.on_evict is None:
+            store.on_evict = self._evicted
 
     def _sound(self, name, clip) -> int:
         if clip is not None:
@@ -185,19 +247,186 @@ class DeferredResolver:
             out.append(u)
         return out
 
+    # ---- column path ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _lookup(keys: np.ndarray, ids: np.ndarray, q: np.ndarray) -> np.ndarray:
+        """ids of the CRC keys q (sorted `keys`), -1 where unknown"""
+        if keys.shape[0] == 0:
+            return np.full(q.shape, -1, np.int64)
+        pos = np.minimum(np.searchsorted(keys, q), keys.shape[0] - 1)
+        return np.where(keys[pos] == q, ids[pos], -1)
+
+    def _learn_sound(self, name: str, clip) -> None:
+        key = name_key(name)
+        if self._key_names.setdefault(key, name) != name:
+            raise KeyError(f"deferred audio: sounds {name!r} and {self._key_names[key]!r} share a CRC-32 key")
+        sid = self._sound(name, clip)
+        order = np.argsort(np.append(self._sound_keys, key), kind="stable")
+        self._sound_keys = np.append(self._sound_keys, key)[order]
+        self._sound_ids = np.append(self._sound_ids, sid)[order]
+        self._tables = None
+
+    def _learn_table(self, rir_key: str) -> None:
+        d = os.path.dirname(rir_key)                        # <binaural_rir_dir>/<azimuth>
+        key = name_key(d)
+        if self._key_names.setdefault(key, d) != d:
+            raise KeyError(f"deferred audio: {d!r} and {self._key_names[key]!r} share a CRC-32 key")
+        tid = len(self._table_dirs)
+        self._table_dirs.append(d)
+        order = np.argsort(np.append(self._table_keys, key), kind="stable")
+        self._table_keys = np.append(self._table_keys, key)[order]
+        self._table_ids = np.append(self._table_ids, tid)[order]
+        self._tables = None
+
+    @staticmethod
+    def _pair_key(table, recv, src):
+        return (table << 40) | (recv << 20) | src
+
+    def _evicted(self, key, slot) -> None:
+        if isinstance(key, tuple) and len(key) == 2 and key[0] == "ix":
+            pos = int(np.searchsorted(self._pair_keys, key[1]))
+            if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == key[1]:
+                self._pair_keys = np.delete(self._pair_keys, pos)
+                self._pair_slots = np.delete(self._pair_slots, pos)
+                self._tables = None
+
+    def _load_pairs(self, pair_keys: np.ndarray, which: np.ndarray, reload: bool = False) -> None:
+        """RIR files of the composite keys at positions `which` -> store slots -> the resident-pair arrays (the slow,
+        first-visit side of the column path: one wav read + one H2D copy per new pose, simulator.py:615-618)"""
+        store = self.engine.store
+        for i in which:
+            k = int(pair_keys[i])
+            t, r, s_ = k >> 40, (k >> 20) & 0xFFFFF, k & 0xFFFFF
+            path = os.path.join(self._table_dirs[t], "{}_{}.wav".format(r, s_))
+            slot = store.slot(("ix", k), lambda path=path: self.rir_reader(path))     # (reloads rows that were clipped)
+            pos = int(np.searchsorted(self._pair_keys, k))
+            if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == k:
+                self._pair_slots[pos] = slot
+            else:
+                self._pair_keys = np.insert(self._pair_keys, pos, k)
+                self._pair_slots = np.insert(self._pair_slots, pos, slot)
+            self._tables = None
+
+    @staticmethod
+    def _records(requests: Sequence[AudioRequest]) -> Optional[bytes]:
+        """the packed records of a step, concatenated (None: some request has none - live RIRs - the step takes the walk)"""
+        try:
+            return b"".join([q.rec for q in requests])
+        except TypeError:
+            return None
+
+    def _request_tables(self):
+        if self._tables is None:
+            store = self.engine.store
+            ctx = self.engine.context()
+            self._tables = ctx.request_tables(self._sound_keys, self._sound_ids, self._table_keys, self._table_ids,
+                                              self._pair_keys, self._pair_slots,
+                                              stale=store._clipped if store.truncate_to is None else None)
+        return self._tables
+
+    def _columns(self, requests: Sequence[AudioRequest], buf: Optional[bytes] = None):
+        """The N requests of a vector step -> unit columns for ``engine.observe_columns`` in numpy, registering what is new:
+        sounds and RIR tables never seen before, poses whose RIR file is not resident yet (the only per-request Python).
+        Engines with ``observe_requests`` run the same lookups in C++ (``ss_ctx_observe_requests``) and come here only for
+        steps that have something to register or load."""
+        if buf is None:
+            buf = self._records(requests)
+            if buf is None:
+                return None
+        n = len(requests)
+        recs = np.frombuffer(buf, np.int64).reshape(n, REC_N)
+        live = recs[:, REC_SILENT] == 0
+        has_dis = live & (recs[:, REC_DIS_SOUND] >= 0)
+        any_dis = bool(has_dis.any())
+        for _ in range(2):
+            sound = self._lookup(self._sound_keys, self._sound_ids, recs[:, REC_SOUND])
+            table = self._lookup(self._table_keys, self._table_ids, recs[:, REC_TABLE])
+            dsound = self._lookup(self._sound_keys, self._sound_ids, recs[:, REC_DIS_SOUND]) if any_dis else None
+            new = live & ((sound < 0) | (table < 0))
+            if any_dis:
+                new |= has_dis & (dsound < 0)
+            if not new.any():
+                break
+            for i in np.flatnonzero(new):                   # first use of a sound / a RIR directory
+                q = requests[i]
+                if sound[i] < 0 and name_key(q.sound) not in self._key_names:
+                    self._learn_sound(q.sound, q.clip)
+                if table[i] < 0 and name_key(os.path.dirname(q.rir_key)) not in self._key_names:
+                    self._learn_table(q.rir_key)
+                if any_dis and has_dis[i] and dsound[i] < 0 and name_key(q.dis_sound) not in self._key_names:
+                    self._learn_sound(q.dis_sound, q.dis_clip)
+        else:
+            raise KeyError("deferred audio: a request names a sound or RIR directory that could not be registered")
+        store = self.engine.store
+        store.begin_batch()
+        tbl = np.where(live, table, 0)
+        pk = self._pair_key(tbl, recs[:, REC_RECV], recs[:, REC_SRC])
+        dpk = self._pair_key(tbl, recs[:, REC_RECV], recs[:, REC_DIS_SRC]) if any_dis else None
+        for attempt in range(2):
+            rir = self._lookup(self._pair_keys, self._pair_slots, pk)
+            drir = self._lookup(self._pair_keys, self._pair_slots, dpk) if any_dis else None
+            used = rir[live & (rir >= 0)]
+            if any_dis:
+                used = np.concatenate([used, drir[has_dis & (drir >= 0)]])
+            store.touch_slots(used)
+            miss = live & (rir < 0)
+            dmiss = has_dis & (drir < 0) if any_dis else None
+            # rows clipped while only 1-s clips existed are reloaded once whole RIRs are needed (RirStore.slot does it)
+            if store.truncate_to is None and used.shape[0] and store._clipped[used].any():
+                miss = miss | (live & (rir >= 0) & store._clipped[np.maximum(rir, 0)])
+                if any_dis:
+                    dmiss = dmiss | (has_dis & (drir >= 0) & store._clipped[np.maximum(drir, 0)])
+            if not (miss.any() or (any_dis and dmiss.any())):
+                break
+            if attempt:
+                raise KeyError("deferred audio: RIR pairs still missing after loading them")
+            self._load_pairs(pk, np.flatnonzero(miss))
+            if any_dis:
+                self._load_pairs(dpk, np.flatnonzero(dmiss))
+        cols = dict(sound=np.where(live, sound, 0), t0=np.where(live, recs[:, REC_T0], 0), rir=np.where(live, rir, -1))
+        if any_dis:
+            cols.update(dis_sound=np.where(has_dis, dsound, 0), dis_rir=np.where(has_dis, drir, -1))
+        return cols
+
     def resolve(self, requests: Sequence[AudioRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None):
         """-> {"spectrogram": [N,65,T4,2], ("audiogoal": [N,2,sr])} device tensors, one launch for all envs."""
+        buf = self._records(requests) if self.columns_ok else None
+        if buf is not None:
+            import torch
+            r = self.engine.renderer
+            n = len(requests)
+            want_audiogoal = want_audiogoal or audiogoal_out is not None
+            if want_spectrogram and spectrogram_out is None:
+                spectrogram_out = torch.empty((n,) + tuple(r.spectrogram_shape), dtype=torch.float32, device=r.device)
+            if want_audiogoal and audiogoal_out is None:
+                audiogoal_out = torch.empty((n, 2, r.out_len), dtype=torch.float32, device=r.device)
+            sg, ag = (spectrogram_out if want_spectrogram else None), (audiogoal_out if want_audiogoal else None)
+            done = False
+            if hasattr(self.engine, "observe_requests"):   # lookups + planner + launch in one C call
+                done = self.engine.observe_requests(buf, n, self._request_tables(), spectrogram_out=sg, audiogoal_out=ag) == 0
+                self.native_steps += done
+            if not done:                                    # something to register / load (or an engine without the C path)
+                self.engine.observe_columns(self._columns(requests, buf), spectrogram_out=sg, audiogoal_out=ag)
+            self.column_steps += 1
+            out = {}
+            if want_spectrogram:
+                out["spectrogram"] = spectrogram_out
+            if want_audiogoal:
+                out["audiogoal"] = audiogoal_out
+            return out
+        self.walk_steps += 1
         return self.engine.observe(self.units(requests), want_audiogoal=want_audiogoal or audiogoal_out is not None,
                                    want_spectrogram=want_spectrogram, spectrogram_out=spectrogram_out,
                                    audiogoal_out=audiogoal_out)
 
-    def resolve_observations(self, observations: Sequence[dict], rollouts=None):
+    def resolve_observations(self, observations: Sequence[dict], rollouts=None, replace: bool = True):
         """Replacement for the audio half of ``batch_obs`` (ss_baselines/common/utils.py:126-153): `observations` is
         the list of per-env dicts the vector env returned; entries under 'spectrogram' / 'audiogoal' that are
         ``AudioRequest`` s are rendered in one launch (into the rollout rows of the next ``insert()`` when `rollouts` is
         given) and REPLACED, per env, by their device tensors (views of the batch), so the dicts can go on to
-        ``batch_obs`` unchanged.  Returns the batched tensors {uuid: [N, ...]}."""
+        ``batch_obs`` unchanged (``replace=False``: trainers that take the audio from the returned batch / the rollout
+        rows leave the requests in the dicts and save the N views).  Returns the batched tensors {uuid: [N, ...]}."""
         keys = [k for k in ("spectrogram", "audiogoal") if observations and isinstance(observations[0].get(k), AudioRequest)]
         if not keys:
             return {}
@@ -205,7 +434,8 @@ class DeferredResolver:
         slots = rollouts.next_observation_slots([k for k in keys if k in rollouts.observations]) if rollouts is not None else {}
         out = self.resolve(reqs, want_audiogoal="audiogoal" in keys, want_spectrogram="spectrogram" in keys,
                            spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
-        for k in keys:
-            for i, obs in enumerate(observations):
-                obs[k] = out[k][i]
+        if replace:
+            for k in keys:
+                for obs, row in zip(observations, out[k].unbind(0)):      # ONE call makes the N row views
+                    obs[k] = row
         return {k: out[k] for k in keys}

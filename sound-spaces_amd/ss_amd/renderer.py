@@ -444,6 +444,7 @@ class RirStore:
                             torch.zeros((slots,), dtype=torch.int32, device=self.device))
         self.slots, self.cap, self.group = slots, cap, group
         self.truncate_to, self.max_cap, self.on_grow = truncate_to, max_cap, on_grow
+        self.on_evict = None                                   # on_evict(key, slot): the entry of `key` is about to be reused
         self.host_len = np.zeros((slots,), np.int32)          # host mirror of bank.lengths (branch selection, planning)
         self._slot_of: Dict[object, int] = {}      # insertion order == LRU order (oldest first)
         self._free: List[int] = list(range(slots - group, -1, -group))
@@ -471,6 +472,9 @@ class RirStore:
 
     def clear(self) -> None:
         """Forget every entry (the rows are rewritten on the next miss)."""
+        if self.on_evict is not None:
+            for key, slot in list(self._slot_of.items()):
+                self.on_evict(key, slot)
         self._slot_of.clear()
         self._free = list(range(self.slots - self.group, -1, -self.group))
         self.host_len[:] = 0
@@ -556,10 +560,24 @@ class RirStore:
         victim = next(iter(self._slot_of))
         slot = self._slot_of[victim]
         if self._batch and self._batch_of[slot] == self._batch:     # (callers that never open a batch: no guard)
-            raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
-                               "(an entry handed out for this launch would be overwritten); raise rir_slots")
+            # the oldest entry is in use by this launch.  Entries marked through touch_slots() (the column paths never
+            # pass through slot(), so the dict order does not know they were used) are skipped: take the oldest entry
+            # that this batch has not handed out
+            for victim, slot in self._slot_of.items():
+                if self._batch_of[slot] != self._batch:
+                    break
+            else:
+                raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
+                                   "(an entry handed out for this launch would be overwritten); raise rir_slots")
         del self._slot_of[victim]
+        if self.on_evict is not None:
+            self.on_evict(victim, slot)
         return slot
+
+    def touch_slots(self, slots: np.ndarray) -> None:
+        """Column paths (``DeferredResolver``, tables of ``RirIndex``) look slots up without going through ``slot()``: this
+        marks them as handed out for the current batch, so that a miss of the same step cannot evict them."""
+        self._batch_of[slots] = self._batch
 
     def slot(self, key, loader, refresh: bool = False) -> int:
         """Bank slot of ``key`` (first slot of its group); ``loader()`` -> float array [L,2] / [2,L] or None (a list of
@@ -842,7 +860,71 @@ class AudioEngine:
     def source_id(self, name: str, clip: np.ndarray) -> int:
         if self.store.truncate_to is not None and np.shape(clip)[0] != self.renderer.sr:
             self.store.truncate_to = None          # from now on whole RIRs; clipped rows reload at their next use
-        return self.renderer.add_source(name, clip)
+        sid = self.renderer.add_source(name, clip)
+        ctx = getattr(self, "_ctx", None)
+        if ctx is not None and name not in ctx._names:
+            cid = ctx.add_source(name, self.renderer.sources._host[sid])
+            assert cid == sid, "the context's sound ids mirror the renderer's"
+        return sid
+
+    # ---- the C++ context over the same banks (column paths: DeferredResolver) ---------------------------------------
+    def context(self):
+        """An ``ss_amd.context.AudioContext`` (planner, window cache and descriptor ring inside libss_hip.so) over THIS
+        engine's source registry and RIR store: same sound ids, same bank slots.  Callers hand it unit COLUMNS
+        (``observe_columns``); the per-unit Python planner of ``observe()`` is not involved."""
+        if getattr(self, "_ctx", None) is None:
+            from .context import AudioContext
+            r = self.renderer
+            if isinstance(self.store, BucketedRirStore):
+                raise NotImplementedError("AudioEngine.context(): length-bucketed stores use ss_ctx_set_rir_buckets directly")
+            ctx = AudioContext(r.sr, n_valid=r.n_valid, wrap=r.wrap, pad_mode=r.pad_mode)
+            for sid, (name, _) in enumerate(sorted(r.sources.names.items(), key=lambda kv: kv[1])):
+                assert ctx.add_source(name, r.sources._host[sid]) == sid
+            self._ctx = ctx
+            self._ctx_bank = None
+            grow = self.store.on_grow
+
+            def on_grow(bank):
+                if grow is not None:
+                    grow(bank)
+                self._ctx_bank = None
+            self.store.on_grow = on_grow
+        return self._ctx
+
+    def _sync_context_bank(self):
+        ctx = self.context()
+        n_sync = self.store.sync_spectra()
+        bank = self.store.bank
+        key = (bank.data.data_ptr(), bank.data.shape[2], None if bank.spectra is None else bank.spectra.data_ptr())
+        if self._ctx_bank != key or n_sync:
+            ctx.set_rir_bank(bank.data, bank.lengths)
+            if bank.spectra is not None and self.store.spectral:
+                ctx.set_rir_spectra(bank.spectra)
+            self._ctx_bank = key
+        return ctx
+
+    def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None) -> int:
+        """One step from the packed request records of ``ss_amd.deferred`` (``ss_ctx_observe_requests``: lookups + planner +
+        launch in one C call).  Returns the number of unresolved requests (0: the step is on the stream)."""
+        ctx = self._sync_context_bank()
+        if getattr(self, "_req_miss", None) is None or self._req_miss["buf"].shape[0] < n:
+            import ctypes
+            buf, cnt = np.zeros((max(n, 256),), np.int32), ctypes.c_int(0)
+            self._req_miss = dict(buf=buf, n=cnt, ptr=buf.ctypes.data, n_ptr=ctypes.addressof(cnt))
+        dev = self.renderer.device
+        stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+        sg = None if spectrogram_out is None else spectrogram_out.data_ptr()
+        ag = None if audiogoal_out is None else audiogoal_out.data_ptr()
+        if torch.cuda.current_device() == (dev.index or 0):
+            return ctx.observe_requests(recs, n, tables, sg, ag, stream, self._req_miss)
+        with torch.cuda.device(dev):
+            return ctx.observe_requests(recs, n, tables, sg, ag, stream, self._req_miss)
+
+    def observe_columns(self, cols: Dict[str, np.ndarray], spectrogram_out=None, audiogoal_out=None) -> None:
+        """One step from unit columns {sound, t0, rir[, dis_sound, dis_rir, last_rir, wrap, last_wrap]} (numpy, one entry
+        per env; rir < 0 = silent) through the context: ONE ctypes call, outputs written into the given device tensors."""
+        ctx = self._sync_context_bank()
+        ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **cols)
 
     def begin_batch(self) -> None:
         self.store.begin_batch()

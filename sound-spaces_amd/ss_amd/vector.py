@@ -163,6 +163,18 @@ class RirIndex:
     def scene_id(self, name: str) -> int:
         return self._names[name]
 
+    def ensure_nodes(self, scene: int, n_nodes: int) -> None:
+        """Grow the table of `scene` to at least n_nodes x n_nodes (scenes registered before their node count is known:
+        the deferred resolver learns the nodes from the requests it sees)."""
+        t = self._tables[scene]
+        if n_nodes <= t.shape[0]:
+            return
+        n = max(n_nodes, 2 * t.shape[0])
+        g = np.full((n, n), -1, np.int32)
+        g[:t.shape[0], :t.shape[0]] = t
+        self._tables[scene] = g
+        self._stale = True
+
     def set(self, scene: int, recv, src, base) -> None:
         self._tables[scene][recv, src] = base
         if self._stale:

@@ -201,3 +201,44 @@ class OracleContext:
                 audiogoal_out[i] = torch.from_numpy(a)
             if spectrogram_out is not None:
                 spectrogram_out[i] = torch.from_numpy(O.compute_spectrogram(a).astype(np.float32))
+
+
+class OracleColumnEngine(OracleEngine):
+    """OracleEngine with the COLUMN surface of ss_amd.renderer.AudioEngine (``store`` = a real RirStore on the CPU,
+    ``observe_columns``), so that DeferredResolver's column path - CRC keys, resident-pair arrays, eviction hook, clipped-row
+    reloads - runs without a GPU; the arithmetic is the oracle's."""
+
+    def __init__(self, sr, slots=64):
+        super().__init__(sr)
+        from ss_amd.renderer import RirStore, UnitRequest
+        self._unit = UnitRequest
+        self.store = RirStore(slots, sr, "cpu", truncate_to=sr, max_cap=1 << 17)
+        self.renderer = NS(spectrogram_shape=O.spectrogram_shape(sr), device=torch.device("cpu"), out_len=sr, sr=sr)
+        self.column_calls = 0
+
+    def source_id(self, name, clip):
+        if self.store.truncate_to is not None and np.shape(clip)[0] != self.sr:
+            self.store.truncate_to = None                  # as AudioEngine.source_id: whole RIRs from now on
+        return super().source_id(name, clip)
+
+    def _row(self, slot):
+        n = int(self.store.host_len[slot])
+        return np.ascontiguousarray(self.store.bank.data[slot, :, :n].numpy().T)
+
+    def observe_columns(self, cols, spectrogram_out=None, audiogoal_out=None):
+        self.column_calls += 1
+        n = len(cols["sound"])
+        units = []
+        self.rirs = {}
+        for i in range(n):
+            if cols["rir"][i] < 0:
+                units.append(self._unit(silent=True))
+                continue
+            u = self._unit(sound=int(cols["sound"][i]), t0=int(cols["t0"][i]), rir=int(cols["rir"][i]))
+            self.rirs[u.rir] = self._row(u.rir)
+            if "dis_rir" in cols and cols["dis_rir"][i] >= 0:
+                u.dis_sound, u.dis_rir = int(cols["dis_sound"][i]), int(cols["dis_rir"][i])
+                self.rirs[u.dis_rir] = self._row(u.dis_rir)
+            units.append(u)
+        self.observe(units, want_audiogoal=audiogoal_out is not None, want_spectrogram=spectrogram_out is not None,
+                     spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)

@@ -9,6 +9,7 @@
 
 #include "hip_shim.h"
 #include "../../sound-spaces_amd/csrc/ss_kernels.hpp"
+#include "../../sound-spaces_amd/csrc/ss_kernels32.hpp"
 #include "../../sound-spaces_amd/csrc/ss_tables.hpp"
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -89,6 +90,8 @@ ssk::Tables host_tables() {
     tb.twItem = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwItemOff);
     tb.tw512 = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTw512Off);
     tb.win = tab.data() + ssk_host::kWinOff;
+    tb.twG = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwGOff);
+    tb.twP2 = reinterpret_cast<const ssk::c32*>(tab.data() + ssk_host::kTwP2Off);
     return tb;
 }
 }  // namespace
@@ -181,6 +184,58 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
             });
             if (rc) return rc;
         }
+    }
+    return 0;
+}
+
+// ---- 512-thread core (ss_kernels32.hpp): window spectra in ITS order + the loop-free row kernel
+int hs_source_windows32(const float* src, const int* desc, float* spec, int n_windows) {
+    ssk::SrcParams p;
+    p.src = src; p.desc = desc; p.spec = reinterpret_cast<ssk::f32x4*>(spec); p.tb = host_tables();
+    p.desc_stride = 4; p.scale = ssk::kWindowScale;
+    gridDim = dim3{(unsigned)n_windows, 1, 1};
+    for (int w = 0; w < n_windows; ++w) {
+        blockIdx = dim3{(unsigned)w, 0, 0};
+        int rc = run_block(ssk::kT32, [&] { ssk::k_source_windows32(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hs_conv32(int fuse, const float* spec, const float* rir, const int* rir_len, const int* desc, float* out,
+              float* sgram, int n_units, long long us, int cs, int es, int cap, int n_valid, int out_len, int pad_mode,
+              int use_tab) {
+    ssk::ConvParams p;
+    p.spec = reinterpret_cast<const ssk::f32x4*>(spec); p.rir = rir; p.rir_len = rir_len; p.desc = desc;
+    p.out = out; p.sgram = sgram; p.tb = host_tables();
+    p.rir_unit_stride = us; p.rir_chan_stride = cs; p.rir_elem_stride = es; p.rir_cap = cap;
+    p.n_valid = n_valid; p.out_len = out_len;
+    p.n_frames = 1 + out_len / ssk::kHop;
+    p.t4 = (p.n_frames + 3) / 4;
+    p.pad_mode = pad_mode;
+    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 1;
+    apply_bucket2(p);
+    p.fade_len = 0;
+    p.nb_y = 1;
+    if (n_valid > ssk::kB || cap > ssk::kB || (fuse && (out_len > ssk::kB || p.t4 > 26))) return -1;
+    if (use_tab) {
+        if (n_units > ssk::kTabUnits) return -2;
+        for (int i = 0; i < n_units; ++i) {
+            const int* d = desc + 8 * i;
+            const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;
+            p.tab[2 * i] = ok ? d[0] : -1;
+            p.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
+        }
+        p.tab_n = n_units;
+    }
+    gridDim = dim3{(unsigned)(2 * n_units), 1, 1};
+    for (int b = 0; b < 2 * n_units; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(ssk::kT32, [&] {
+            if (fuse) { if (use_tab) ssk::k_conv32<true, true>(p); else ssk::k_conv32<true, false>(p); }
+            else { if (use_tab) ssk::k_conv32<false, true>(p); else ssk::k_conv32<false, false>(p); }
+        });
+        if (rc) return rc;
     }
     return 0;
 }

@@ -19,7 +19,7 @@ def lib():
         so = os.path.join(HERE, "libss_hostsim.so")
         srcs = [os.path.join(HERE, f) for f in ("hostsim.cpp", "hip_shim.h")]
         csrc = os.path.join(HERE, "..", "..", "sound-spaces_amd", "csrc")
-        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp")]
+        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             cxx = os.environ.get("SS_HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")   # needs ext_vector_type
             subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
@@ -34,7 +34,7 @@ def _p(a, t):
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
         interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False,
-        bucket2=None):
+        bucket2=None, core32=False, tab=False):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -77,7 +77,8 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
     wd = np.concatenate(rows) if rows else np.zeros((0, 4), np.int32)
     wd = np.ascontiguousarray(wd, np.int32)
     spec = np.zeros((max(1, len(wd)), P.SPEC_FLOATS), np.float32)
-    rc = L.hs_source_windows(_p(flat, ctypes.c_float), _p(wd, ctypes.c_int), _p(spec, ctypes.c_float), len(wd))
+    rc = (L.hs_source_windows32 if core32 else L.hs_source_windows)(_p(flat, ctypes.c_float), _p(wd, ctypes.c_int),
+                                                                    _p(spec, ctypes.c_float), len(wd))
     assert rc == 0, rc
     N = len(units)
     out = np.full((N, 2, out_len), np.nan, np.float32)
@@ -97,6 +98,18 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
         L.hs_set_bucket2(_p(bucket2, ctypes.c_float), R, int(bucket2.shape[2]))
     if crossfade:
         simple = 2
+    if core32:                                           # 512-thread core: the loop-free row kernel only
+        assert simple == 1 and not spectral and not row_wgs and not persist
+        rc = L.hs_conv32(int(fuse), _p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(rl, ctypes.c_int),
+                         _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
+                         _p(sg, ctypes.c_float) if fuse else None, N, ctypes.c_longlong(us), cs, es, cap, n_valid, out_len,
+                         pad_mode, int(tab))
+        assert rc == 0, rc
+        if want_spectrogram and not fuse:
+            L.hs_set_spec_n_valid(int(n_valid))
+            rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
+            assert rc == 0, rc
+        return (out if want_audiogoal else None), (sg if (fuse or want_spectrogram) else None)
     if row_wgs:                                          # k_obs_rows: fused rows of 2-3 blocks, `row_wgs` persistent workgroups
         assert out_len > P.KB and not (crossfade and spectral)
         hb, hspec = 0, None

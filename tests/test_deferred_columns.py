@@ -1,0 +1,137 @@
+"""DeferredResolver's COLUMN path (ss_amd/deferred.py::_columns): the N AudioRequests of a vector step become unit columns
+through their packed records (CRC keys -> ids by searchsorted, resident RIR files by sorted composite keys) and ONE
+``engine.observe_columns`` call - no per-request Python after first use.  CPU: a real RirStore on the host + the oracle's
+arithmetic (tests/fakes.py::OracleColumnEngine); the GPU half is tests/test_gpu_parity.py::test_deferred_column_path_on_gpu.
+Reference arrangement: habitat.VectorEnv workers (ss_baselines/common/env_utils.py:91-107)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from fakes import FakeSim, OracleColumnEngine, OracleEngine
+from oracle import ss_oracle as O
+from ss_amd import deferred
+from ss_amd.deferred import DeferredResolver, attach_deferred
+from test_deferred import SR, apply, make_world, trajectory
+
+
+def drive(n_env, steps, has_distractor, slots, sounds=None, files=None, mutate=None):
+    sounds0, files0 = make_world()
+    sounds, files = sounds or sounds0, files or files0
+    sims = [FakeSim(SR, sounds, files, has_distractor) for _ in range(n_env)]
+    for i, s in enumerate(sims):
+        s._current_distractor_sound = "dist.wav"
+        attach_deferred(s, env_rank=i)
+    fast_eng, slow_eng = OracleColumnEngine(SR, slots=slots), OracleEngine(SR)
+    fast = DeferredResolver(fast_eng, rir_reader=files.get)
+    slow = DeferredResolver(slow_eng, rir_reader=files.get, fast=False)
+    assert fast.columns_ok and not slow.columns_ok
+    trajs = [trajectory(r, steps) for r in range(n_env)]
+    for k in range(steps):
+        for r, s in enumerate(sims):
+            apply(s, k, trajs[r][k])
+            if mutate:
+                mutate(k, r, s)
+        reqs = [pickle.loads(pickle.dumps(s.get_current_spectrogram_observation(None))) for s in sims]
+        assert all(len(q.rec) == 8 * deferred.REC_N for q in reqs)
+        a = fast.resolve(reqs, want_audiogoal=True)
+        b = slow.resolve(reqs, want_audiogoal=True)
+        assert torch.allclose(a["audiogoal"], b["audiogoal"], atol=1e-6), k
+        assert torch.allclose(a["spectrogram"], b["spectrogram"], atol=1e-6), k
+    assert fast.column_steps == steps and fast.walk_steps == 0 and fast_eng.column_calls == steps
+    return fast, fast_eng
+
+
+@pytest.mark.parametrize("has_distractor", [False, True])
+def test_column_path_equals_the_request_walk(has_distractor):
+    fast, eng = drive(3, 9, has_distractor, slots=64)
+    # every resident pair is one wav read; the second visit of a pose reads nothing
+    assert eng.store.misses == fast._pair_keys.shape[0]
+
+
+def test_column_path_under_eviction_keeps_its_index_consistent():
+    # 6 slots for 3 envs that wander over 32 (receiver, azimuth) poses: every step evicts; an evicted pair must be reloaded,
+    # never looked up at its old slot, and a slot in use by the step must not be taken for another unit of the same step
+    fast, eng = drive(3, 12, False, slots=6)
+    assert eng.store.misses > 6 and fast._pair_keys.shape[0] <= 6
+    live = {k[1] for k in eng.store._slot_of if isinstance(k, tuple) and k[0] == "ix"}
+    assert live == set(fast._pair_keys.tolist())
+    for k, slot in zip(fast._pair_keys.tolist(), fast._pair_slots.tolist()):
+        assert eng.store._slot_of[("ix", k)] == slot
+
+
+def test_clipped_rows_reload_when_the_first_long_clip_arrives():
+    # rows stored while only 1-s clips existed are clipped to sr samples (exact for them, simulator.py:629-632); the first
+    # multi-second clip needs whole RIRs (:634-647): the column path reloads the clipped rows it is about to use
+    rng = np.random.default_rng(9)
+    sounds, files = make_world()
+    files = {k: np.ascontiguousarray(O.synth_rir(rng, SR, length=SR + 3000, n=1)[0].T) for k in files}      # RIRs > 1 s
+    fast, eng = drive(2, 9, False, slots=64, files=files)
+    assert eng.store.truncate_to is None and not eng.store._clipped.any()
+
+
+def test_requests_without_records_take_the_walk():
+    sounds, files = make_world()
+    sim = FakeSim(SR, sounds, files)
+    attach_deferred(sim, env_rank=0)
+    eng = OracleColumnEngine(SR)
+    res = DeferredResolver(eng, rir_reader=files.get)
+    q = sim.get_current_spectrogram_observation(None)
+    q2 = pickle.loads(pickle.dumps(q))
+    q2.rec = None                                           # e.g. a request from a worker running an older ss_amd
+    a = res.resolve([q2], want_audiogoal=True)
+    assert res.walk_steps == 1 and res.column_steps == 0
+    b = res.resolve([q], want_audiogoal=True)
+    assert res.column_steps == 1
+    assert torch.allclose(a["spectrogram"], b["spectrogram"], atol=1e-6)
+    with pytest.raises(ValueError):
+        DeferredResolver(OracleEngine(SR), fast=True)
+
+
+def test_cpp_request_lookup_equals_the_numpy_columns():
+    """ss_ctx_requests_units (the host half of ss_ctx_observe_requests: CRC keys -> ids, resident pairs, stale rows by
+    binary search in C++) against DeferredResolver._columns on the same records; misses are reported, not guessed."""
+    from ss_amd.context import AudioContext
+    sounds, files = make_world()
+    n_env, steps = 5, 7                                       # (steps beyond _duration = 6 are silent)
+    sims = [FakeSim(SR, sounds, files, True) for _ in range(n_env)]
+    for i, s in enumerate(sims):
+        s._current_distractor_sound = "dist.wav"
+        attach_deferred(s, env_rank=i)
+    eng = OracleColumnEngine(SR, slots=64)
+    res = DeferredResolver(eng, rir_reader=files.get)
+    ctx = AudioContext(SR)
+    trajs = [trajectory(r, steps) for r in range(n_env)]
+    saw_miss = False
+    for k in range(steps):
+        for r, s in enumerate(sims):
+            apply(s, k, trajs[r][k])
+        reqs = [s.get_current_spectrogram_observation(None) for s in sims]
+        buf = res._records(reqs)
+
+        def tables():
+            return ctx.request_tables(res._sound_keys, res._sound_ids, res._table_keys, res._table_ids, res._pair_keys,
+                                      res._pair_slots, stale=eng.store._clipped if eng.store.truncate_to is None else None)
+        before, miss = ctx.requests_units(buf, n_env, tables())
+        cols = res._columns(reqs, buf)                          # registers / loads whatever the step needs
+        for name, clip in zip(eng.names, eng.sources):          # the context mirrors the engine's sound ids
+            ctx.add_source_len(name, len(clip))
+        want_miss = [i for i, q in enumerate(reqs) if not q.silent]
+        if k == 0:
+            assert miss.tolist() == want_miss                   # nothing registered yet: every live request is a miss
+        saw_miss |= len(miss) > 0
+        after, miss2 = ctx.requests_units(buf, n_env, tables())
+        assert miss2.shape[0] == 0
+        for name in ("sound", "t0", "rir"):
+            np.testing.assert_array_equal(after[name], cols[name])
+        if "dis_rir" in cols:
+            np.testing.assert_array_equal(after["dis_rir"], cols["dis_rir"])
+            np.testing.assert_array_equal(after["dis_sound"], cols["dis_sound"])
+    assert saw_miss
+    # a stale row (clipped while only 1-s clips existed) is a miss for the C++ lookup too
+    stale = np.zeros((64,), bool)
+    stale[int(after["rir"][after["rir"] >= 0][0])] = True
+    t = ctx.request_tables(res._sound_keys, res._sound_ids, res._table_keys, res._table_ids, res._pair_keys, res._pair_slots,
+                           stale=stale)
+    assert ctx.requests_units(buf, n_env, t)[1].shape[0] >= 1

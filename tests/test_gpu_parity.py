@@ -1168,3 +1168,46 @@ def test_crossfade_44k_reference_run_vector_both_forms():
     ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg1, r.n_valid, r.out_len, r.pad_mode,
                        flags=plan.flags)
     check(sg1[0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spectral", [False, True])
+def test_deferred_column_path_on_gpu(spectral):
+    """DeferredResolver on the C++ context (ss_amd/deferred.py::_columns -> AudioEngine.observe_columns -> ss_ctx_observe): the
+    requests of a vector step become unit columns without a per-request walk; results equal the walk (Python planner) and
+    the oracle; a store of 8 slots for 4 envs wandering over 32 poses evicts under the index; distractor + a 3-s clip whose
+    arrival reloads the rows that had been clipped to 1 s.  Reference arrangement: ss_baselines/common/env_utils.py:91-107."""
+    import pickle
+    from fakes import FakeSim
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.renderer import AudioEngine
+    from test_deferred import SR, apply, make_world, trajectory
+    sounds, files = make_world()
+    n_env, steps = 4, 10
+    sims = [FakeSim(SR, sounds, files, has_distractor=True) for _ in range(n_env)]
+    for i, s in enumerate(sims):
+        s._current_distractor_sound = "dist.wav"
+        attach_deferred(s, env_rank=i)
+    fast = DeferredResolver(AudioEngine(SR, device=DEV, rir_slots=8, rir_spectral=spectral), rir_reader=files.get)
+    slow = DeferredResolver(AudioEngine(SR, device=DEV, rir_slots=64), rir_reader=files.get, fast=False)
+    assert fast.columns_ok
+    trajs = [trajectory(r, steps) for r in range(n_env)]
+    for k in range(steps):
+        for r, s in enumerate(sims):
+            apply(s, k, trajs[r][k])
+        reqs = [pickle.loads(pickle.dumps(s.get_current_spectrogram_observation(None))) for s in sims]
+        a = fast.resolve(reqs, want_audiogoal=True)
+        b = slow.resolve(reqs, want_audiogoal=True)
+        ag, sg = a["audiogoal"].cpu().numpy(), a["spectrogram"].cpu().numpy()
+        check(ag, b["audiogoal"].cpu().numpy())
+        check(sg, b["spectrogram"].cpu().numpy())
+        if k in (0, 5):                                      # and against the oracle, per env
+            for r, (s, q) in enumerate(zip(sims, reqs)):
+                if q.silent:
+                    assert not ag[r].any()
+                    continue
+                want = O.conv_window_fft(sounds[q.sound], files[q.rir_key], q.t0, SR) + \
+                    O.conv_window_fft(sounds[q.dis_sound], files[q.dis_rir_key], 0, SR)
+                check(ag[r], want.astype(np.float32))
+    assert fast.column_steps == steps and fast.walk_steps == 0 and slow.walk_steps == steps
+    assert fast.engine.store.misses > 8                      # evictions happened under the resident-pair arrays

@@ -613,3 +613,46 @@ def test_zero_pooled_blocks_are_written_not_computed_at_any_step_length(sr, n_va
             check(out[0], ref)
             check(sg[0], ref_s)
             assert (sg[0][ref_s == 0] == 0).all()                         # the written zeros are exact
+
+
+# ---- the 512-thread / 32-values-per-thread core (ss_fft_core32.hpp, ss_kernels32.hpp) ---------------------------------
+@pytest.mark.parametrize("name", SIM_CASES)
+def test_core32_sim_branches_vs_reference_vectors(name):
+    d = case_inputs(name)
+    sr = d["sr"]
+    if d["rir"].shape[0] > P.KB:
+        pytest.skip("the loop-free kernel serves RIRs of one block")
+    ref_a, ref_s, stride = case_outputs(name)
+    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
+    for tab in (False, True):
+        out, sg = hs.run([d["source"]], planar(d["rir"]), [d["rir"].shape[0]], [dict(sound=0, t0=t0, rir=0)],
+                         sr, sr, fuse=True, core32=True, tab=tab)
+        check(out[0][:, ::stride], ref_a)
+        check(sg[0], ref_s)
+
+
+def test_core32_equals_1024_thread_core_on_a_mixed_batch():
+    # silent unit, empty RIR, ragged lengths, interleaved (wav) bank layout, a 0.25-s step, fused and unfused
+    rng = np.random.default_rng(11)
+    sr = 16000
+    srcs = O.synth_sources(rng, sr, k=3)
+    bank = np.zeros((4, 2, sr), np.float32)
+    lens = [sr, 5000, 0, 12345]
+    for i, L in enumerate(lens):
+        if L:
+            bank[i, :, :L] = O.synth_rir(rng, sr, length=L, n=1)[0]
+    units = [dict(sound=0, t0=0, rir=0), dict(rir=-1), dict(sound=1, t0=0, rir=1), dict(sound=2, t0=0, rir=2),
+             dict(sound=1, t0=0, rir=3)]
+    for n_valid in (sr, 4000):
+        a_ref, s_ref = hs.run(srcs, bank, lens, units, n_valid, sr, fuse=True)
+        for kw in (dict(fuse=True), dict(fuse=True, tab=True), dict(fuse=False, want_spectrogram=True),
+                   dict(fuse=True, interleaved=True), dict(fuse=True, pad_mode=1)):
+            if kw.get("pad_mode"):
+                a_ref2, s_ref2 = hs.run(srcs, bank, lens, units, n_valid, sr, fuse=True, pad_mode=1)
+            else:
+                a_ref2, s_ref2 = a_ref, s_ref
+            a, sg = hs.run(srcs, bank, lens, units, n_valid, sr, core32=True, **kw)
+            assert O.relerr(a, a_ref2) <= 2e-6, O.relerr(a, a_ref2)
+            assert O.relerr(sg, s_ref2) <= 2e-6, O.relerr(sg, s_ref2)
+            assert not a[1].any() and not a[3].any()          # silent unit / empty RIR: exact zeros
+            assert not a[:, :, n_valid:].any()
