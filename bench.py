@@ -284,6 +284,15 @@ def measure_deferred_path(torch, np, dev, sr, n_envs, bank, sources, steps, warm
     total = warmup + steps
     acts = rng.integers(0, 3, (total, n_envs))
     nodes = rng.integers(0, n_nodes, (total, n_envs))
+    # scene load: every pose once (wav read + H2D per pose in real use), so that the timed steps are steady-state ones
+    poses = [(r_, s_, az) for r_ in range(n_nodes) for s_ in range(n_nodes) for az in range(4)]
+    for lo in range(0, len(poses), n_envs):
+        part = poses[lo:lo + n_envs]
+        for sim, (r_, s_, az) in zip(sims, part):
+            sim._receiver_position_index, sim._source_position_index, sim._rotation_angle = r_, s_, 90 * az
+            sim._episode_step_count += 1                  # (a new simulator state: a new request)
+        res.resolve([sim.get_current_spectrogram_observation(None) for sim in sims[:len(part)]])
+    torch.cuda.synchronize()
     out = {}
     for name, replace in (("trainer_rollout_rows", False), ("trainer_rollout_rows_and_per_env_views", True)):
         w_us, t_us = [], []
@@ -419,6 +428,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams that consecutive steps alternate between; 0 = auto: 1 on one GPU (per-launch durations "
                          "stay comparable with the rocprofv3 kernel trace), 2 when the all-gather overlaps the kernels")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="timed regions of --steps steps each for the headline pass (value = the median region); 0 = auto: 25 "
+                         "when --steps <= 50 (a 20-step region is 0.5 ms), else 1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
@@ -478,8 +490,9 @@ def main():
     N = n_env * args.rotations                               # units per GPU per step
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sr, args.cpu_seconds)          # before any CUDA context exists (fork-safe)
+    if rank == 0 and not args.no_cpu_baseline:                # rank 0 of ANY world size: an N > 1 line carries it too (the
+        cpu = cpu_baseline(sr, args.cpu_seconds)          # other ranks wait at the first barrier); before any CUDA context
+                                                          # exists (fork-safe)
 
     import numpy as np
     import torch
@@ -518,7 +531,12 @@ def main():
             r.add_source(f"sound{i}", clip)
     bank = synth_rir_bank_device(torch, R, sr, L, dev, seed=7 + rank)
     r.set_rir_bank(RirBank(bank, torch.full((R,), L, dtype=torch.int32, device=dev)))
-    total = args.warmup + args.steps
+    # Short timed regions (the driver's --steps 20 is half a millisecond of GPU time, with ~50 us of launch / sync latency at
+    # its two ends: twelve runs of one build spread +-3.5 %): the headline times REGIONS regions of EXACTLY --steps steps
+    # each - every region bracketed by barrier + synchronize like the one region of the contract, fresh unit columns per
+    # region - and reports the MEDIAN region (value_spread: the others).  --steps > 50: one region, as before.
+    REGIONS = args.regions if args.regions > 0 else (25 if args.steps <= 50 else 1)
+    total = args.warmup + REGIONS * args.steps
     rot = args.rotations
 
     # ---- the steps: unit columns {sound, t0, rir, (distractor)} per step, drawn once; the SAME columns feed the product
@@ -561,7 +579,7 @@ def main():
 
     spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128) * 16000 // sr)
 
-    def run_loop(S, gather_every, spectral, per_step_events=False, lanes=0):
+    def run_loop(S, gather_every, spectral, per_step_events=False, lanes=0, regions=1):
         """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms per step from
         HIP events on the launch stream: the region average, or the per-step list with per_step_events; note).
         lanes = 0: pre-planned descriptors through the stateless entry points on S torch streams (kernel-rate passes; with
@@ -662,34 +680,44 @@ def main():
             step(k)
         flush()
         fence()
-        n_ev = args.steps + 1 if per_step_events else 2
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] if S == 1 else None
-        t_start = time.perf_counter()
-        if evs:
-            evs[0].record(streams[0])
-        for k in range(args.warmup, total):
-            step(k)
-            if evs and per_step_events:
-                evs[k - args.warmup + 1].record(streams[0])
-        if use_ctx and lanes == 1:
-            ctx.join()
-        if evs and not per_step_events and not (use_ctx and lanes > 1):   # (overlapped lanes: wall clock only, no closing event:
-            evs[1].record(streams[0])                                      #  it would need the lanes joined into this stream)
-        flush()
-        fence()
-        elapsed = time.perf_counter() - t_start
-        per_step = None
-        if evs and not (use_ctx and lanes > 1):
-            per_step = ([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if per_step_events
-                        else [evs[0].elapsed_time(evs[1]) / args.steps])
+        region_s, region_ev = [], []
+        timed_events = S == 1 and not (use_ctx and lanes > 1)      # (overlapped lanes: wall clock only - a closing event
+        for rg in range(regions):                                  #  would need the lanes joined into this stream)
+            k0 = args.warmup + rg * args.steps
+            n_ev = args.steps + 1 if per_step_events else 2
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] if timed_events else None
+            t_start = time.perf_counter()
+            if evs:
+                evs[0].record(streams[0])
+            for k in range(k0, k0 + args.steps):
+                step(k)
+                if evs and per_step_events:
+                    evs[k - k0 + 1].record(streams[0])
+            if use_ctx and lanes == 1:
+                ctx.join()
+            if evs and not per_step_events:
+                evs[1].record(streams[0])
+            flush()
+            fence()                                                # barrier + device synchronise: also the cut between regions
+            region_s.append(time.perf_counter() - t_start)
+            if evs:
+                region_ev.append([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if per_step_events
+                                 else [evs[0].elapsed_time(evs[1]) / args.steps])
         if world > 1:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+            tmax = torch.tensor(region_s, device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)            # per region: the slowest rank
+            region_s = [float(v) for v in tmax.tolist()]
+        elapsed = float(np.median(region_s))
+        per_step = None
+        if region_ev:
+            per_step = region_ev[0] if per_step_events else [float(np.median([e[0] for e in region_ev]))]
         if use_ctx:
             ctx.set_overlap(1)
+        state["regions"] = region_s
+        last_regions[:] = region_s
         return elapsed, per_step, note
 
+    last_regions = []
     spectra = None
     if args.spectral or not args.no_secondary:
         r.rirs.build_spectra()
@@ -701,14 +729,15 @@ def main():
     def rate(e):
         return {"value": round(world * N * args.steps / e, 1), "ms_per_step": round(1e3 * e / args.steps, 5)}
     # ---- headline: the product path (one call site, ss_ctx_observe, overlap mode), exchange on when there are ranks ------
-    elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, lanes=LANES)
+    elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, lanes=LANES, regions=REGIONS)
+    head_regions = list(last_regions)
     side = {}
     step_dist = None
     # ---- the kernel's own rate: pre-planned descriptors, ONE stream - per-launch durations are separable only without
     # overlap, and this is the average the rocprofv3 kernel trace of the same command reports for the kernel
     per_step = None
     if rank == 0 or world > 1:
-        e_k, per_step, _ = run_loop(1, 0, args.spectral)
+        e_k, per_step, _ = run_loop(1, 0, args.spectral, regions=REGIONS)
         side["preplanned_single_stream"] = dict(rate(e_k), note="stateless entry point, descriptors planned outside the timed "
                                                 "region, one stream: the kernel rate (r1 / r2 headline protocol)")
     if world == 1 and not args.no_secondary:
@@ -772,6 +801,12 @@ def main():
             "unit": "env-steps/s",
             "n_gpus": world, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0, "steps": args.steps, "warmup": args.warmup, "spinup_steps_untimed": spin_steps,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+            "timed_regions": len(head_regions),
+            "value_spread": (None if len(head_regions) < 2 else
+                             {"regions": len(head_regions), "each": f"{args.steps} steps between barrier + synchronize",
+                              "value": "median region",
+                              **{k_: round(world * N * args.steps / float(np.quantile(head_regions, q_)), 1)
+                                 for k_, q_ in (("min", 1.0), ("p10", 0.9), ("p90", 0.1), ("max", 0.0))}}),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
@@ -780,7 +815,9 @@ def main():
                                                  + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)
                                                  + (2 * sr * 4 if (fused and want_ag) else 0)),
                        "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
-                       "path": "ss_ctx_observe (planner + window cache + descriptor ring inside the timed region), "
+                       "path": "AudioContext.observe_prepared -> ss_ctx_observe (planner + window cache + descriptor ring inside "
+                               "the timed region; the steps' unit columns were converted to the C struct ss_units OUTSIDE it, "
+                               "AudioContext.prepare: a vector env that owns its columns), "
                                f"{LANES} internal stream(s)" + (", consecutive steps overlap" if LANES > 1 else ""),
                        "streams": LANES, "kernel": kname},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -830,8 +867,7 @@ def main():
             out["plugin_path"]["headline"] = dict(out["plugin_path"]["bound_sims"], mode="bound_sims")
             out["plugin_path"]["ceiling"] = dict(out["plugin_path"]["columns"], mode="columns")
             # the reference's default arrangement: worker processes + one resolver in the trainer (ss_amd/deferred.py)
-            out["plugin_path"]["deferred"] = measure_deferred_path(torch, np, dev, sr, n_env, bank, srcs,
-                                                                   min(args.steps, 200), min(args.warmup, 20))
+            out["plugin_path"]["deferred"] = measure_deferred_path(torch, np, dev, sr, n_env, bank, srcs, 200, 20)
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_all_cores"] = round(out["value"] / cpu["value"], 1)

@@ -190,8 +190,12 @@ int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mod
  * neither ss_amd/planning.py nor the opaque spectrum slots of the entry points above.
  *
  * A context is bound to the HIP device that is current when it is created.  Calls must come from one host thread at a time;
- * consecutive calls may name different streams (the library orders the shared window-spectra pool between them), and
- * ss_ctx_set_overlap lets the library alternate two internal streams itself.
+ * consecutive calls may name different streams (the library orders the shared window-spectra pool between them: on a
+ * stream change it records an event on the PREVIOUS call's stream, so a stream handed to ss_ctx_observe must stay alive
+ * until a later call on another stream has returned, or the context is destroyed), and ss_ctx_set_overlap lets the library
+ * alternate two internal streams itself.  hipStreamPerThread is not accepted for rows longer than one block (one handle,
+ * a different stream per thread).  ss_ctx_plan is a planner-only / test entry: after it the next ss_ctx_observe synchronises
+ * the device and starts from an empty window cache.
  * ---------------------------------------------------------------------------------------------------------------*/
 typedef struct ss_ctx ss_ctx;
 

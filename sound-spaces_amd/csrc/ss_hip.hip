@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -27,6 +28,16 @@ DeviceTables g_tables[kMaxDevices];
 std::mutex g_mu;
 
 inline int hip_err(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
+
+// A/B switches for benchmarking (scripts/gpu_ab_*.sh) exist only in -DSS_AB builds: the product library reads no
+// environment variables ("benchmark knobs inside a shipped .so")
+#if defined(SS_AB)
+inline bool ab_flag(const char* name) { return std::getenv(name) != nullptr; }
+inline int ab_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+#else
+constexpr bool ab_flag(const char*) { return false; }
+constexpr int ab_int(const char*, int dflt) { return dflt; }
+#endif
 
 int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
     int dev = 0;
@@ -67,16 +78,15 @@ inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kP
 // kernel arguments (ConvParams::tab).  Callers of the stateless entry points hand over device pointers only: nullptr.
 thread_local const int* g_host_desc = nullptr;
 
-inline void fill_unit_tab(ssk::ConvParams& p, const int* host_desc, int n_units) {
-    p.tab_n = 0;
-    if (!host_desc || n_units > ssk::kTabUnits) return;
+inline bool fill_unit_tab(ssk::UnitTab<true>& ut, const int* host_desc, int n_units) {
+    if (!host_desc || n_units > ssk::kTabUnits) return false;
     for (int i = 0; i < n_units; ++i) {
         const int* d = host_desc + 8 * i;
         const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;          // window m = 0 of the unit's key is stored
-        p.tab[2 * i] = ok ? d[0] : -1;
-        p.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
+        ut.tab[2 * i] = ok ? d[0] : -1;
+        ut.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
     }
-    p.tab_n = n_units;
+    return true;
 }
 
 template <bool FUSE>
@@ -93,20 +103,20 @@ int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, 
     // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
     const bool planar = p.rir_elem_stride == 1 && !(p.rir_cap & 1) && !(reinterpret_cast<size_t>(p.rir) & 7) &&
                         !(p.rir_unit_stride & 1) && !(p.rir_chan_stride & 1) && p.rir_cap >= 2;
-    static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
+    static const bool no_rows = ab_flag("SS_HIP_NO_ROW_KERNEL");
     if constexpr (!FUSE) {              // the fused kernel gains nothing from it (measured), see k_conv_rows
         if (simple && planar && !no_rows && 2 * n_units > n_cus) {
             hipLaunchKernelGGL(ssk::k_conv_rows, dim3(n_cus), block, 0, st, p, 2 * n_units);
             return hip_err(hipGetLastError());
         }
     }
-    if (flags & SS_FLAG_CROSSFADE) hipLaunchKernelGGL((ssk::k_conv<FUSE, false, true>), grid, block, 0, st, p);
+    if (flags & SS_FLAG_CROSSFADE) hipLaunchKernelGGL((ssk::k_conv<FUSE, false, true>), grid, block, 0, st, p, ssk::UnitTab<false>());
     else if (simple) {
-        fill_unit_tab(p, g_host_desc, n_units);
-        if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv<FUSE, true, false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p);
+        ssk::UnitTab<true> ut;
+        if (fill_unit_tab(ut, g_host_desc, n_units)) hipLaunchKernelGGL((ssk::k_conv<FUSE, true, false, true>), grid, block, 0, st, p, ut);
+        else hipLaunchKernelGGL((ssk::k_conv<FUSE, true>), grid, block, 0, st, p, ssk::UnitTab<false>());
     }
-    else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((ssk::k_conv<FUSE, false>), grid, block, 0, st, p, ssk::UnitTab<false>());
     return hip_err(hipGetLastError());
 }
 
@@ -118,6 +128,8 @@ struct StashBuf { float* ptr = nullptr; size_t bytes = 0; };
 std::map<std::pair<int, hipStream_t>, StashBuf> g_stash;
 
 int get_stash(hipStream_t st, size_t bytes, float** out) {
+    // one handle for a different stream on every thread: two concurrent launches would share one stash
+    if (st == hipStreamPerThread) return SS_EINVAL;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_err(e);
@@ -136,6 +148,18 @@ int get_stash(hipStream_t st, size_t bytes, float** out) {
     }
     *out = b.ptr;
     return 0;
+}
+
+// a stream is about to be destroyed (the context's overlap lanes): its stash goes with it (~96 MiB per lane
+// leaked by every create / destroy of a context with overlap); the caller has synchronised the stream
+void drop_stash(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_stash.find(std::make_pair(dev, st));
+    if (it == g_stash.end()) return;
+    if (it->second.ptr) (void)hipFree(it->second.ptr);
+    g_stash.erase(it);
 }
 
 // should k_obs_rows serve this shape?  (rows of 2 or 3 blocks, stash mask of 32 bits.)  Rows with ONE rendered block
@@ -187,9 +211,9 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
 template <bool FUSE>
 int launch_conv32(ssk::ConvParams& p, int n_units, hipStream_t st) {
     const dim3 grid(2 * n_units), block(ssk::kT32);
-    fill_unit_tab(p, g_host_desc, n_units);
-    if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv32<FUSE, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((ssk::k_conv32<FUSE, false>), grid, block, 0, st, p);
+    ssk::UnitTab<true> ut;
+    if (fill_unit_tab(ut, g_host_desc, n_units)) hipLaunchKernelGGL((ssk::k_conv32<FUSE, true>), grid, block, 0, st, p, ut);
+    else hipLaunchKernelGGL((ssk::k_conv32<FUSE, false>), grid, block, 0, st, p, ssk::UnitTab<false>());
     return hip_err(hipGetLastError());
 }
 
@@ -203,13 +227,23 @@ int ss_version(void) { return 1; }
 
 // Frees the per-(device, stream) scratch k_obs_rows keeps (see get_stash); synchronises the device first.
 int ss_release_scratch(void) {
-    hipError_t e = hipDeviceSynchronize();
+    int cur = 0;
+    hipError_t e = hipGetDevice(&cur);
     if (e != hipSuccess) return hip_err(e);
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_stash)
-        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    g_stash.clear();
-    return 0;
+    int rc = 0;
+    for (auto& kv : g_stash) {                                  // every entry's OWN device is synchronised before its free
+        if (!kv.second.ptr) continue;
+        e = hipSetDevice(kv.first.first);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = hip_err(e); continue; }    // (left allocated: a launch may still be using it)
+        (void)hipFree(kv.second.ptr);
+        kv.second.ptr = nullptr;
+        kv.second.bytes = 0;
+    }
+    for (auto it = g_stash.begin(); it != g_stash.end();) it = it->second.ptr ? std::next(it) : g_stash.erase(it);
+    (void)hipSetDevice(cur);
+    return rc;
 }
 
 int ss_init(void) {
@@ -274,7 +308,7 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.hspec = nullptr;
     p.h_blocks = 0;
     // default on: the two ears of a unit (same window spectrum) share an XCD's L2; SS_HIP_XCD_MAP=0 is the A/B switch
-    static const int xcd_map = getenv("SS_HIP_XCD_MAP") ? atoi(getenv("SS_HIP_XCD_MAP")) : 1;
+    static const int xcd_map = ab_int("SS_HIP_XCD_MAP", 1);
     p.xcd_map = xcd_map;
     p.stash = nullptr;
     p.stash_nbh = 0;
@@ -282,7 +316,6 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.n_terms = 2;
     p.n_buckets = 1;
     for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
-    p.tab_n = 0;
 #if defined(SS_LADDER)                                     // profiling builds only (scripts/gpu_ladder.sh compiles with -DSS_LADDER)
     static const int dbg = getenv("SS_HIP_DBG") ? atoi(getenv("SS_HIP_DBG")) : 0;
     p.dbg = dbg;
@@ -529,7 +562,7 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
     p.nb_y = nb_y;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1 &&
                         (p.n_buckets == 1 || (flags & SS_FLAG_FIRST_BUCKET));
-    static const bool no_rows = getenv("SS_HIP_NO_ROW_KERNEL") != nullptr;          // A/B switch for benchmarking
+    static const bool no_rows = ab_flag("SS_HIP_NO_ROW_KERNEL");
     if constexpr (!FUSE) {              // more rows than CUs: persistent workgroups prefetching the next row's H'
         if (simple && !no_rows && n_cus > 0 && n_units > n_cus && !(reinterpret_cast<size_t>(p.hspec) & 15)) {
             hipLaunchKernelGGL(ssk::k_conv_spec_rows, dim3(n_cus), dim3(ssk::kT), 0, st, p, 2 * n_units);
@@ -538,10 +571,10 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
     }
     const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
     if (simple) {
-        fill_unit_tab(p, g_host_desc, n_units);
-        if (p.tab_n > 0) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p);
-    } else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p);
+        ssk::UnitTab<true> ut;
+        if (fill_unit_tab(ut, g_host_desc, n_units)) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true, true>), grid, block, 0, st, p, ut);
+        else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true>), grid, block, 0, st, p, ssk::UnitTab<false>());
+    } else hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, false>), grid, block, 0, st, p, ssk::UnitTab<false>());
     return hip_err(hipGetLastError());
 }
 
@@ -629,6 +662,7 @@ static void ctx_free_device(ssctx::Context& c) {
     if (c.lanes_made) {
         for (int l = 0; l < ssctx::kLanes; ++l) {
             (void)hipStreamSynchronize(c.lane_stream[l]);
+            drop_stash(c.lane_stream[l]);                       // k_obs_rows' per-(device, stream) scratch of this lane
             (void)hipEventDestroy(c.ev_lane[l]);
             (void)hipEventDestroy(c.ev_win[l]);
             (void)hipStreamDestroy(c.lane_stream[l]);
@@ -732,7 +766,8 @@ int ss_ctx_plan(ss_ctx* h, const ss_units* units, int n, int* unit_desc_out, int
     ssctx::PlanResult res;
     int rc = ssctx::plan_units(h->c, units, n, unit_desc_out, &res);
     if (rc) return rc;
-    if (res.n_new_windows > 0) h->c.plan_only_keys = true;       // keys now in the cache whose spectra nobody computes
+    h->c.plan_only_keys = true;       // keys in the cache whose spectra nobody computes, a tick without a ring slot: the
+                                      // next ss_ctx_observe starts from an empty cache (after a device synchronise)
     if (flags_out) *flags_out = res.flags;
     if (n_new_windows_out) *n_new_windows_out = res.n_new_windows;
     if (new_windows_out) {
@@ -819,7 +854,12 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e;
     if (c.plan_only_keys) {                                    // ss_ctx_plan was used on this context: its keys claim
-        ssctx::cache_reset(c);                                 // spectra that were never computed - start from an empty cache
+        // spectra that were never computed, and its ticks took no ring slot (the eviction guard of the overlap mode counts
+        // ticks as ring slots) - start from an empty cache, and only once nothing in flight reads the pool (a
+        // reset under two lanes let lane A's k_source_windows write slots lane B was still reading)
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return hip_err(e);
+        ssctx::cache_reset(c);
         c.plan_only_keys = false;
     }
     // The window-spectra pool is shared by every step: a step on a NEW stream reads spectra the previous stream wrote
@@ -868,7 +908,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     // workgroup over the host link) - an upload between two launches on the stream costs a blit kernel plus a barrier on
     // either side of it (measured: ~15 us of idle GPU per 25-us step).  Large steps (several descriptors per workgroup,
     // long kernels) keep the upload.
-    static const bool force_copy = std::getenv("SS_HIP_DESC_COPY") != nullptr;
+    static const bool force_copy = ab_flag("SS_HIP_DESC_COPY");
     const bool direct = !force_copy && n <= ssctx::kDirectDescUnits;
     int* hd = c.h_desc + static_cast<size_t>(k) * c.ring_cap * 8;
     int* dd = direct ? hd : c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
@@ -932,7 +972,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         }
         audiogoal = c.ag_scratch;
     }
-    static const bool no_tab = std::getenv("SS_HIP_NO_UNIT_TAB") != nullptr;         // A/B switch for benchmarking
+    static const bool no_tab = ab_flag("SS_HIP_NO_UNIT_TAB");
     g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
     if (!c.buckets.empty()) {
         const int nb = static_cast<int>(c.buckets.size());

@@ -878,17 +878,24 @@ struct ConvParams {
     // bucket per term from the wave-uniform bank index (scalar compares, no memory access).
     int n_buckets;
     BankBucket bk[kMaxBuckets - 1];
-    // Loop-free kernels, launches of <= kTabUnits units whose descriptors the HOST knows (the context API): the two words a
-    // SIMPLE row needs - {bank index | -1, window-spectrum slot} - ride in the kernel-argument block itself, so the chain in
-    // front of the row's first loads is ONE scalar fetch (arguments) instead of arguments -> descriptor (which for the
-    // context's in-place descriptors is a round trip over the host link) -> length word.  Read by the TAB instantiations only
-    // (k_conv<.., SIMPLE, .., TAB>, k_conv_spec<.., SIMPLE, TAB>); tab_n = 0: the launcher picked the plain ones.
-    int tab_n;
-    int tab[2 * kTabUnits];
 #if defined(SS_LADDER)
     int dbg;                     // timing experiments only (scripts/gpu_ladder.sh, -DSS_LADDER builds): early exit point
 #endif
 };
+
+// Loop-free kernels, launches of <= kTabUnits units whose descriptors the HOST knows (the context API): the two words a
+// SIMPLE row needs - {bank index | -1, window-spectrum slot} - ride in the kernel-argument block itself, so the chain in
+// front of the row's first loads is ONE scalar fetch (arguments) instead of arguments -> descriptor (which for the
+// context's in-place descriptors is a round trip over the host link) -> length word.  A kernel argument of its OWN, passed
+// to the TAB instantiations only (k_conv<.., SIMPLE, .., TAB>, k_conv_spec<.., SIMPLE, TAB>, k_conv32<.., TAB>): every
+// other launch keeps a kernarg block of a few hundred bytes (inside ConvParams the 2 KiB went up with every
+// launch of every kernel and sat next to the 4 KiB kernarg limit).
+template <bool TAB>
+struct UnitTab { };
+template <>
+struct UnitTab<true> { int tab[2 * kTabUnits]; };
+static_assert(sizeof(ConvParams) <= 512, "ConvParams is passed by value to every conv kernel: keep it small");
+static_assert(sizeof(ConvParams) + sizeof(UnitTab<true>) + 64 <= 4096, "kernel arguments of the TAB instantiations");
 
 // Workgroup b of a 1-D launch runs on XCD b % 8 (MI355X_MICROARCH: observed dispatch order, for speed only).  Dealing
 // the (unit, ear) rows out in that order puts the two ears of a unit - which read the SAME 128 KiB window spectrum -
@@ -1117,7 +1124,7 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
 // current RIR (term 0) and the head of the row becomes prev*(fade-n)/fade + cur*n/fade.  One launch, and in the
 // fused kernel the spectrogram is taken from the blended row without it ever leaving the CU.
 template <bool FUSE, bool SIMPLE, bool XFADE = false, bool TAB = false>
-__global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
+__global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = UnitTab<TAB>()) {
     static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
     static_assert(!TAB || SIMPLE, "the unit table serves the loop-free kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
@@ -1146,8 +1153,8 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
     c32 y[8];
     bool any = false;
     if (SIMPLE) {
-        constexpr bool tab = TAB;                           // (an instantiation of its own: no run-time test in either prologue)
-        const int ridx = tab ? p.tab[2 * unit] : __builtin_amdgcn_readfirstlane(d[0]);
+        int ridx;
+        if constexpr (TAB) ridx = ut.tab[2 * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
         bool active = false;
         if (ridx >= 0) {
             const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
@@ -1165,8 +1172,8 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p) {
             // word: its row is zero up to the capacity, so its convolution comes out as exact zeros (as in k_conv_spec)
             int slot0 = 0;
             bool ok = true;
-            if (tab) {
-                slot0 = p.tab[2 * unit + 1];
+            if constexpr (TAB) {
+                slot0 = ut.tab[2 * unit + 1];
             } else {
                 const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
                 const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
@@ -1324,7 +1331,7 @@ __device__ __forceinline__ void spec_block_product(const f32x4* spec, int t, con
 }
 
 template <bool FUSE, bool SIMPLE, bool TAB = false>
-__global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
+__global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p, UnitTab<TAB> ut = UnitTab<TAB>()) {
     static_assert(!TAB || SIMPLE, "the unit table serves the loop-free kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
@@ -1369,7 +1376,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p) {
     const size_t row_f4 = (size_t)p.h_blocks * (kSpecComplex / 2);     // f32x4 per (entry, ear)
     if (SIMPLE) {
         i32x4 dw;
-        if (TAB) dw = i32x4{p.tab[2 * unit], p.tab[2 * unit + 1], 0, 1};            // {index | -1, slot of window 0, m_min, count}
+        if constexpr (TAB) dw = i32x4{ut.tab[2 * unit], ut.tab[2 * unit + 1], 0, 1};            // {index | -1, slot of window 0, m_min, count}
         else dw = uniform_load4(d);
         const int ridx = dw.x;
         if (ridx >= 0) {

@@ -91,7 +91,7 @@ constexpr int kConv32LdsComplex = kLds32Complex + kTwP2;
 static_assert(8 * kWaveScratch <= kConv32LdsComplex, "the 8 wave scratches of the STFT phase overlay the FFT buffer");
 
 template <bool FUSE, bool TAB>
-__global__ __launch_bounds__(512) void k_conv32(ConvParams p) {
+__global__ __launch_bounds__(512) void k_conv32(ConvParams p, UnitTab<TAB> ut = UnitTab<TAB>()) {
     alignas(16) __shared__ c32 lds[kConv32LdsComplex];
     __shared__ float s_win[FUSE ? kNfft : 1];
     alignas(16) __shared__ c32 s_tw512[FUSE ? kTw512Lds : 1];
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p) {
         wq = p.tb.twM[64 * (t & 15)];
     }
     c32 y[16];
-    constexpr bool tab = TAB;
-    const int ridx = tab ? p.tab[2 * unit] : __builtin_amdgcn_readfirstlane(d[0]);
+    int ridx;
+    if constexpr (TAB) ridx = ut.tab[2 * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
     bool active = false;
     if (ridx >= 0) {
         const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p) {
         }
         int slot0 = 0;
         bool ok = true;
-        if (tab) {
-            slot0 = p.tab[2 * unit + 1];
+        if constexpr (TAB) {
+            slot0 = ut.tab[2 * unit + 1];
         } else {
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);

@@ -782,7 +782,15 @@ class BucketedRirStore:
         for i, key in enumerate(keys):
             b = self._where.get(key)
             if b is not None and key in self.stores[b]._slot_of:
-                out[i] = self.first[b] + self.stores[b].slot(key, loaders[i])
+                st = self.stores[b]
+                sl = st._slot_of[key]
+                if st.truncate_to is None and st._clipped[sl:sl + self.group].any():
+                    # a row clipped while only 1-s clips existed must be re-read WHOLE, and the whole RIR may belong to a
+                    # longer bucket: through slot(), which re-buckets it (the sub-store's own reload raised
+                    # 'exceeds max_cap' for a multi-second RIR sitting in bucket 0)
+                    out[i] = self.slot(key, loaders[i])
+                else:
+                    out[i] = self.first[b] + st.slot(key, loaders[i])
             else:
                 todo.append(i)
         uniq = list({keys[i]: i for i in reversed(todo)}.values())[::-1]

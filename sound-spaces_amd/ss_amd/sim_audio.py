@@ -80,11 +80,14 @@ def _render_to_host(backend, req, want_spectrogram: bool):
 
 
 class HipSimAudio:
+    _ids = __import__("itertools").count()
+
     def __init__(self, sim, engine, rir_reader: Callable[[str], Optional[np.ndarray]] = wav_rir_reader):
         """engine: ss_amd.renderer.AudioEngine (or any object with source_id / rir_slot / observe)."""
         self.sim = sim
         self.engine = engine
         self.rir_reader = rir_reader
+        self._env_id = next(HipSimAudio._ids)        # stable key of this env's live RIR row (USE_RENDERED_OBSERVATIONS False)
         for name in ("_audiogoal_cache", "_spectrogram_cache"):
             if not isinstance(getattr(sim, name, None), dict):
                 setattr(sim, name, {})
@@ -94,15 +97,16 @@ class HipSimAudio:
     def sr(self) -> int:
         return int(self.sim.config.AUDIO.RIR_SAMPLING_RATE)
 
-    def _rir_slot(self, source_index) -> int:
+    def _rir_slot(self, source_index, from_file: bool = False) -> int:
         sim = self.sim
-        if sim.config.USE_RENDERED_OBSERVATIONS:
+        if from_file or sim.config.USE_RENDERED_OBSERVATIONS:
             path = os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle),
-                                "{}_{}.wav".format(sim._receiver_position_index, source_index))      # :615-616
+                                "{}_{}.wav".format(sim._receiver_position_index, source_index))      # :615-616, :650-651
             return self.engine.rir_slot(path, lambda: self.rir_reader(path))
-        # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded
+        # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded.  The key is a
+        # counter drawn at attach time: id(sim) can be handed to another simulator once this one is collected
         rir = np.transpose(np.array(sim._sim.get_sensor_observations()["audio_sensor"]))
-        return self.engine.rir_slot(("live", id(sim), source_index), lambda: rir, refresh=True)
+        return self.engine.rir_slot(("live", self._env_id), lambda: rir, refresh=True)
 
     def unit_request(self) -> UnitRequest:
         """The request _compute_audiogoal would serve right now.  Advances ``_audio_index`` exactly where the
@@ -123,7 +127,7 @@ class HipSimAudio:
         if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :649
             dclip = sim._source_sound_dict[sim._current_distractor_sound]
             req.dis_sound = self.engine.source_id(sim._current_distractor_sound, dclip)
-            req.dis_rir = self._rir_slot(sim._distractor_position_index)
+            req.dis_rir = self._rir_slot(sim._distractor_position_index, from_file=True)   # always the wav file (:650-658)
         return req
 
     def _joint_index(self):

@@ -49,6 +49,18 @@ class FakeSim:
     def reader(self, path):
         return self.rir_files.get(path)
 
+    def use_live_rirs(self, rir_fn):
+        """simulator.py:625-626: USE_RENDERED_OBSERVATIONS False - the RIR of the current pose comes from the habitat_sim
+        audio sensor ([2][L] nested lists) instead of a wav file; `rir_fn(call number)` plays the ray tracer."""
+        self.config.USE_RENDERED_OBSERVATIONS = False
+        self.live_calls = 0
+
+        def get_sensor_observations():
+            self.live_calls += 1
+            return {"audio_sensor": rir_fn(self.live_calls - 1)}
+        self._sim = NS(get_sensor_observations=get_sensor_observations)
+        return self
+
 
 class FakeContinuousSim:
     """The attributes of soundspaces.continuous_simulator.ContinuousSoundSpacesSim that its audio code touches

@@ -103,7 +103,6 @@ static int g_b2_first = 0, g_b2_cap = 0;
 static void apply_bucket2(ssk::ConvParams& p) {
     p.n_buckets = 1;
     for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
-    p.tab_n = 0;
     if (g_b2_rir) {
         p.n_buckets = 2;
         p.bk[0] = ssk::BankBucket{g_b2_rir, nullptr, g_b2_first, g_b2_cap, (g_b2_cap + ssk::kB - 1) / ssk::kB, 0};
@@ -218,22 +217,22 @@ int hs_conv32(int fuse, const float* spec, const float* rir, const int* rir_len,
     p.fade_len = 0;
     p.nb_y = 1;
     if (n_valid > ssk::kB || cap > ssk::kB || (fuse && (out_len > ssk::kB || p.t4 > 26))) return -1;
+    ssk::UnitTab<true> ut;
     if (use_tab) {
         if (n_units > ssk::kTabUnits) return -2;
         for (int i = 0; i < n_units; ++i) {
             const int* d = desc + 8 * i;
             const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;
-            p.tab[2 * i] = ok ? d[0] : -1;
-            p.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
+            ut.tab[2 * i] = ok ? d[0] : -1;
+            ut.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
         }
-        p.tab_n = n_units;
     }
     gridDim = dim3{(unsigned)(2 * n_units), 1, 1};
     for (int b = 0; b < 2 * n_units; ++b) {
         blockIdx = dim3{(unsigned)b, 0, 0};
         int rc = run_block(ssk::kT32, [&] {
-            if (fuse) { if (use_tab) ssk::k_conv32<true, true>(p); else ssk::k_conv32<true, false>(p); }
-            else { if (use_tab) ssk::k_conv32<false, true>(p); else ssk::k_conv32<false, false>(p); }
+            if (fuse) { if (use_tab) ssk::k_conv32<true, true>(p, ut); else ssk::k_conv32<true, false>(p); }
+            else { if (use_tab) ssk::k_conv32<false, true>(p, ut); else ssk::k_conv32<false, false>(p); }
         });
         if (rc) return rc;
     }

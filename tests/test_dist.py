@@ -244,3 +244,95 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+# ---- RCCL on a real multi-GPU box ---------------------------------------------------------------
+# One process per GPU, backend "nccl" (= RCCL on ROCm), world size 2: the arrangement of the reference's DD-PPO launcher
+# (ss_baselines/av_nav/ddppo/ddppo_trainer.py:140-142, ss_baselines/av_nav/single_node.sh:8-11).  The gpurun boxes have ONE
+# GPU, so these skip there; the first multi-GPU box that runs `pytest -m gpu` exercises RCCL without a code change.
+def _rccl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = f"cuda:{rank}"
+    try:
+        from ss_amd.dist import ChunkedSlabExchange, PeerCopyExchange, SlabExchange
+        ok = True
+        n_local = 16
+        ex = SlabExchange((n_local, 65, 26, 2), device=dev)                      # all_gather_into_tensor over xGMI
+        for k in range(6):
+            slab = ex.next_local()
+            slab.fill_(float(100 * k + rank))
+            full = ex.gather()
+            ex.wait()
+            torch.cuda.synchronize()
+            for r in range(world):
+                ok &= bool((full[r * n_local:(r + 1) * n_local] == 100 * k + r).all())
+        for cls in (SlabExchange, PeerCopyExchange):                             # the bench's chunked schedule on both transports
+            seen = []
+            cx = ChunkedSlabExchange(4, (65, 26, 2), 3, device=dev, exchange_cls=cls,
+                                     gathered=lambda full, n: seen.append((full, n)))
+            for k in range(7):
+                cx.step_rows().fill_(float(1000 * rank + k))
+                cx.step_done()
+                if seen:
+                    full, n_steps = seen.pop()
+                    cx.exchange.wait()
+                    torch.cuda.synchronize()
+                    for r in range(world):
+                        blk = full[r * 12:(r + 1) * 12]
+                        for i in range(n_steps):
+                            ok &= bool((blk[i * 4:(i + 1) * 4] == 1000 * r + (k - n_steps + 1) + i).all())
+            cx.flush()
+            torch.cuda.synchronize()
+            full, n_steps = seen.pop()
+            for r in range(world):
+                ok &= bool((full[r * 12:r * 12 + 4] == 1000 * r + 6).all()) and n_steps == 1
+            dist.barrier()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _need_two_gpus():
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs on one node (RCCL over xGMI); this box has %d" %
+                    (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+
+
+@pytest.mark.gpu
+def test_rccl_slab_and_peer_copy_exchange_two_gpus():
+    _need_two_gpus()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["allgather", "none"])
+def test_bench_two_gpus_over_rccl(exchange):
+    """`bench.py --gpus 2` as the driver would run it on a multi-GPU node: two ranks, RCCL, one JSON line whose value is the
+    whole-job aggregate and which still carries the CPU baseline (rank 0)."""
+    _need_two_gpus()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--exchange", exchange], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["roofline"]["frac"] > 0

@@ -1211,3 +1211,107 @@ def test_deferred_column_path_on_gpu(spectral):
                 check(ag[r], want.astype(np.float32))
     assert fast.column_steps == steps and fast.walk_steps == 0 and slow.walk_steps == steps
     assert fast.engine.store.misses > 8                      # evictions happened under the resident-pair arrays
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("has_distractor", [False, True])
+def test_live_rir_branch_on_gpu(has_distractor):
+    """soundspaces/simulator.py:625-626 (USE_RENDERED_OBSERVATIONS False: the RIR of the pose comes from the habitat_sim
+    audio sensor) on the real engine: eager adapter, batched observer and deferred mode, an episode each, vs the oracle;
+    the distractor keeps reading its wav file (:650-658)."""
+    import pickle
+    from fakes import NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.renderer import AudioEngine
+    from test_live_rir import SR, check_episode, episode
+
+    def eager(sim, files):
+        sim_audio.attach(sim, AudioEngine(SR, device=DEV, rir_slots=8), rir_reader=files.get)
+        sg = sensors.SpectrogramSensor(sim=sim, config=NS())
+        ag = sensors.AudioGoalSensor(sim=sim, config=NS())
+        if has_distractor:                                   # (no per-pose cache with a distractor: one fused call)
+            return lambda s: s._ss_hip_audio._compute(True)
+
+        def both(s):
+            a = ag.get_observation(observations=None, episode=None)
+            return a, sg.get_observation(observations=None, episode=None)     # audiogoal cached -> stand-alone spectrogram kernel
+        return both
+
+    def batched(sim, files):
+        eng = AudioEngine(SR, device=DEV, rir_slots=8)
+        back = sim_audio.attach(sim, eng, rir_reader=files.get)
+        obs = sim_audio.VectorAudioObserver(eng, [back], want_audiogoal=True)
+
+        def observe(s):
+            o = obs.observe()
+            return o["audiogoal"][0].cpu().numpy(), o["spectrogram"][0].cpu().numpy()
+        return observe
+
+    def deferred(sim, files):
+        attach_deferred(sim, env_rank=0)
+        res = DeferredResolver(AudioEngine(SR, device=DEV, rir_slots=8), rir_reader=files.get)
+        sg = sensors.SpectrogramSensor(sim=sim, config=NS())
+
+        def observe(s):
+            req = pickle.loads(pickle.dumps(sg.get_observation(observations=None, episode=None)))
+            out = res.resolve([req], want_audiogoal=True)
+            return out["audiogoal"][0].cpu().numpy(), out["spectrogram"][0].cpu().numpy()
+        return observe
+
+    for make in (eager, batched, deferred):
+        check_episode(episode(make, has_distractor), tol=TOL)
+
+
+@pytest.mark.gpu
+def test_core32_kernels_vs_oracle_and_1024_thread_core():
+    """The 512-thread / 32-values-per-thread FFT core (csrc/ss_fft_core32.hpp; ss_source_windows32_f32 + ss_audio_obs32_f32)
+    on 96 units incl. silent units, empty and ragged RIRs, a 0.25-s step: audiogoal and spectrogram against the 1024-thread
+    kernels on the same inputs and, for a sample of units, the oracle (soundspaces/simulator.py:629-632, tasks/nav.py:86-100)."""
+    import ctypes
+    from ss_amd import _lib
+    from ss_amd.renderer import BatchedAudioRenderer, RirBank
+    sr, N, R = 16000, 96, 40
+    rng = np.random.default_rng(12)
+    clips = O.synth_sources(rng, sr, k=7)
+    for n_valid in (sr, 4000):
+        r = BatchedAudioRenderer(sr, device=DEV, step_time=None if n_valid == sr else n_valid / sr)
+        for i, c in enumerate(clips):
+            r.add_source(str(i), c)
+        lens = rng.integers(2000, sr + 1, R)
+        lens[3] = 0
+        lens[5] = sr
+        rirs = [O.synth_rir(rng, sr, length=int(L), n=1)[0].T if L else None for L in lens]
+        bank = RirBank.from_arrays(rirs, DEV, cap=sr)
+        r.set_rir_bank(bank)
+        sound, ridx = rng.integers(0, 7, N), rng.integers(0, R, N)
+        ridx[[4, 17]] = -1                                                      # silent units
+        plan = r.plan_arrays(sound, np.zeros(N, np.int64), ridx)
+        ag0, sg0 = r.render(plan, want_audiogoal=True)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        s32 = torch.zeros_like(r._spec)
+        for (sid, t0, wrap), (slot, ws) in r._windows.items():
+            wd = torch.from_numpy(np.ascontiguousarray(P.window_desc_rows(ws, r.sources.offsets[sid], r.sources.lengths[sid], wrap))).to(DEV)
+            assert lib.ss_source_windows32_f32(r.sources.flat().data_ptr(), wd.data_ptr(), s32[slot:slot + len(wd)].data_ptr(),
+                                               len(wd), stream) == 0
+        ag1, sg1 = torch.full_like(ag0, 7.0), torch.full_like(sg0, 7.0)
+        cap = bank.cap
+        assert lib.ss_audio_obs32_f32(s32.data_ptr(), bank.data.data_ptr(), bank.lengths.data_ptr(), plan.desc.data_ptr(),
+                                      ag1.data_ptr(), sg1.data_ptr(), N, 2 * cap, cap, 1, cap, n_valid, sr, 0, stream) == 0
+        torch.cuda.synchronize()
+        a0, a1, g0, g1 = (t.cpu().numpy() for t in (ag0, ag1, sg0, sg1))
+        check(a1, a0)
+        check(g1, g0)
+        for u in (4, 17):
+            assert not a1[u].any() and not g1[u].any()
+        assert not a1[:, :, n_valid:].any()
+        for u in range(0, N, 13):
+            if ridx[u] < 0 or lens[ridx[u]] == 0:
+                assert not a1[u].any()
+                continue
+            ref = O.conv_window_fft(clips[sound[u]], rirs[ridx[u]], 0, n_valid)
+            check(a1[u][:, :n_valid], ref.astype(np.float32))
+            full = np.zeros((2, sr), np.float32)
+            full[:, :n_valid] = ref
+            check(g1[u], O.compute_spectrogram(full))
