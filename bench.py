@@ -449,6 +449,11 @@ def main():
                     help="no GPU, no kernels: the multi-rank launch / exchange / JSON flow on CPU tensors over gloo (tests only; "
                          "the line says dry_run and its value is not a measurement)")
     ap.add_argument("--with-audiogoal", action="store_true", help="also materialise the [N,2,sr] waveform")
+    ap.add_argument("--features", default=None,
+                    help="comma list of logmel,gccphat: the STFT-derived extension features of BASELINE configs[4] (savi: "
+                         "'GCC-PHAT + log-mel fused sensor'), produced INSIDE the timed region by one k_features launch per step "
+                         "on the step's stream (ss_ctx_observe_features); default: both for --workload savi, none otherwise; "
+                         "'none' switches them off")
     ap.add_argument("--workload", choices=["audiogoal", "savi"], default="audiogoal",
                     help="audiogoal: the headline shape (1-s clips, no distractor).  savi: BASELINE configs[4] (semantic_audionav): "
                          "21 sounds of 1-20 s (all windowing branches of simulator.py:629-647), a distractor on every env "
@@ -462,6 +467,9 @@ def main():
     elif args.config == "cfg4":
         args.envs, args.sr, args.rotations, args.workload = 256, 16000, 1, "savi"
 
+    feats = args.features if args.features is not None else ("logmel,gccphat" if args.workload == "savi" else "none")
+    feats = [f for f in feats.split(",") if f and f != "none"]
+    assert all(f in ("logmel", "gccphat") for f in feats), "--features: logmel, gccphat"
     # --gpus N is a request, not a label: without a torch.distributed environment this process becomes the launcher of N
     # ranks (one per GPU; ss_baselines/av_nav/single_node.sh:8-11 does the same with torch.distributed.launch)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -501,6 +509,7 @@ def main():
     from ss_amd import planning as P
     from ss_amd.dist import ChunkedSlabExchange, PeerCopyExchange
     from ss_amd.renderer import BatchedAudioRenderer, RirBank
+    from ss_amd import ops as ops_mod
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
     local_dev = local_rank % torch.cuda.device_count()
@@ -576,6 +585,19 @@ def main():
         ctx.add_source(f"sound{i}", r.sources._host[i])
     ctx.set_rir_bank(bank, lengths_dev)
     preps, spin_preps = [ctx.prepare(**c) for c in cols], [ctx.prepare(**c) for c in spin_cols]
+    feat_sets = None
+    if feats:
+        assert fused and sr <= P.KB, "--features: rows of one block (16 kHz)"
+        args.with_audiogoal = want_ag = True                   # the features read the step's waveform
+        n_mels = 64
+        ms_np, mw_np, _ = P.mel_filterbank_sparse(sr, n_mels)
+        mel_start, mel_w = torch.from_numpy(ms_np).to(dev), torch.from_numpy(mw_np).to(dev)
+        T_fr = 1 + sr // 160
+        feat_sets = []
+        for _ in range(2):                                     # one output set per lane of the overlap mode
+            lm = torch.empty((N, n_mels, T_fr, 2), dtype=torch.float32, device=dev) if "logmel" in feats else None
+            gc = torch.empty((N, 65, T_fr), dtype=torch.float32, device=dev) if "gccphat" in feats else None
+            feat_sets.append(ctx.features(lm, mel_start, mel_w, 1e-6, gc, 32, 1e-8))
 
     spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128) * 16000 // sr)
 
@@ -610,10 +632,15 @@ def main():
         main_stream = torch.cuda.current_stream(dev).cuda_stream
 
         def render(k, plans, columns, rows, ag):
-            if use_ctx:                                            # (unit columns converted to the C struct once, above)
+            if use_ctx and feat_sets is not None:
+                ctx.observe_prepared_features(columns[k], rows.data_ptr(), ag.data_ptr(), main_stream, feat_sets[k & 1])
+            elif use_ctx:                                          # (unit columns converted to the C struct once, above)
                 ctx.observe_prepared(columns[k], rows.data_ptr(), None if ag is None else ag.data_ptr(), main_stream)
             else:
                 r.render(plans[k], spectrogram_out=rows, audiogoal_out=ag)
+                if feat_sets is not None:                          # same two launches as the product path, pre-planned units
+                    fk = feat_sets[k & 1]["keep"]
+                    ops_mod.audio_features_into(ag, None, fk[0], fk[3], fk[1], fk[2])
 
         def step(k, plans=descs, columns=preps):
             st = streams[k % S]
@@ -632,7 +659,10 @@ def main():
             n_sg, n_ag = len(sg_ptrs), len(ag_ptrs)
 
             def step(k, plans=descs, columns=preps):               # noqa: F811
-                ctx.observe_prepared(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream)
+                if feat_sets is not None:
+                    ctx.observe_prepared_features(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream, feat_sets[k & 1])
+                else:
+                    ctx.observe_prepared(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream)
 
         def fence():
             # (torch.cuda.synchronize() is a DEVICE synchronise: it covers the context's internal streams as well; joining
@@ -787,9 +817,14 @@ def main():
         bpu = (b["fused"] + (2 * sr * 4 if args.with_audiogoal else 0)) if fused else b["conv"] + b["spec"]
         if savi:
             bpu = 2 * (2 * L * 4) + 2 * sr * 4 + 65 * t4 * 2 * 4        # two RIRs read, waveform and spectrogram written
+        if feats:                                             # k_features: the waveform read once more, the features written
+            T_fr = 1 + sr // 160
+            bpu += 2 * sr * 4 + (64 * T_fr * 2 * 4 if "logmel" in feats else 0) + (65 * T_fr * 4 if "gccphat" in feats else 0)
+            kname += " + k_features<" + ",".join(feats) + "> (two launches per step: avg_launch_ms is their sum)"
         ach = bpu * N / (kernel_ms * 1e-3) / 1e9
         workload = (("savi semantic_audionav shape: 21 sounds of 1-20 s, a distractor on every env (2 convolutions + add), "
-                     "audiogoal AND spectrogram written; " if savi else "") +
+                     "audiogoal AND spectrogram written" + (", + " + " + ".join(feats) + " (64 mels / 65 lags per frame) from one "
+                                                            "k_features launch per step" if feats else "") + "; " if savi else "") +
                     f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, " +
                     ("" if savi else f"1-s source clips ({args.sounds} sounds), ") +
                     f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident"
@@ -819,7 +854,7 @@ def main():
                                "the timed region; the steps' unit columns were converted to the C struct ss_units OUTSIDE it, "
                                "AudioContext.prepare: a vector env that owns its columns), "
                                f"{LANES} internal stream(s)" + (", consecutive steps overlap" if LANES > 1 else ""),
-                       "streams": LANES, "kernel": kname},
+                       "streams": LANES, "kernel": kname, "features": feats or None},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
                          "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5),

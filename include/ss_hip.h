@@ -147,6 +147,18 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
                              const int* unit_desc, float* audiogoal, float* spectrogram, int n_units, int n_valid,
                              int out_len, int pad_mode, int flags, void* stream);
 
+/* EXTENSION, one pass for every STFT-derived feature (BASELINE.json configs[4] "GCC-PHAT + log-mel fused sensor"): each
+ * (unit, ear, frame) of x [n_units, 2, len] is framed, windowed and transformed ONCE (both ears in one wave), and from that
+ * one spectrum the kernel writes any subset of
+ *   spectrogram [n_units, 65, T4, 2]            as ss_spectrogram_f32 (the reference's compute_spectrogram, nav.py:86-100)
+ *   logmel      [n_units, n_mels, T, 2]         as ss_logmel_f32  (n_mels <= 64; larger banks: ss_logmel_f32)
+ *   gccphat     [n_units, 2*max_lag+1, T]       as ss_gccphat_f32
+ * (NULL = not wanted; at least one).  Same arguments and results as the three stand-alone entry points, which each re-read
+ * the waveform and redo the STFT. */
+int ss_audio_features_f32(const float* x, int n_units, int len, int pad_mode, float* spectrogram, float* logmel,
+                          const int* mel_start, const float* mel_w, int n_mels, int max_len, float mel_eps,
+                          float* gccphat, int max_lag, float gcc_eps, void* stream);
+
 /* ---- The loop-free case on the 512-thread FFT core (round 4; csrc/ss_fft_core32.hpp) ------------------------------------
  * Rows of ONE partition block from a time-domain bank of rir_cap <= kB, no distractor / cross-fade terms - SoundSpaces 1.0
  * with 1-s clips (simulator.py:629-632) - on a 512-thread / 32-values-per-thread transform (16384 = 32*32*16: two LDS
@@ -242,6 +254,22 @@ int ss_ctx_set_rir_buckets(ss_ctx* ctx, const ss_rir_bucket* buckets, int n_buck
 /* One step.  audiogoal [n,2,sr] and spectrogram [n,65,T4,2] are device buffers; either may be NULL (not both).
  * Asynchronous on `stream`; the host arrays of `units` may be reused as soon as the call returns. */
 int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream);
+/* One step plus its STFT-derived extension features (BASELINE.json configs[4]: savi, "GCC-PHAT + log-mel fused sensor"): as
+ * ss_ctx_observe, then ss_audio_features_f32 over the step's waveform on the SAME stream (in overlap mode: the same internal
+ * lane), so the features need no join of their own.  audiogoal must be given (the features read it); logmel / gccphat of
+ * `f` may each be NULL. */
+typedef struct ss_features {
+    float* logmel;            /* [n, n_mels, 1 + sr/160, 2] or NULL */
+    const int* mel_start;     /* device, [n_mels]          (ss_logmel_f32's band-sparse filter bank) */
+    const float* mel_w;       /* device, [n_mels, max_len] */
+    int n_mels, max_len;
+    float mel_eps;
+    float* gccphat;           /* [n, 2*max_lag+1, 1 + sr/160] or NULL */
+    int max_lag;
+    float gcc_eps;
+} ss_features;
+int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram,
+                            const ss_features* f, void* stream);
 /* Overlap mode.  ss_ctx_set_overlap(ctx, 2): consecutive ss_ctx_observe calls run on two internal streams in turn, each
  * ordered behind what the CALLER's stream holds at the time of the call (the consumers of the output rows it overwrites,
  * uploads of the RIR rows it reads), so the head of step k+1 (descriptor and row loads: HBM latency, nothing to compute)

@@ -14,6 +14,7 @@
 #include "ss_context.hpp"
 #include "ss_kernels.hpp"
 #include "ss_kernels32.hpp"
+#include "ss_features.hpp"
 #include "ss_tables.hpp"
 
 namespace {
@@ -420,6 +421,48 @@ int ss_gccphat_f32(const float* x, float* out, int n_units, int len, int pad_mod
     p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
     const int chunks = (groups + p.gpw - 1) / p.gpw;
     hipLaunchKernelGGL(ssk::k_gccphat, dim3(n_units * chunks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hip_err(hipGetLastError());
+}
+
+int ss_audio_features_f32(const float* x, int n_units, int len, int pad_mode, float* spectrogram, float* logmel,
+                          const int* mel_start, const float* mel_w, int n_mels, int max_len, float mel_eps, float* gccphat,
+                          int max_lag, float gcc_eps, void* stream) {
+    if (n_units == 0) return 0;
+    if (!x || n_units < 0 || len < ssk::kNfft / 2 + 1 || (!spectrogram && !logmel && !gccphat)) return SS_EINVAL;
+    if (pad_mode != SS_PAD_REFLECT && pad_mode != SS_PAD_CONSTANT) return SS_EINVAL;
+    if (logmel && (!mel_start || !mel_w || n_mels < 1 || n_mels > ssk::kFeatMaxMels || max_len < 4 ||
+                   max_len > ssk::kFeatMaxLen || (max_len & 3) || n_mels * max_len > ssk::kFeatMelTable || !(mel_eps > 0.f) ||
+                   (reinterpret_cast<size_t>(mel_w) & 15)))
+        return SS_EINVAL;
+    if (gccphat && (max_lag < 1 || max_lag > ssk::kGccMaxLag || !(gcc_eps > 0.f))) return SS_EINVAL;
+    ssk::FeatParams p;
+    int rc = get_tables(&p.tb);
+    if (rc) return rc;
+    p.x = x; p.sgram = spectrogram; p.mel = logmel; p.gcc = gccphat;
+    p.mel_start = mel_start; p.mel_w = mel_w;
+    p.len = len; p.n_frames = n_frames_of(len); p.t4 = t4_of(len); p.pad_mode = pad_mode;
+    p.n_mels = logmel ? n_mels : 0; p.max_len = logmel ? max_len : 4; p.max_lag = gccphat ? max_lag : 1;
+    p.mel_eps = mel_eps; p.gcc_eps = gcc_eps;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    // two ~80 KiB workgroups per CU: with more (unit, group) rounds than that, a workgroup walks several groups of its unit
+    // (tables staged once, the next round's segments prefetched) so that the launch is ONE wave of resident workgroups
+    int n_cus = 256;
+    { ssk::Tables unused; (void)get_tables(&unused, &n_cus); }
+    long long gpw = ((long long)n_units * groups + 2LL * n_cus - 1) / (2LL * n_cus);
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    const dim3 grid(n_units * chunks), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int which = (logmel ? 1 : 0) | (spectrogram ? 2 : 0) | (gccphat ? 4 : 0);
+    switch (which) {
+        case 1: hipLaunchKernelGGL((ssk::k_features<true, false, false>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((ssk::k_features<false, true, false>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((ssk::k_features<true, true, false>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((ssk::k_features<false, false, true>), grid, block, 0, st, p); break;
+        case 5: hipLaunchKernelGGL((ssk::k_features<true, false, true>), grid, block, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((ssk::k_features<false, true, true>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((ssk::k_features<true, true, true>), grid, block, 0, st, p); break;
+    }
     return hip_err(hipGetLastError());
 }
 
@@ -1043,12 +1086,24 @@ int ss_ctx_join(ss_ctx* h, void* stream) {
     return 0;
 }
 
-int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
+static int ctx_features_on(ss_ctx* h, int n, const float* audiogoal, const ss_features* f, void* stream) {
+    if (!f) return 0;
+    const ssctx::Context& c = h->c;
+    return ss_audio_features_f32(audiogoal, n, c.out_len, c.pad_mode, nullptr, f->logmel, f->mel_start, f->mel_w, f->n_mels,
+                                 f->max_len, f->mel_eps, f->gccphat, f->max_lag, f->gcc_eps, stream);
+}
+
+static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, const ss_features* f,
+                           void* stream) {
     if (!h || n < 0 || (!audiogoal && !spectrogram)) return SS_EINVAL;
+    if (f && (!audiogoal || (!f->logmel && !f->gccphat))) return SS_EINVAL;
     if (n == 0) return 0;
     ssctx::Context& c = h->c;
     if ((!c.rir && !c.hspec && c.buckets.empty()) || !c.rir_len || !c.src_dev) return SS_EINVAL;
-    if (c.n_lanes <= 1) return ctx_observe_on(h, units, n, audiogoal, spectrogram, stream, -1);
+    if (c.n_lanes <= 1) {
+        const int rc = ctx_observe_on(h, units, n, audiogoal, spectrogram, stream, -1);
+        return rc ? rc : ctx_features_on(h, n, audiogoal, f, stream);
+    }
     // overlap mode: this step goes to the next internal stream, behind whatever the caller's stream holds right now (the
     // consumers of the output rows it overwrites, uploads of RIR rows it reads); the caller's stream sees the result after
     // ss_ctx_join.  Consecutive steps run on different streams: the head of step k+1 (descriptor + row loads, HBM latency,
@@ -1058,7 +1113,18 @@ int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, fl
     if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
     if (e != hipSuccess) return hip_err(e);
     c.lane_dirty[lane] = true;
-    return ctx_observe_on(h, units, n, audiogoal, spectrogram, c.lane_stream[lane], lane);
+    const int rc = ctx_observe_on(h, units, n, audiogoal, spectrogram, c.lane_stream[lane], lane);
+    return rc ? rc : ctx_features_on(h, n, audiogoal, f, c.lane_stream[lane]);
+}
+
+int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
+    return ctx_observe_any(h, units, n, audiogoal, spectrogram, nullptr, stream);
+}
+
+int ss_ctx_observe_features(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, const ss_features* f,
+                            void* stream) {
+    if (!f) return SS_EINVAL;
+    return ctx_observe_any(h, units, n, audiogoal, spectrogram, f, stream);
 }
 
 

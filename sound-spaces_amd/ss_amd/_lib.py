@@ -15,7 +15,7 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
            "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
-           "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units")
+           "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features")
 
 
 class SsRirBucket(ctypes.Structure):
@@ -36,6 +36,13 @@ class SsRequestTables(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("sound_keys", "sound_ids", "table_keys", "table_ids", "pair_keys", "pair_slots",
                                               "stale")] + \
                [(n, ctypes.c_int) for n in ("n_sounds", "n_tables", "n_pairs", "n_slots")]
+
+
+class SsFeatures(ctypes.Structure):
+    """struct ss_features of include/ss_hip.h."""
+    _fields_ = [("logmel", ctypes.c_void_p), ("mel_start", ctypes.c_void_p), ("mel_w", ctypes.c_void_p), ("n_mels", ctypes.c_int),
+                ("max_len", ctypes.c_int), ("mel_eps", ctypes.c_float), ("gccphat", ctypes.c_void_p), ("max_lag", ctypes.c_int),
+                ("gcc_eps", ctypes.c_float)]
 
 
 class SsUnits(ctypes.Structure):
@@ -93,6 +100,9 @@ def load() -> ctypes.CDLL:
     lib.ss_audio_obs_spec_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp]
     lib.ss_source_windows32_f32.argtypes = [vp, vp, vp, c_int, vp]
     lib.ss_audio_obs32_f32.argtypes = [vp, vp, vp, vp, vp, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, vp]
+    lib.ss_audio_features_f32.argtypes = [vp, c_int, c_int, c_int, vp, vp, vp, vp, c_int, c_int, ctypes.c_float, vp, c_int,
+                                          ctypes.c_float, vp]
+    lib.ss_ctx_observe_features.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, ctypes.POINTER(SsFeatures), vp]
     lib.ss_ctx_observe_requests.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp]
     lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
     for name in EXPORTS:

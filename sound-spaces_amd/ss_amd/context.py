@@ -200,6 +200,27 @@ class AudioContext:
         if rc != 0:
             _lib.check(rc, "ss_ctx_observe")
 
+    @staticmethod
+    def features(logmel_out=None, mel_start=None, mel_w=None, mel_eps: float = 1e-6, gccphat_out=None, max_lag: int = 32,
+                 gcc_eps: float = 1e-8):
+        """The extension features of a step as the C struct ``ss_features`` (device tensors, borrowed): pass the result to
+        ``observe_prepared(..., features=)``.  logmel_out [n, n_mels, T, 2] with the band-sparse bank (mel_start int32
+        [n_mels], mel_w float32 [n_mels, max_len]: ``planning.mel_filterbank_sparse``); gccphat_out [n, 2*max_lag+1, T]."""
+        f = _lib.SsFeatures()
+        if logmel_out is not None:
+            f.logmel, f.mel_start, f.mel_w = logmel_out.data_ptr(), mel_start.data_ptr(), mel_w.data_ptr()
+            f.n_mels, f.max_len, f.mel_eps = int(mel_w.shape[0]), int(mel_w.shape[1]), float(mel_eps)
+        if gccphat_out is not None:
+            f.gccphat, f.max_lag, f.gcc_eps = gccphat_out.data_ptr(), int(max_lag), float(gcc_eps)
+        return dict(f=f, ref=ctypes.byref(f), keep=(logmel_out, mel_start, mel_w, gccphat_out))
+
+    def observe_prepared_features(self, prep, spectrogram_ptr, audiogoal_ptr, stream: int, features) -> None:
+        """``observe_prepared`` + the step's log-mel / GCC-PHAT on the same stream (``ss_ctx_observe_features``)."""
+        rc = self.lib.ss_ctx_observe_features(self._h, prep["ref"], prep["n"], audiogoal_ptr, spectrogram_ptr, features["ref"],
+                                              stream)
+        if rc != 0:
+            _lib.check(rc, "ss_ctx_observe_features")
+
     def bind_sims(self, state, index, has_distractor: bool = False):
         """Pointers to the int64 state columns (``ss_amd.vector.VectorSimState``) and the RIR index tables, for
         ``observe_sims``: built once, rebuilt by the caller when the index tables are rebuilt (``index.version``)."""

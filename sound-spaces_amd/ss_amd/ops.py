@@ -145,6 +145,49 @@ def gccphat(x: torch.Tensor, max_lag: int = 32, eps: float = 1e-8, pad_mode="ref
     return out
 
 
+def audio_features_into(x: torch.Tensor, spectrogram_out=None, logmel_out=None, gccphat_out=None, mel_start=None, mel_w=None,
+                        mel_eps: float = 1e-6, max_lag: int = 32, gcc_eps: float = 1e-8, pad_mode="reflect") -> None:
+    """EXTENSION: every STFT-derived feature from ONE pass over the waveform x [N, 2, n] (``ss_audio_features_f32``): any
+    subset of the pooled spectrogram [N,65,T4,2] (nav.py:86-100), log-mel [N,n_mels,T,2] and GCC-PHAT [N,2*max_lag+1,T];
+    same results as ``spectrogram_into`` / ``logmel_into`` / ``gccphat_into``, which each re-read x and redo the STFT."""
+    _chk(x, torch.float32, "x")
+    N, two, n = x.shape
+    assert two == 2 and (spectrogram_out is not None or logmel_out is not None or gccphat_out is not None)
+    n_mels = max_len = 0
+    if spectrogram_out is not None:
+        _chk(spectrogram_out, torch.float32, "spectrogram_out")
+        assert tuple(spectrogram_out.shape) == (N,) + spectrogram_shape(n)
+    if logmel_out is not None:
+        _chk(logmel_out, torch.float32, "logmel_out"); _chk(mel_start, torch.int32, "mel_start"); _chk(mel_w, torch.float32, "mel_w")
+        n_mels, max_len = mel_w.shape
+        assert mel_start.shape == (n_mels,) and tuple(logmel_out.shape) == (N, n_mels, 1 + n // 160, 2)
+    if gccphat_out is not None:
+        _chk(gccphat_out, torch.float32, "gccphat_out")
+        assert tuple(gccphat_out.shape) == (N, 2 * max_lag + 1, 1 + n // 160)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ss_audio_features_f32(x.data_ptr(), N, n, _PAD[pad_mode], ptr(spectrogram_out), ptr(logmel_out),
+                                                     ptr(mel_start), ptr(mel_w), int(n_mels), int(max_len), float(mel_eps),
+                                                     ptr(gccphat_out), int(max_lag), float(gcc_eps), _stream(x)),
+                   "ss_audio_features_f32")
+
+
+def audio_features(x: torch.Tensor, want=("logmel", "gccphat"), mel_start=None, mel_w=None, mel_eps: float = 1e-6,
+                   max_lag: int = 32, gcc_eps: float = 1e-8, pad_mode="reflect"):
+    """-> dict of the wanted features ("spectrogram", "logmel", "gccphat"), one launch."""
+    N, _, n = x.shape
+    out = {}
+    if "spectrogram" in want:
+        out["spectrogram"] = torch.empty((N,) + spectrogram_shape(n), dtype=torch.float32, device=x.device)
+    if "logmel" in want:
+        out["logmel"] = torch.empty((N, mel_w.shape[0], 1 + n // 160, 2), dtype=torch.float32, device=x.device)
+    if "gccphat" in want:
+        out["gccphat"] = torch.empty((N, 2 * max_lag + 1, 1 + n // 160), dtype=torch.float32, device=x.device)
+    audio_features_into(x, out.get("spectrogram"), out.get("logmel"), out.get("gccphat"), mel_start, mel_w, mel_eps, max_lag,
+                        gcc_eps, pad_mode)
+    return out
+
+
 def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_out, n_valid: int, out_len: int,
                    pad_mode="reflect", interleaved: bool = False, flags: int = 0) -> None:
     """Fused observation.  ``audiogoal`` may be None (the waveform then never leaves the CU).  Cross-faded rows longer
@@ -301,6 +344,16 @@ def _register():
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0: logmel(x, ms, mw, eps, pad_mode), "CUDA")
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0:
              x.new_empty((x.shape[0], mw.shape[0], 1 + x.shape[2] // 160, 2)), "Meta")
+    lib.define("audio_features(Tensor x, Tensor mel_start, Tensor mel_w, float mel_eps=1e-6, int max_lag=32, float gcc_eps=1e-8, "
+               "int pad_mode=0) -> (Tensor, Tensor)")
+
+    def _audio_features(x, ms, mw, mel_eps=1e-6, max_lag=32, gcc_eps=1e-8, pad_mode=0):
+        o = audio_features(x, ("logmel", "gccphat"), ms, mw, mel_eps, max_lag, gcc_eps, pad_mode)
+        return o["logmel"], o["gccphat"]
+    lib.impl("audio_features", _audio_features, "CUDA")
+    lib.impl("audio_features", lambda x, ms, mw, mel_eps=1e-6, max_lag=32, gcc_eps=1e-8, pad_mode=0:
+             (x.new_empty((x.shape[0], mw.shape[0], 1 + x.shape[2] // 160, 2)),
+              x.new_empty((x.shape[0], 2 * max_lag + 1, 1 + x.shape[2] // 160))), "Meta")
     lib.impl("intensity", intensity, "CUDA")
     lib.impl("intensity", lambda a, num_frame=150: a.new_empty((a.shape[0],)), "Meta")
     lib.impl("source_windows", source_windows, "CUDA")

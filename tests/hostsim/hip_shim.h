@@ -26,3 +26,4 @@ float hostsim_lane_read(float v, int src_lane);   // value of `v` held by lane s
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }   // fibers run one at a time

@@ -10,6 +10,7 @@
 #include "hip_shim.h"
 #include "../../sound-spaces_amd/csrc/ss_kernels.hpp"
 #include "../../sound-spaces_amd/csrc/ss_kernels32.hpp"
+#include "../../sound-spaces_amd/csrc/ss_features.hpp"
 #include "../../sound-spaces_amd/csrc/ss_tables.hpp"
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -399,6 +400,38 @@ int hs_gccphat(const float* x, float* out, int n_units, int len, int pad_mode, i
     for (int b = 0; b < n_units * chunks; ++b) {
         blockIdx = dim3{(unsigned)b, 0, 0};
         int rc = run_block(256, [&] { ssk::k_gccphat(p); });
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hs_features(const float* x, int n_units, int len, int pad_mode, float* sgram, float* mel, const int* start, const float* w,
+                int n_mels, int max_len, float mel_eps, float* gcc, int max_lag, float gcc_eps, int gpw) {
+    ssk::FeatParams p;
+    p.x = x; p.sgram = sgram; p.mel = mel; p.gcc = gcc; p.tb = host_tables(); p.mel_start = start; p.mel_w = w;
+    p.len = len; p.n_frames = 1 + len / ssk::kHop; p.t4 = (p.n_frames + 3) / 4; p.pad_mode = pad_mode;
+    p.n_mels = mel ? n_mels : 0; p.max_len = mel ? max_len : 4; p.max_lag = gcc ? max_lag : 1;
+    p.mel_eps = mel_eps; p.gcc_eps = gcc_eps;
+    if (mel && (n_mels > ssk::kFeatMaxMels || max_len > ssk::kFeatMaxLen || (max_len & 3) || n_mels * max_len > ssk::kFeatMelTable)) return -2;
+    if (gcc && (max_lag < 1 || max_lag > ssk::kGccMaxLag)) return -2;
+    const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
+    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
+    const int chunks = (groups + p.gpw - 1) / p.gpw;
+    gridDim = dim3{(unsigned)(n_units * chunks), 1, 1};
+    for (int b = 0; b < n_units * chunks; ++b) {
+        blockIdx = dim3{(unsigned)b, 0, 0};
+        int rc = run_block(256, [&] {
+            const int which = (mel ? 1 : 0) | (sgram ? 2 : 0) | (gcc ? 4 : 0);
+            switch (which) {
+                case 1: ssk::k_features<true, false, false>(p); break;
+                case 2: ssk::k_features<false, true, false>(p); break;
+                case 3: ssk::k_features<true, true, false>(p); break;
+                case 4: ssk::k_features<false, false, true>(p); break;
+                case 5: ssk::k_features<true, false, true>(p); break;
+                case 6: ssk::k_features<false, true, true>(p); break;
+                default: ssk::k_features<true, true, true>(p); break;
+            }
+        });
         if (rc) return rc;
     }
     return 0;

@@ -19,7 +19,7 @@ def lib():
         so = os.path.join(HERE, "libss_hostsim.so")
         srcs = [os.path.join(HERE, f) for f in ("hostsim.cpp", "hip_shim.h")]
         csrc = os.path.join(HERE, "..", "..", "sound-spaces_amd", "csrc")
-        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp")]
+        srcs += [os.path.join(csrc, f) for f in ("ss_kernels.hpp", "ss_fft_core.hpp", "ss_tables.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp", "ss_features.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             cxx = os.environ.get("SS_HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")   # needs ext_vector_type
             subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
@@ -189,5 +189,28 @@ def gccphat(x, max_lag=32, eps=1e-8, pad_mode=0, gpw=1):
     N, _, n = x.shape
     out = np.full((N, 2 * max_lag + 1, 1 + n // 160), np.nan, np.float32)
     rc = L.hs_gccphat(_p(x, ctypes.c_float), _p(out, ctypes.c_float), N, n, pad_mode, max_lag, ctypes.c_float(eps), gpw)
+    assert rc == 0, rc
+    return out
+
+
+def features(x, sr, want=("spectrogram", "logmel", "gccphat"), n_mels=64, mel_eps=1e-6, max_lag=32, gcc_eps=1e-8, pad_mode=0, gpw=1):
+    """k_features: every STFT-derived feature from ONE pass over the waveform -> dict of the wanted outputs."""
+    L = lib()
+    x = np.ascontiguousarray(x, np.float32)
+    N, _, n = x.shape
+    start, w, max_len = P.mel_filterbank_sparse(sr, n_mels)
+    start = np.ascontiguousarray(start, np.int32); w = np.ascontiguousarray(w, np.float32)
+    T = 1 + n // 160
+    out = {}
+    if "spectrogram" in want:
+        out["spectrogram"] = np.full((N, 65, P.spectrogram_shape(n)[1], 2), np.nan, np.float32)
+    if "logmel" in want:
+        out["logmel"] = np.full((N,) + P.logmel_shape(n, n_mels), np.nan, np.float32)
+    if "gccphat" in want:
+        out["gccphat"] = np.full((N, 2 * max_lag + 1, T), np.nan, np.float32)
+    ptr = lambda k: _p(out[k], ctypes.c_float) if k in out else None
+    rc = L.hs_features(_p(x, ctypes.c_float), N, n, pad_mode, ptr("spectrogram"), ptr("logmel"), _p(start, ctypes.c_int),
+                       _p(w, ctypes.c_float), n_mels, max_len, ctypes.c_float(mel_eps), ptr("gccphat"), max_lag,
+                       ctypes.c_float(gcc_eps), gpw)
     assert rc == 0, rc
     return out

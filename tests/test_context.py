@@ -391,3 +391,60 @@ def test_ctx_observe_distractor_crossfade_and_44k():
     c3.observe(np.zeros(2), np.zeros(2), np.array([0, -1]), spectrogram_out=sg)
     a = O.compute_audiogoal(s44, r44[0], sr)
     assert O.relerr(sg[0].cpu().numpy(), O.compute_spectrogram(a)) <= 1e-4 and not sg[1].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [1, 2])
+def test_observe_features_equals_observe_then_feature_kernels(overlap):
+    """ss_ctx_observe_features (BASELINE.json configs[4]: savi with the fused GCC-PHAT + log-mel sensor): the step and its
+    extension features on one stream - in overlap mode on the step's own lane, no join between them - equal
+    ss_ctx_observe followed by the stand-alone feature kernels; a plain step on the same context afterwards is unaffected."""
+    import torch
+    from ss_amd import ops, planning as P
+    from ss_amd.renderer import RirBank
+    dev = "cuda:0"
+    rng = np.random.default_rng(31)
+    src = list(O.synth_sources(rng, SR, k=3)) + [O.synth_sources(rng, SR, k=1, seconds=3)[0]]
+    rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=6)]
+    bank = RirBank.from_arrays(rirs, dev)
+    ctx = AudioContext(SR)
+    for i, s_ in enumerate(src):
+        ctx.add_source(f"s{i}", s_)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    n = 9
+    cols = [dict(sound=rng.integers(0, 4, n), t0=np.zeros(n, np.int64), rir=rng.integers(0, 6, n),
+                 dis_sound=rng.integers(0, 3, n), dis_rir=rng.integers(0, 6, n)) for _ in range(4)]
+    for c in cols:
+        c["t0"] = np.where(c["sound"] == 3, SR * rng.integers(0, 3, n), 0)
+        c["rir"][2] = -1                                                        # a silent unit
+    ms, mw, _ = P.mel_filterbank_sparse(SR, 64)
+    msd, mwd = torch.from_numpy(ms).to(dev), torch.from_numpy(mw).to(dev)
+    T = 1 + SR // 160
+    want = []
+    for c in cols:                                                             # the reference order: observe, then the kernels
+        ag, sg = torch.empty((n, 2, SR), device=dev), torch.empty((n, 65, 26, 2), device=dev)
+        ctx.observe(spectrogram_out=sg, audiogoal_out=ag, **c)
+        want.append((ag, sg, ops.logmel(ag, msd, mwd), ops.gccphat(ag)))
+    torch.cuda.synchronize()
+    ctx.set_overlap(overlap)
+    stream = torch.cuda.current_stream().cuda_stream
+    got = []
+    for c in cols:
+        ag, sg = torch.full((n, 2, SR), 9.0, device=dev), torch.full((n, 65, 26, 2), 9.0, device=dev)
+        lm, gc = torch.full((n, 64, T, 2), 9.0, device=dev), torch.full((n, 65, T), 9.0, device=dev)
+        f = ctx.features(lm, msd, mwd, 1e-6, gc, 32, 1e-8)
+        ctx.observe_prepared_features(ctx.prepare(**c), sg.data_ptr(), ag.data_ptr(), stream, f)
+        got.append((ag, sg, lm, gc, f))
+    ctx.join()
+    torch.cuda.synchronize()
+    for (ag, sg, lm, gc, _), (ag0, sg0, lm0, gc0) in zip(got, want):
+        assert torch.equal(ag, ag0) and torch.equal(sg, sg0)
+        assert float((lm - lm0).abs().max()) <= 5e-5 and float((gc - gc0).abs().max()) <= 5e-6
+        assert not ag[2].any() and torch.allclose(lm[2], torch.full_like(lm[2], float(np.log(1e-6))), rtol=1e-6)
+    ctx.set_overlap(1)
+    sg = torch.empty((n, 65, 26, 2), device=dev)
+    ctx.observe(spectrogram_out=sg, **cols[0])
+    torch.cuda.synchronize()
+    assert torch.equal(sg, want[0][1])
+    with pytest.raises(Exception):                                             # the features read the waveform: no audiogoal, no call
+        ctx.observe_prepared_features(ctx.prepare(**cols[0]), sg.data_ptr(), None, stream, got[0][4])
