@@ -54,10 +54,16 @@ def call():
 
 for _ in range(600):
     call()
-t0 = time.perf_counter()
-for _ in range(2000):
-    call()
-print("eager: %.1f us per call" % (1e6 * (time.perf_counter() - t0) / 2000))
+for direct in (True, False, True, False):
+    sim_audio.EAGER_DIRECT_HOST = direct
+    for _ in range(200):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        call()
+    print("eager (outputs %s): %.1f us per call" % ("written straight into pinned host memory" if direct else
+                                                    "to a device buffer + one async D2H copy", 1e6 * (time.perf_counter() - t0) / 2000))
+sim_audio.EAGER_DIRECT_HOST = True
 pr = cProfile.Profile(); pr.enable()
 for _ in range(2000):
     call()

@@ -10,7 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libss_hip.so")
-SOURCES = ["ss_hip.hip", "ss_kernels.hpp", "ss_fft_core.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp", "ss_features.hpp", "ss_tables.hpp", "ss_context.hpp", os.path.join("..", "..", "include", "ss_hip.h")]
+TORCH_SO = os.path.join(CSRC, "libss_torch_ops.so")
+SOURCES = ["ss_torch_ops.cpp", "ss_hip.hip", "ss_kernels.hpp", "ss_fft_core.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp", "ss_features.hpp", "ss_tables.hpp", "ss_context.hpp", os.path.join("..", "..", "include", "ss_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
@@ -28,7 +29,7 @@ def _source_hash():
 
 def up_to_date():
     """By content, not mtime: the snapshot that carries the prebuilt library to the GPU box does not keep timestamps."""
-    if not (os.path.exists(SO) and os.path.exists(STAMP)):
+    if not (os.path.exists(SO) and os.path.exists(TORCH_SO) and os.path.exists(STAMP)):
         return False
     return open(STAMP).read().strip() == _source_hash()
 
@@ -44,9 +45,27 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd[:-1] + [tmp_so], cwd=CSRC)
     guard_isa(hipcc, verbose)
     os.replace(tmp_so, SO)
+    build_torch_ops(verbose)
     with open(STAMP, "w") as f:
         f.write(_source_hash() + "\n")
     return SO
+
+
+def build_torch_ops(verbose=True):
+    """libss_torch_ops.so: the TORCH_LIBRARY extension (csrc/ss_torch_ops.cpp; host C++ only, calls libss_hip.so through the
+    C ABI).  Compiled with g++ against the headers / libraries of the torch that is installed HERE (the GPU box runs the
+    same image); finds libss_hip.so next to itself ($ORIGIN)."""
+    from torch.utils import cpp_extension as ce
+    inc = sum((["-I", p] for p in ce.include_paths()), []) + ["-I", "/opt/rocm/include"]
+    libdir = ce.library_paths()[0]
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "ss_torch_ops.cpp", "-o", TORCH_SO + ".tmp",
+            "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-D_GLIBCXX_USE_CXX11_ABI=1"] + inc +
+           ["-L", libdir, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-L", CSRC, "-lss_hip",
+            "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + libdir])
+    if verbose:
+        print("[ss_amd] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(TORCH_SO + ".tmp", TORCH_SO)
 
 
 def guard_isa(hipcc, verbose=True):

@@ -47,6 +47,15 @@ class AudioContext:
         self.handle = AudioContext._next_handle          # torch.ops.ss_hip.ctx_observe(handle, ...) finds the context by it
         AudioContext._next_handle += 1
         AudioContext._by_handle[self.handle] = self
+        self._native = False
+        try:                                             # the C++ op layer resolves a handle to the raw ss_ctx* itself
+            from . import ops
+            if ops.NATIVE_OPS:
+                import torch
+                torch.ops.ss_hip.ctx_register(self.handle, int(h.value))
+                self._native = True
+        except ImportError:                              # (torch-free use of the context: planner tests)
+            pass
         self._names: Dict[str, int] = {}
         self.lengths = []
         self._bank = None                    # keeps the borrowed tensors alive
@@ -60,6 +69,12 @@ class AudioContext:
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_native", False):
+                try:
+                    import torch
+                    torch.ops.ss_hip.ctx_unregister(self.handle)
+                except Exception:                        # interpreter shutdown
+                    pass
             self.lib.ss_ctx_destroy(self._h)
             self._h = None
 

@@ -327,14 +327,35 @@ def intensity(audiogoal: torch.Tensor, num_frame: int = 150) -> torch.Tensor:
 
 
 # ---- torch.ops.ss_hip.* ------------------------------------------------------------------------------
+def _load_native_ops() -> bool:
+    """The TORCH_LIBRARY extension (csrc/ss_torch_ops.cpp, built in-tree by build.py): the hot ops - spectrogram, audio_obs,
+    ctx_observe and the one-dispatch eager observation eager_obs - are C++ dispatches straight into libss_hip.so.  Without
+    the file (a tree that was never built) the same schemas are registered from Python below, over ctypes."""
+    import logging
+    import os
+    so = os.path.join(os.path.dirname(_lib.SO_PATH), "libss_torch_ops.so")
+    if not os.path.exists(so):
+        return False
+    try:
+        torch.ops.load_library(so)
+        return True
+    except OSError as e:                                    # e.g. built against another torch: keep the Python registrations
+        logging.warning("ss_amd: %s did not load (%s); torch.ops.ss_hip.* stay on the Python registrations", so, e)
+        return False
+
+
+NATIVE_OPS = _load_native_ops()
+
+
 def _register():
-    lib = torch.library.Library("ss_hip", "DEF")
+    lib = torch.library.Library("ss_hip", "FRAGMENT" if NATIVE_OPS else "DEF")
     lib.define("source_windows(Tensor src, Tensor win_desc) -> Tensor")
     lib.define("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, "
                "int out_len, bool interleaved=False, int flags=0) -> Tensor")
-    lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
-    lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
-               "int pad_mode=0, bool interleaved=False, int flags=0) -> (Tensor, Tensor)")
+    if not NATIVE_OPS:
+        lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
+        lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+                   "int pad_mode=0, bool interleaved=False, int flags=0) -> (Tensor, Tensor)")
     lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
     lib.define("gccphat(Tensor x, int max_lag=32, float eps=1e-8, int pad_mode=0) -> Tensor")
     lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0: gccphat(x, max_lag, eps, pad_mode), "CUDA")
@@ -358,12 +379,12 @@ def _register():
     lib.impl("intensity", lambda a, num_frame=150: a.new_empty((a.shape[0],)), "Meta")
     lib.impl("source_windows", source_windows, "CUDA")
     lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
-    lib.impl("spectrogram", lambda x, pad_mode=0: spectrogram(x, pad_mode), "CUDA")
-
     def _audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode=0, interleaved=False, flags=0):
         ag, sg = audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode, True, interleaved, flags)
         return ag, sg
-    lib.impl("audio_obs", _audio_obs, "CUDA")
+    if not NATIVE_OPS:
+        lib.impl("spectrogram", lambda x, pad_mode=0: spectrogram(x, pad_mode), "CUDA")
+        lib.impl("audio_obs", _audio_obs, "CUDA")
 
     # spectral RIR bank: the bank builder + the two *_spec entry points
     lib.define("rir_spectra(Tensor rir_bank) -> Tensor")
@@ -394,13 +415,13 @@ def _register():
     # the observe-level op: one vector step through a context (planner + window cache + descriptor ring in the library).
     # `ctx` = AudioContext.handle (an integer registered by ss_amd.context); unit columns are int32 CPU tensors; the
     # spectrogram rows are written in place (rollout rows) and returned.
-    lib.define("ctx_observe(int ctx, Tensor sound, Tensor t0, Tensor rir, Tensor(a!) spectrogram) -> Tensor(a!)")
-
     def _ctx_observe(ctx, sound, t0, rir, spectrogram):
         from .context import AudioContext
         AudioContext.from_handle(ctx).observe(sound.numpy(), t0.numpy(), rir.numpy(), spectrogram_out=spectrogram)
         return spectrogram
-    lib.impl("ctx_observe", _ctx_observe, "CompositeExplicitAutograd")
+    if not NATIVE_OPS:
+        lib.define("ctx_observe(int ctx, Tensor sound, Tensor t0, Tensor rir, Tensor(a!) spectrogram) -> Tensor(a!)")
+        lib.impl("ctx_observe", _ctx_observe, "CompositeExplicitAutograd")
 
     # shape functions (Meta) so the ops compose with tracing / fake tensors
     lib.impl("source_windows", lambda src, wd: src.new_empty((wd.shape[0], SPEC_FLOATS)), "Meta")

@@ -51,6 +51,11 @@ def wav_rir_reader(path: str, lenient: bool = False) -> Optional[np.ndarray]:
     return np.asarray(rir, dtype=np.float32)
 
 
+# eager observations: the kernels write their outputs straight into the pinned host buffer (device-mapped under ROCm) instead
+# of a device buffer that a copy-engine job then moves (scripts/prof_eager.py A/B: see profiles/r4/NOTES.md)
+EAGER_DIRECT_HOST = True
+
+
 def _render_to_host(backend, req, want_spectrogram: bool):
     """One unit through the engine and back to the host as (audiogoal [2, sr], spectrogram or None), numpy arrays owned by
     the caller (the reference's are too: they end up in the simulator's caches).  Both outputs land in ONE device buffer and
@@ -70,11 +75,25 @@ def _render_to_host(backend, req, want_spectrogram: bool):
         st = backend._stage = (torch.empty(n_ag + n_sg, dtype=torch.float32, device=eng.renderer.device),
                                torch.empty(n_ag + n_sg, dtype=torch.float32).pin_memory())
     dbuf, hbuf = st
-    eng.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram, audiogoal_out=dbuf[:n_ag].view(1, 2, sr),
-                spectrogram_out=dbuf[n_ag:].view((1,) + shp) if want_spectrogram else None)
     n = n_ag + n_sg if want_spectrogram else n_ag
-    hbuf[:n].copy_(dbuf[:n], non_blocking=True)
-    torch.cuda.current_stream(dbuf.device).synchronize()         # (an event record + synchronize measured 10 us slower)
+    from . import ops
+    if ops.NATIVE_OPS and hasattr(eng, "context") and not getattr(eng, "_no_native_eager", False):
+        # ONE C++ dispatch (csrc/ss_torch_ops.cpp::eager_obs): the library's planner + window cache + launch
+        # (ss_ctx_observe on a one-unit step), one async copy of both outputs into pinned memory, stream synchronise
+        try:
+            ctx = eng._sync_context_bank()
+        except NotImplementedError:                              # (length-bucketed stores keep the renderer path)
+            eng._no_native_eager = True
+            return _render_to_host(backend, req, want_spectrogram)
+        wrap = 1 if req.wrap is None else int(bool(req.wrap))
+        torch.ops.ss_hip.eager_obs(ctx.handle, int(req.sound), int(req.t0), int(req.rir), int(req.dis_sound), int(req.dis_rir),
+                                   int(req.last_rir), wrap, wrap if req.last_wrap is None else int(bool(req.last_wrap)),
+                                   dbuf[:0] if EAGER_DIRECT_HOST else dbuf, hbuf, sr, want_spectrogram)
+    else:
+        eng.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram, audiogoal_out=dbuf[:n_ag].view(1, 2, sr),
+                    spectrogram_out=dbuf[n_ag:].view((1,) + shp) if want_spectrogram else None)
+        hbuf[:n].copy_(dbuf[:n], non_blocking=True)
+        torch.cuda.current_stream(dbuf.device).synchronize()     # (an event record + synchronize measured 10 us slower)
     h = hbuf.numpy()
     return h[:n_ag].reshape(2, sr).copy(), (h[n_ag:n].reshape(shp).copy() if want_spectrogram else None)
 
