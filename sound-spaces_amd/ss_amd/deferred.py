@@ -53,6 +53,11 @@ class AudioRequest:
     # N requests of a vector step into unit COLUMNS with a dozen numpy operations instead of a Python walk (see
     # DeferredResolver._columns).  Names travel as CRC-32 keys; the strings above stay for first-use registration.
     rec: Optional[bytes] = None
+    # pose_cache mode (attach_deferred(..., pose_cache=True)): the reference's per-pose memo (simulator.py:678-701) kept by
+    # the worker's own simulator dicts; a hit asks the trainer for the row it stored when this pose was first rendered
+    cache_key: Optional[tuple] = None             # (source, receiver, azimuth)
+    cache_hit: bool = False
+    cache_epoch: int = 0                          # bumps when the simulator dropped its caches (scene / sound change, :395-397)
 
 
 # layout of AudioRequest.rec (int64 words)
@@ -63,6 +68,12 @@ _SILENT_REC[REC_SILENT] = 1
 _SILENT_REC[REC_DIS_SOUND] = -1
 
 
+def _silent_rec(env: int) -> bytes:
+    rec = _SILENT_REC.copy()
+    rec[REC_ENV] = env
+    return rec.tobytes()
+
+
 def name_key(name: str) -> int:
     """CRC-32 of a sound name / RIR directory: the same integer in every process without a registry round trip."""
     return zlib.crc32(name.encode("utf-8"))
@@ -71,8 +82,12 @@ def name_key(name: str) -> int:
 class DeferredSimAudio:
     """Worker-side adapter for ``SoundSpacesSim`` (continuous=False) or ``ContinuousSoundSpacesSim``."""
 
-    def __init__(self, sim, env_rank: int = 0, continuous: bool = False):
+    def __init__(self, sim, env_rank: int = 0, continuous: bool = False, pose_cache: bool = False):
         self.sim, self.env, self.continuous = sim, env_rank, continuous
+        # reference-exact mode for multi-second sounds (see FastVectorAudioObserver(pose_cache=)): SoundSpaces 1.0 without
+        # a distractor only - the reference bypasses its caches otherwise (:679-681), SS2.0 has none (cont. :458-462)
+        self.pose_cache = bool(pose_cache) and not continuous
+        self._epoch, self._cache_obj = 0, None
         self._sent = set()                        # sounds whose clip the trainer already has
         self._keys: Dict[str, int] = {}           # name -> CRC-32 (sounds, "<rir dir>/<azimuth>" tables)
 
@@ -100,6 +115,22 @@ class DeferredSimAudio:
                    sim.azimuth_angle, sim._current_sound)
         if getattr(self, "_memo_key", None) == key:
             return self._memo
+        if self.pose_cache and not sim.config.AUDIO.HAS_DISTRACTOR_SOUND:
+            cache = sim._spectrogram_cache                    # the simulator's own dict: reconfigure() replaces it (:395-397)
+            if cache is not self._cache_obj or (not cache and self._cache_obj is not None and self._had_entries):
+                self._epoch += 1
+                self._cache_obj = cache
+            self._had_entries = bool(cache)
+            pose = (sim._source_position_index, sim._receiver_position_index, sim.azimuth_angle)      # :683
+            if pose in cache:                                 # hit: nothing is computed, _audio_index stays (:634-635)
+                req = AudioRequest(env=self.env, kind=kind, cache_key=pose, cache_hit=True, cache_epoch=self._epoch)
+            else:
+                req = self._request(kind)
+                req.cache_key, req.cache_epoch = pose, self._epoch
+                cache[pose] = req                             # marks the pose as rendered (the value is never read)
+                self._had_entries = True
+            self._memo_key, self._memo = key, req
+            return req
         self._memo_key, self._memo = key, self._request(kind)
         return self._memo
 
@@ -157,10 +188,10 @@ class DeferredSimAudio:
         return self.request("spectrogram")
 
 
-def attach_deferred(sim, env_rank: int = 0, continuous: bool = False) -> DeferredSimAudio:
+def attach_deferred(sim, env_rank: int = 0, continuous: bool = False, pose_cache: bool = False) -> DeferredSimAudio:
     """Worker side: the task sensors (the reference's or ss_amd's) keep calling ``sim.get_current_*_observation`` and now
     get an ``AudioRequest`` back, which habitat ships to the trainer as the sensor's 'observation'."""
-    backend = DeferredSimAudio(sim, env_rank, continuous)
+    backend = DeferredSimAudio(sim, env_rank, continuous, pose_cache)
     sim.get_current_audiogoal_observation = backend.get_current_audiogoal_observation
     sim.get_current_spectrogram_observation = backend.get_current_spectrogram_observation
     sim._ss_hip_audio = backend
@@ -198,6 +229,11 @@ class DeferredResolver:
         self._pair_keys = np.zeros((0,), np.int64)
         self._pair_slots = np.zeros((0,), np.int64)
         self._tables = None                       # the arrays above as the C struct of ss_ctx_observe_requests (rebuilt on change)
+        # pose_cache workers: env -> [epoch, {pose: pool row}], pools of cached output rows on the device
+        self._pose_maps: Dict[int, list] = {}
+        self._pose_pool: Dict[str, object] = {}
+        self._pose_free: List[int] = []
+        self._pose_cap = 0
         self.native_steps = 0
         if self.columns_ok and store.on_evict is None:
             store.on_evict = self._evicted
@@ -391,6 +427,58 @@ class DeferredResolver:
     def resolve(self, requests: Sequence[AudioRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None):
         """-> {"spectrogram": [N,65,T4,2], ("audiogoal": [N,2,sr])} device tensors, one launch for all envs."""
+        if any(q.cache_key is not None for q in requests):
+            return self._resolve_with_pose_cache(requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
+        return self._resolve(requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
+
+    def _resolve_with_pose_cache(self, requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out):
+        """pose_cache workers: misses are rendered and their rows kept in a device-side pool under (env, pose); hits are
+        row copies out of it (the reference returns the array it cached at that pose, simulator.py:683-686)."""
+        import torch
+        hits = [i for i, q in enumerate(requests) if q.cache_hit]
+        # a hit renders nothing: it rides through the launch as a silent unit (exact zeros, then overwritten)
+        reqs = [AudioRequest(env=q.env, kind=q.kind, silent=True, rec=_silent_rec(q.env)) if q.cache_hit else q for q in requests]
+        out = self._resolve(reqs, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
+        dev = next(iter(out.values())).device
+        maps = self._pose_maps
+        miss_rows, miss_slots = [], []
+        for i, q in enumerate(requests):
+            if q.cache_key is None:
+                continue
+            m = maps.setdefault(q.env, [q.cache_epoch, {}])
+            if m[0] != q.cache_epoch:                           # the worker's simulator dropped its caches
+                self._pose_free += list(m[1].values())
+                m[0], m[1] = q.cache_epoch, {}
+            if not q.cache_hit:
+                miss_rows.append(i)
+        if miss_rows:
+            while len(self._pose_free) < len(miss_rows):
+                new_cap = max(256, 2 * self._pose_cap)
+                for name, t in out.items():
+                    grown = torch.empty((new_cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                    if name in self._pose_pool:
+                        grown[:self._pose_cap] = self._pose_pool[name]
+                    self._pose_pool[name] = grown
+                self._pose_free += list(range(new_cap - 1, self._pose_cap - 1, -1))
+                self._pose_cap = new_cap
+            for i in miss_rows:
+                j = self._pose_free.pop()
+                maps[requests[i].env][1][requests[i].cache_key] = j
+                miss_slots.append(j)
+            mi, sj = (torch.as_tensor(v, dtype=torch.long, device=dev) for v in (miss_rows, miss_slots))
+            for name, t in out.items():
+                self._pose_pool[name].index_copy_(0, sj, t.index_select(0, mi))
+        if hits:
+            slots = [maps[requests[i].env][1][requests[i].cache_key] for i in hits]
+            hi, hj = (torch.as_tensor(v, dtype=torch.long, device=dev) for v in (hits, slots))
+            for name, t in out.items():
+                if name not in self._pose_pool:
+                    raise KeyError(f"pose_cache: {name} was not among the outputs when this pose was first rendered")
+                t.index_copy_(0, hi, self._pose_pool[name].index_select(0, hj))
+        return out
+
+    def _resolve(self, requests: Sequence[AudioRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
+                 spectrogram_out=None, audiogoal_out=None):
         buf = self._records(requests) if self.columns_ok else None
         if buf is not None:
             import torch

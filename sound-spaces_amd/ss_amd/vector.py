@@ -253,13 +253,28 @@ class FastVectorAudioObserver:
     """One launch per vector step, state read from columns (module docstring)."""
 
     def __init__(self, ctx, state: VectorSimState, index: RirIndex, sampling_rate: int, has_distractor: bool = False,
-                 miss: Optional[Callable[[int, int, int, int], int]] = None, native: bool = True):
+                 miss: Optional[Callable[[int, int, int, int], int]] = None, native: bool = True, pose_cache: bool = False):
         """ctx: ss_amd.context.AudioContext with its RIR bank set; miss(env, recv, src, azimuth) -> slot is called for
-        envs whose pair is not in the index (loads it AND enters it into the index; default: raise)."""
+        envs whose pair is not in the index (loads it AND enters it into the index; default: raise).
+        pose_cache: the REFERENCE-EXACT mode for multi-second sounds.  The reference memoises observations per (source,
+        receiver, azimuth) (simulator.py:678-701); the key ignores ``_audio_index``, so an agent that stands still or comes
+        back to a pose gets the observation FIRST rendered there again - old clip window, even a silent or pre-silence one -
+        and ``_audio_index`` does not advance on the hit (:634-635 run inside the miss only).  With pose_cache=True the
+        column observer does the same: a per-env map pose -> row of a device-side pool; hits are device-to-device row
+        copies, misses are rendered and stored; an env's map is dropped when its scene or sound changes (:395-397).
+        Ignored with a distractor (the reference bypasses its caches then, :679-681).  Default False: every step renders
+        the cache-miss path (identical for 1-s sounds, whose window never changes)."""
         self.ctx, self.state, self.index, self.sr = ctx, state, index, int(sampling_rate)
         self.has_distractor = has_distractor
         self.miss = miss
-        self.native = native and hasattr(ctx, "observe_sims")
+        self.pose_cache = bool(pose_cache) and not has_distractor
+        self._pose_maps: List[Dict[int, int]] = [dict() for _ in range(state.n)]
+        self._pose_tag = np.full((state.n, 2), -2, np.int64)      # (scene, sound) the env's map belongs to
+        self._pool: Dict[str, object] = {}                       # output name -> [capacity, ...] device tensor of cached rows
+        self._pool_free: List[int] = []
+        self._pool_cap = 0
+        self.pose_hits = self.pose_misses = 0
+        self.native = native and hasattr(ctx, "observe_sims") and not self.pose_cache
         self._bound, self._bound_version = None, -1
         self._rollouts, self._names = None, []
         self._clip_len = np.zeros((0,), np.int64)
@@ -269,8 +284,9 @@ class FastVectorAudioObserver:
             self._clip_len = np.asarray(self.ctx.lengths, np.int64)
         return self._clip_len
 
-    def columns(self):
-        """State -> the unit columns of this step (and advance ``_audio_index`` like simulator.py:634-635)."""
+    def columns(self, hold: Optional[np.ndarray] = None):
+        """State -> the unit columns of this step (and advance ``_audio_index`` like simulator.py:634-635).  hold: envs
+        (bool mask) served from the pose cache this step: rendered as silent rows, index not advanced."""
         st, sr = self.state, self.sr
         if st.dirty.any():
             st.resolve_sounds(self.ctx.add_source)
@@ -286,6 +302,8 @@ class FastVectorAudioObserver:
         if self.miss is not None:
             for i in np.flatnonzero((rir < 0) & ~silent):
                 rir[i] = self.miss(int(i), int(st.recv[i]), int(st.src[i]), int(az[i]))
+        if hold is not None:
+            silent = silent | hold                            # no render, no RIR needed for a hit
         cols = dict(sound=np.where(silent, 0, st.sound), t0=np.where(silent, 0, t0), rir=np.where(silent, -1, rir))
         bad = (cols["rir"] < 0) & ~silent
         if self.has_distractor:                                                                      # :649-664
@@ -302,6 +320,8 @@ class FastVectorAudioObserver:
             raise KeyError(f"no RIR loaded for env {i}: (scene {int(st.scene[i])}, receiver {int(st.recv[i])}, source "
                            f"{int(st.src[i])}, azimuth {int(az[i])}) - pass miss= to load pairs on demand")
         adv = multi & ~silent & (clip_len >= sr)          # (clips shorter than 1 s never advance: len // sr == 0)
+        if hold is not None:                              # pose-cache hits: the reference does not run _compute_audiogoal
+            adv &= ~hold
         if adv.any():
             st.audio_index[adv] = (st.audio_index[adv] + 1) % (clip_len[adv] // sr)               # :635
         return cols
@@ -309,6 +329,8 @@ class FastVectorAudioObserver:
     def observe(self, spectrogram_out=None, audiogoal_out=None) -> None:
         """Native path (default): the per-step host work runs inside libss_hip.so (``ss_ctx_observe_sims``) on pointers
         to the state columns; ``native=False`` keeps the numpy formulation of ``columns()`` (same results, tested)."""
+        if self.pose_cache:
+            return self._observe_with_pose_cache(spectrogram_out, audiogoal_out)
         if not self.native:
             self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns())
             return
@@ -332,6 +354,64 @@ class FastVectorAudioObserver:
                 if self.has_distractor and st.dis_sound[i] >= 0:
                     self.miss(i, int(st.recv[i]), int(st.dis_src[i]), int(az[i]))
         raise KeyError("RIR pairs still missing after the miss loader ran (it must enter them into the RirIndex)")
+
+    # ---- reference-exact pose cache (see __init__) ---------------------------------------------------------------------
+    def _pool_rows(self, outs, need: int) -> List[int]:
+        import torch
+        while len(self._pool_free) < need:                   # grow the pools (contents kept)
+            new_cap = max(256, 2 * self._pool_cap)
+            for name, t in outs.items():
+                grown = torch.empty((new_cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                if name in self._pool:
+                    grown[:self._pool_cap] = self._pool[name]
+                self._pool[name] = grown
+            self._pool_free += list(range(new_cap - 1, self._pool_cap - 1, -1))
+            self._pool_cap = new_cap
+        return [self._pool_free.pop() for _ in range(need)]
+
+    def _observe_with_pose_cache(self, spectrogram_out, audiogoal_out) -> None:
+        import torch
+        st = self.state
+        if st.dirty.any():
+            st.resolve_sounds(self.ctx.add_source)
+        outs = {k: v for k, v in (("spectrogram", spectrogram_out), ("audiogoal", audiogoal_out)) if v is not None}
+        if set(self._pool) - set(outs) or (self._pool and set(outs) - set(self._pool)):
+            raise ValueError("pose_cache: the observer must be asked for the same outputs every step")
+        n = st.n
+        az = (-st.rot) % 360
+        key = (st.src << 40) | (st.recv << 20) | az           # (source, receiver, azimuth): simulator.py:683
+        hit_rows, hit_pool, miss_rows = [], [], []
+        for i in range(n):                                    # per-env maps: this mode trades the column path's speed for
+            tag = (int(st.scene[i]), int(st.sound[i]))        # the reference's exact cache semantics
+            if tag != (int(self._pose_tag[i, 0]), int(self._pose_tag[i, 1])):      # scene / sound changed (:395-397)
+                self._pool_free += list(self._pose_maps[i].values())
+                self._pose_maps[i].clear()
+                self._pose_tag[i] = tag
+            j = self._pose_maps[i].get(int(key[i]))
+            if j is None:
+                miss_rows.append(i)
+            else:
+                hit_rows.append(i)
+                hit_pool.append(j)
+        hold = np.zeros((n,), bool)
+        hold[hit_rows] = True
+        self.pose_hits += len(hit_rows)
+        self.pose_misses += len(miss_rows)
+        self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns(hold=hold))
+        dev = next(iter(outs.values())).device
+        if miss_rows:                                         # store what was rendered (silent rows included: the
+            slots = self._pool_rows(outs, len(miss_rows))     # reference caches its zeros under the pose as well)
+            for i, j in zip(miss_rows, slots):
+                self._pose_maps[i][int(key[i])] = j
+            mi = torch.as_tensor(miss_rows, dtype=torch.long, device=dev)
+            sj = torch.as_tensor(slots, dtype=torch.long, device=dev)
+            for name, t in outs.items():
+                self._pool[name].index_copy_(0, sj, t.index_select(0, mi))
+        if hit_rows:
+            hi = torch.as_tensor(hit_rows, dtype=torch.long, device=dev)
+            hj = torch.as_tensor(hit_pool, dtype=torch.long, device=dev)
+            for name, t in outs.items():
+                t.index_copy_(0, hi, self._pool[name].index_select(0, hj))
 
     def observe_into(self, rollouts):
         """Render this vector step straight into the rollout rows the next ``rollouts.insert()`` fills

@@ -135,3 +135,34 @@ def test_cpp_request_lookup_equals_the_numpy_columns():
     t = ctx.request_tables(res._sound_keys, res._sound_ids, res._table_keys, res._table_ids, res._pair_keys, res._pair_slots,
                            stale=stale)
     assert ctx.requests_units(buf, n_env, t)[1].shape[0] >= 1
+
+
+@pytest.mark.parametrize("engine_cls", [OracleColumnEngine, OracleEngine])
+def test_deferred_pose_cache_equals_the_eager_adapter_step_for_step(engine_cls):
+    """attach_deferred(..., pose_cache=True): the worker keeps the reference's per-pose memo in the simulator's own cache
+    dict (simulator.py:678-701, dropped by reconfigure, :395-397), a hit travels as (pose, epoch) and the trainer returns
+    the row it stored when the pose was first rendered - deferred mode equals the eager adapter step for step on a 3-s
+    sound (standing still, coming back, silence, a sound change), on the column path and on the request walk."""
+    from ss_amd import sim_audio
+    sounds, files = make_world()
+    sim, twin = FakeSim(SR, sounds, files), FakeSim(SR, sounds, files)
+    attach_deferred(sim, env_rank=0, pose_cache=True)
+    back = sim_audio.HipSimAudio(twin, OracleEngine(SR), rir_reader=files.get)
+    res = DeferredResolver(engine_cls(SR), rir_reader=files.get)
+    script = [(1, 90, 0, "long.wav"), (1, 90, 1, "long.wav"), (3, 90, 2, "long.wav"), (1, 90, 3, "long.wav"), (2, 180, 4, "long.wav"),
+              (2, 180, 7, "long.wav"), (0, 0, 8, "long.wav"), (1, 90, 9, "telephone.wav"), (1, 90, 10, "telephone.wav")]
+    hits = 0
+    for step, (recv, rot, cnt, snd) in enumerate(script):
+        for x in (sim, twin):
+            if x._current_sound != snd:
+                x._current_sound, x._audio_index = snd, 0
+                x._audiogoal_cache, x._spectrogram_cache = dict(), dict()          # reconfigure (:395-397)
+            x._receiver_position_index, x._rotation_angle, x._episode_step_count, x._duration = recv, rot, cnt, 6
+        q = pickle.loads(pickle.dumps(sim.get_current_spectrogram_observation(None)))
+        hits += q.cache_hit
+        out = res.resolve([q], want_audiogoal=True)
+        e_sg, e_ag = back.get_current_spectrogram_observation(), back.get_current_audiogoal_observation()
+        assert torch.allclose(out["spectrogram"][0], torch.from_numpy(np.asarray(e_sg, np.float32)), atol=1e-6), step
+        assert torch.allclose(out["audiogoal"][0], torch.from_numpy(np.asarray(e_ag, np.float32)), atol=1e-6), step
+        assert sim._audio_index == twin._audio_index, step
+    assert hits == 4                                                             # steps 1, 3, 5 (cached pose outlives the sound), 8

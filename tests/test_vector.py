@@ -255,3 +255,52 @@ def test_column_mode_renders_every_step_where_the_reference_pose_cache_freezes_t
     h = files[f"rirs/replica/apartment_0/{(-90) % 360}/1_2.wav"]
     ref = O.compute_spectrogram(O.compute_audiogoal(clip, h, SR, audio_index=1))
     assert O.relerr(sg[0].numpy(), ref) < 1e-5
+
+
+def test_pose_cache_mode_equals_the_reference_cache_step_for_step_on_a_3s_sound():
+    """``FastVectorAudioObserver(pose_cache=True)`` reproduces the reference's per-pose memo
+    (simulator.py:678-701: key (source, receiver, azimuth), `_audio_index` advanced inside the miss only, :634-635; caches
+    dropped on a scene / sound change, :395-397) - column mode equals eager mode STEP FOR STEP on a multi-second sound:
+    standing still, leaving and coming back (the old window returns), silence after `_duration` (a cached pose keeps
+    sounding, a new pose caches its zeros), a sound change."""
+    n = 2
+    sims, sounds, files, store, index = world(n, seconds=(3, 1))
+    names = list(sounds)
+    twins = []
+    eng = OracleEngine(SR)
+    for s_ in sims:
+        t = FakeSim(SR, sounds, files)
+        t.binaural_rir_dir = s_.binaural_rir_dir
+        twins.append((t, sim_audio.HipSimAudio(t, eng, rir_reader=t.reader)))
+    bank = lambda slot: store.bank.data[slot, :, :int(store.host_len[slot])].numpy().T
+    ctx = OracleContext(SR, bank)
+    state = VectorSimState(n)
+    for i, s_ in enumerate(sims):
+        state.bind(s_, i)
+        state.scene[i] = index.scene_id(s_.binaural_rir_dir.split("/")[-1])
+    obs = FastVectorAudioObserver(ctx, state, index, SR, pose_cache=True)
+    assert not obs.native
+    # (receiver, rotation, step_count, sound) per step and env; duration 6: steps 7+ are silent
+    script = [((1, 90, 0, 0), (2, 0, 0, 0)), ((1, 90, 1, 0), (2, 0, 1, 0)),      # stand still: hit, index frozen
+              ((3, 90, 2, 0), (2, 90, 2, 0)), ((1, 90, 3, 0), (2, 0, 3, 0)),      # move; come back: the FIRST window returns
+              ((4, 180, 4, 0), (4, 0, 4, 0)), ((4, 180, 7, 0), (1, 0, 7, 0)),     # silence: cached pose still sounds, new pose caches zeros
+              ((1, 90, 8, 1), (1, 0, 8, 0)),                                      # env 0 changes its sound: its map is dropped
+              ((1, 90, 9, 1), (2, 0, 9, 0))]
+    sg, ag = torch.zeros((n, 65, 26, 2)), torch.zeros((n, 2, SR))
+    for step, moves in enumerate(script):
+        for (s_, (t, _)), (recv, rot, cnt, snd) in zip(zip(sims, twins), moves):
+            for x in (s_, t):
+                if x._current_sound != names[snd]:
+                    x._current_sound, x._audio_index = names[snd], 0
+                    x._audiogoal_cache, x._spectrogram_cache = {}, {}                # what reconfigure does (:395-397); the
+                x._receiver_position_index, x._source_position_index, x._rotation_angle = recv, 2, rot     # observer sees the
+                x._episode_step_count, x._duration = cnt, 6                           # sound id change in its columns
+        obs.observe(spectrogram_out=sg, audiogoal_out=ag)
+        for i, (t, back) in enumerate(twins):
+            e_sg = back.get_current_spectrogram_observation()
+            e_ag = back.get_current_audiogoal_observation()
+            assert torch.allclose(sg[i], torch.from_numpy(np.asarray(e_sg, np.float32)), atol=1e-6), (step, i)
+            assert torch.allclose(ag[i], torch.from_numpy(np.asarray(e_ag, np.float32)), atol=1e-6), (step, i)
+            assert sims[i]._audio_index == t._audio_index, (step, i)
+    assert obs.pose_hits >= 5 and obs.pose_misses >= 8
+    # and without the switch the same script diverges at the first hit (the documented difference, tested above)
