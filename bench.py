@@ -336,18 +336,22 @@ def dist_of(ms):
 
 
 def measured_traffic(units, sr, kernel):
-    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r3/traffic.json written by
-    scripts/gpu_profile_r3.sh with the hash of the kernel sources): null when the sources have changed since."""
+    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r4/traffic.json written by
+    scripts/gpu_profile_r4.sh with the hash of the kernel sources): null when the sources have changed since.  Both
+    counters carry the factor measured in the same pass on a known byte count in the kernel's dominant access pattern
+    (scripts/calib_traffic.hip)."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r3", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r4", "traffic.json")))
         have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.srchash")).read().strip()
         e = tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
-            corr = float(e.get("fetch_correction", 1.0))
-            return {"bytes": int(corr * e["fetch_bytes"] + e["write_bytes"]), "fetch_bytes_raw": int(e["fetch_bytes"]),
-                    "fetch_correction": corr, "write_bytes": int(e["write_bytes"]), "tcc_hit_rate": e.get("tcc_hit_rate"),
-                    "traffic_source": "profiles/r3 rocprofv3 --pmc pass of this build (source hash matches), not measured in this run",
-                    "note": e.get("note", "") + "; " + e.get("correction_note", "")}
+            fc, wc = float(e.get("fetch_correction", 1.0)), float(e.get("write_correction", 1.0))
+            return {"bytes": int(fc * e["fetch_bytes"] + wc * e["write_bytes"]), "fetch_bytes_raw": int(e["fetch_bytes"]),
+                    "fetch_correction": fc, "write_bytes_raw": int(e["write_bytes"]), "write_correction": wc,
+                    "calibrated_on": {"fetch": e.get("fetch_pattern"), "write": e.get("write_pattern")},
+                    "tcc_hit_rate": e.get("tcc_hit_rate"),
+                    "traffic_source": "profiles/r4 rocprofv3 --pmc pass of this build (source hash matches), not measured in this run",
+                    "note": e.get("note", "")}
     except Exception:
         pass
     return None
@@ -817,6 +821,8 @@ def main():
         bpu = (b["fused"] + (2 * sr * 4 if args.with_audiogoal else 0)) if fused else b["conv"] + b["spec"]
         if savi:
             bpu = 2 * (2 * L * 4) + 2 * sr * 4 + 65 * t4 * 2 * 4        # two RIRs read, waveform and spectrogram written
+            kname = kname.replace("<FUSE=true>", "<FUSE=true,loop>")    # distractor terms: the two-term loop instantiation
+        traffic_kernels = [kname] + (["k_features<" + ",".join(feats) + ">"] if feats else [])
         if feats:                                             # k_features: the waveform read once more, the features written
             T_fr = 1 + sr // 160
             bpu += 2 * sr * 4 + (64 * T_fr * 2 * 4 if "logmel" in feats else 0) + (65 * T_fr * 4 if "gccphat" in feats else 0)
@@ -863,10 +869,10 @@ def main():
                          "pipeline_achieved": round(bpu * N / (elapsed / args.steps) / 1e9, 1),
                          "pipeline_frac": round(bpu * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        tr = measured_traffic(N, sr, kname)
-        if tr is not None:
-            out["roofline"]["traffic"] = tr["bytes"]
-            out["roofline"]["traffic_detail"] = tr
+        trs = [measured_traffic(N, sr, k_) for k_ in traffic_kernels]
+        if all(t_ is not None for t_ in trs):
+            out["roofline"]["traffic"] = sum(t_["bytes"] for t_ in trs)
+            out["roofline"]["traffic_detail"] = trs[0] if len(trs) == 1 else dict(zip(traffic_kernels, trs))
         if step_dist:
             out["gpu_ms_per_step"] = step_dist
         if fused and sr <= P.KB:
