@@ -103,6 +103,10 @@ for cfg in ("headline", "cfg2", "cfg4"):
             f_kib = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]); w_kib = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
             rd, wr = dominant[nm]
             fc = calib.get(rd, {}).get("factor", 1.0); wc = calib.get(wr, {}).get("factor", 1.0)
+            if wr == "wr4":
+                wc = 1.0        # WRITE_SIZE counts the bytes that MOVE: 4-byte stores to every other float of a line are written
+                                # as whole sectors (calibration: 2x the bytes stored) - that IS the traffic; the factor 0.5 would
+                                # turn it back into bytes stored
             kernels[nm] = {
                 "units_per_launch": bench["config"]["units_per_gpu"], "sampling_rate": bench["config"]["sampling_rate"],
                 "fetch_bytes": f_kib * 1024, "write_bytes": w_kib * 1024,

@@ -36,7 +36,7 @@ struct FeatParams {
     Tables tb;
     const int* mel_start;  // [n_mels]
     const float* mel_w;    // [n_mels][max_len]
-    int len, n_frames, t4, pad_mode, gpw;
+    int len, n_frames, t4, pad_mode, n_units;
     int n_mels, max_len, max_lag;
     float mel_eps, gcc_eps;
 };
@@ -144,13 +144,22 @@ __device__ __forceinline__ void ear_power_features(c32* sc, int lane, const EarX
                 // band starts and max_len are multiples of 4 (ABI contract): two aligned 16-byte LDS reads per 4 bins
                 const f32x4* pj = reinterpret_cast<const f32x4*>(pw + s_start[j]);
                 const f32x4* wj = reinterpret_cast<const f32x4*>(s_w + j * max_len);
-                c32 acc = mk2(0.f, 0.f);
+                c32 acc = mk2(0.f, 0.f), acc2 = mk2(0.f, 0.f);
                 const int steps = s_glen[g];
-                for (int i = 0; i < steps; ++i) {
-                    const f32x4 a = wj[i], b = pj[i];
+                int i = 0;
+                for (; i + 1 < steps; i += 2) {                            // two 4-bin steps in flight: four loads, then the math
+                    const f32x4 a = wj[i], b = pj[i], a2 = wj[i + 1], b2 = pj[i + 1];
                     acc = acc + mk2(a.x * b.x, a.y * b.y);                 // (v_pk_fma_f32: two bins per instruction)
+                    acc2 = acc2 + mk2(a2.x * b2.x, a2.y * b2.y);
                     acc = acc + mk2(a.z * b.z, a.w * b.w);
+                    acc2 = acc2 + mk2(a2.z * b2.z, a2.w * b2.w);
                 }
+                if (i < steps) {
+                    const f32x4 a = wj[i], b = pj[i];
+                    acc = acc + mk2(a.x * b.x, a.y * b.y);
+                    acc2 = acc2 + mk2(a.z * b.z, a.w * b.w);
+                }
+                acc = acc + acc2;
 #if defined(__HIP_DEVICE_COMPILE__)
                 mel_store(j, f, __builtin_amdgcn_logf(acc.x + acc.y + mel_eps) * 0.69314718055994531f);
 #else
@@ -207,11 +216,13 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
     __shared__ int s_start[kFeatMaxMels];
     __shared__ int s_glen[kFeatMaxMels / 16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, q = lane & 15;
-    const int groups = (p.n_frames + kSegFrames - 1) / kSegFrames, chunks = (groups + p.gpw - 1) / p.gpw;
-    const int unit = blockIdx.x / chunks, g0 = (blockIdx.x % chunks) * p.gpw, g1 = min(groups, g0 + p.gpw);
+    // Rounds: task = (unit, group of 16 frames), task id = unit * groups + group.  Workgroup b takes tasks b, b + G, b + 2G ...
+    // (G = gridDim.x <= two per CU): 1792 tasks on 512 workgroups = 4 rounds for the first 256 workgroups and 3 for the
+    // others - one of each kind per CU - instead of 4 for everybody when a workgroup owned a contiguous range of one unit's groups
+    const int groups = (p.n_frames + kSegFrames - 1) / kSegFrames;
+    const int n_tasks = p.n_units * groups, G = (int)gridDim.x;
     constexpr bool want_mel = MEL, want_sg = SG, want_gcc = GCC;
     const int n_lags = 2 * p.max_lag + 1;
-    const float* row0 = p.x + (size_t)unit * 2 * p.len;
     f32x4* seg4 = reinterpret_cast<f32x4*>(sc);
     const float* seg_r = reinterpret_cast<const float*>(sc);                 // right ear: quads [0, 728)
     const float* seg_l = seg_r + kSegLen;                                    // left ear: over the scratches
@@ -223,9 +234,11 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
     // per ear).  (The helper of the stand-alone kernels resolves the padding per lane at load time: a ~300-instruction
     // edge path with dependent scalar loads, inlined at every call site.)
     const int len = p.len;
-    const bool vec_ok = !(len & 3) && !(reinterpret_cast<size_t>(row0) & 15);
+    const bool vec_ok = !(len & 3) && !(reinterpret_cast<size_t>(p.x) & 15);        // (rows are 2 len floats apart)
     f32x4 r[6];
-    auto fetch = [&](int g) {
+    auto fetch = [&](int task) {
+        const int unit = task / groups, g = task - unit * groups;
+        const float* row0 = p.x + (size_t)unit * 2 * len;
         const int s0 = kHop * kSegFrames * g - kNfft / 2;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
     for (int e = t; e < kNfft; e += 256) s_win[e] = p.tb.win[e];
     s_tw512[posN(t)] = p.tb.tw512[t];
     if (t < kFeatMaxMels / 16) s_glen[t] = 0;
-    fetch(g0);
+    if ((int)blockIdx.x < n_tasks) fetch(blockIdx.x);
     if (want_mel) {
         if (t < p.n_mels) s_start[t] = p.mel_start[t];
         for (int e = t; e < p.n_mels * p.max_len; e += 256) s_w[e] = p.mel_w[e];      // (independent loads: pipelined)
@@ -263,7 +276,9 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
     c32 wq = p.tb.twM[64 * q];
     SSK_OPAQUE2(wq);                                        // see k_spectrogram
     const float eps4 = 4.f * p.gcc_eps;                     // the split yields 2X, so the products carry a factor 4
-    for (int g = g0; g < g1; ++g) {
+    for (int task = blockIdx.x; task < n_tasks; task += G) {
+        const int unit = task / groups, g = task - unit * groups;
+        const float* row0 = p.x + (size_t)unit * 2 * len;
         c32 xl[16];
         const int fl = 4 * wv + (lane >> 4);                // frame of this lane within the group
         {
@@ -296,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
             }
             lds_barrier();                                  // left segment dead: the wave scratches overlay it
         }
-        if (g + 1 < g1) fetch(g + 1);                       // next round's segments in flight under this round's math
+        if (task + G < n_tasks) fetch(task + G);            // next round's segments in flight under this round's math
         if (kSegFrames * g + 4 * wv < p.n_frames) {         // wave-uniform: at least one live frame in this block
             c32* wsc = sc + kFeatSegComplex + wv * kWaveScratch;
             EarXY L, R;

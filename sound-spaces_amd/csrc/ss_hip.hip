@@ -444,14 +444,13 @@ int ss_audio_features_f32(const float* x, int n_units, int len, int pad_mode, fl
     p.n_mels = logmel ? n_mels : 0; p.max_len = logmel ? max_len : 4; p.max_lag = gccphat ? max_lag : 1;
     p.mel_eps = mel_eps; p.gcc_eps = gcc_eps;
     const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
-    // two ~80 KiB workgroups per CU: with more (unit, group) rounds than that, a workgroup walks several groups of its unit
-    // (tables staged once, the next round's segments prefetched) so that the launch is ONE wave of resident workgroups
+    // two ~80 KiB workgroups per CU: one wave of resident workgroups that share the (unit, group) rounds round-robin (tables
+    // staged once per workgroup, the next round's segments prefetched under the current round's math)
     int n_cus = 256;
     { ssk::Tables unused; (void)get_tables(&unused, &n_cus); }
-    long long gpw = ((long long)n_units * groups + 2LL * n_cus - 1) / (2LL * n_cus);
-    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : (int)gpw;
-    const int chunks = (groups + p.gpw - 1) / p.gpw;
-    const dim3 grid(n_units * chunks), block(256);
+    p.n_units = n_units;
+    const long long tasks = (long long)n_units * groups;
+    const dim3 grid(static_cast<unsigned>(tasks < 2LL * n_cus ? tasks : 2LL * n_cus)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int which = (logmel ? 1 : 0) | (spectrogram ? 2 : 0) | (gccphat ? 4 : 0);
     switch (which) {

@@ -415,10 +415,11 @@ int hs_features(const float* x, int n_units, int len, int pad_mode, float* sgram
     if (mel && (n_mels > ssk::kFeatMaxMels || max_len > ssk::kFeatMaxLen || (max_len & 3) || n_mels * max_len > ssk::kFeatMelTable)) return -2;
     if (gcc && (max_lag < 1 || max_lag > ssk::kGccMaxLag)) return -2;
     const int groups = (p.n_frames + ssk::kSegFrames - 1) / ssk::kSegFrames;
-    p.gpw = gpw < 1 ? 1 : gpw > groups ? groups : gpw;
-    const int chunks = (groups + p.gpw - 1) / p.gpw;
-    gridDim = dim3{(unsigned)(n_units * chunks), 1, 1};
-    for (int b = 0; b < n_units * chunks; ++b) {
+    p.n_units = n_units;
+    const int tasks = n_units * groups;                 // gpw: rounds per workgroup wanted -> grid = ceil(tasks / gpw)
+    const int wgs = (tasks + (gpw < 1 ? 1 : gpw) - 1) / (gpw < 1 ? 1 : gpw);
+    gridDim = dim3{(unsigned)wgs, 1, 1};
+    for (int b = 0; b < wgs; ++b) {
         blockIdx = dim3{(unsigned)b, 0, 0};
         int rc = run_block(256, [&] {
             const int which = (mel ? 1 : 0) | (sgram ? 2 : 0) | (gcc ? 4 : 0);
