@@ -47,6 +47,12 @@ class AudioRequest:
     dis_rir_key: Optional[str] = None
     live_rir: Optional[np.ndarray] = None         # SS2.0 / habitat_sim audio sensor: the RIR itself, [L, 2] float32
     last_rir: Optional[np.ndarray] = None         # SS2.0 CROSSFADE: the previous step's RIR
+    # SS2.0: sequence numbers of the worker's live RIRs (> 0).  `_last_rir` is the RIR the worker sent as `live_rir` one
+    # request earlier (continuous_simulator.py:384) - the worker checks that (its own compare, in its own process) and says
+    # so with `last_seq = live_seq - 1`: the trainer finds the row it already holds by number instead of comparing 72 KB
+    # against each held row per env and step
+    live_seq: int = 0
+    last_seq: int = 0
     wrap: Optional[bool] = None
     last_wrap: Optional[bool] = None
     # SS1.0 requests against RIR files: the same facts as REC_N packed int64 words (bytes), so that the trainer turns the
@@ -148,10 +154,18 @@ class DeferredSimAudio:
             req.t0 = int(sim._current_sample_index)
             req.live_rir = np.ascontiguousarray(rir)
             req.wrap = req.t0 - rir.shape[0] >= 0                                    # cont. :433 vs :438-447
+            self._live_seq = getattr(self, "_live_seq", 0) + 1                       # (one _request per simulator state: request())
+            req.live_seq = self._live_seq
             last = getattr(sim, "_last_rir", None)
             if sim.config.AUDIO.CROSSFADE and last is not None:                      # cont. :422
-                req.last_rir = np.ascontiguousarray(last, dtype=np.float32)
-                req.last_wrap = req.t0 - req.last_rir.shape[0] >= 0
+                last = np.ascontiguousarray(last, dtype=np.float32)
+                req.last_wrap = req.t0 - last.shape[0] >= 0
+                prev = getattr(self, "_live_prev", None)
+                from .sim_audio import same_rir
+                req.last_rir = last
+                if prev is not None and same_rir(prev, last):                        # the array of the previous request: the
+                    req.last_seq = self._live_seq - 1                                # trainer holds it under that number
+            self._live_prev = req.live_rir
             return req
         if clip.shape[0] != sr:                                                      # simulator.py:634-635
             req.t0 = sim._audio_index * sr
@@ -211,6 +225,7 @@ class DeferredResolver:
         self.rir_reader = rir_reader or wav_rir_reader
         self._clips: Dict[str, np.ndarray] = {}
         self._live: Dict[int, list] = {}          # env -> [held arrays, slots, turn] (see HipContinuousSimAudio)
+        self._live_seq: Dict[int, list] = {}      # env -> [held sequence numbers, slots, turn] (numbered live RIRs)
         # column path (engines that own a C++ context: ss_amd.renderer.AudioEngine on a GPU).  CRC keys -> ids through
         # sorted arrays (np.searchsorted), RIR slots through dense (table, receiver, source) tables
         store = getattr(engine, "store", None)
@@ -245,11 +260,34 @@ class DeferredResolver:
             raise KeyError(f"deferred audio: the clip of sound {name!r} never arrived (worker restarted?)")
         return self.engine.source_id(name, self._clips[name])
 
+    def _live_slot_seq(self, env: int, seq: int, rir: Optional[np.ndarray], avoid: int = -1) -> int:
+        """Bank slot of env's live RIR number `seq` (workers that number their RIRs): no content compares.  rir = None: the
+        row must still be held (it was this env's `live_rir` one request ago)."""
+        st = self._live_seq.setdefault(env, [[0, 0], [-1, -1], [0]])
+        seqs, slots, turn = st
+
+        def gone():
+            raise KeyError(f"deferred audio: env {env}'s live RIR {seq} is no longer in the store (rir_slots < 2 per env?)")
+        for k in (0, 1):
+            if seqs[k] == seq:
+                slots[k] = self.engine.rir_slot(("live", env, k), (lambda: rir) if rir is not None else gone, refresh=False)
+                return slots[k]
+        if rir is None:
+            gone()
+        k = turn[0]
+        if slots[k] == avoid and avoid >= 0:
+            k ^= 1
+        turn[0] = k ^ 1
+        seqs[k] = seq
+        slots[k] = self.engine.rir_slot(("live", env, k), lambda: rir, refresh=True)
+        return slots[k]
+
     def _live_slot(self, env: int, rir: np.ndarray, avoid: int = -1) -> int:
+        from .sim_audio import same_rir
         held, slots, turn = self._live.setdefault(env, [[None, None], [-1, -1], [0]])
         for k in (0, 1):
             h = held[k]
-            if h is not None and (h is rir or (h.shape == rir.shape and np.array_equal(h, rir))):
+            if h is not None and same_rir(h, rir):
                 # through the store even on a content match: touches the LRU, marks the slot as used by this batch and
                 # re-uploads the row if the store has meanwhile given the slot to another key (ADVICE r2)
                 slots[k] = self.engine.rir_slot(("live", env, k), lambda: rir, refresh=False)
@@ -271,7 +309,13 @@ class DeferredResolver:
                 out.append(UnitRequest(silent=True))
                 continue
             u = UnitRequest(sound=self._sound(q.sound, q.clip), t0=q.t0, wrap=q.wrap, last_wrap=q.last_wrap)
-            if q.live_rir is not None:
+            if q.live_rir is not None and q.live_seq > 0:                 # numbered live RIRs (SS2.0 workers of this version)
+                u.rir = self._live_slot_seq(q.env, q.live_seq, q.live_rir)
+                if q.last_seq > 0:
+                    u.last_rir = self._live_slot_seq(q.env, q.last_seq, q.last_rir, avoid=u.rir)
+                elif q.last_rir is not None:                                  # not the previous request's array: sent in full
+                    u.last_rir = self._live_slot_seq(q.env, -q.live_seq, q.last_rir, avoid=u.rir)
+            elif q.live_rir is not None:
                 u.rir = self._live_slot(q.env, q.live_rir)
                 if q.last_rir is not None:
                     u.last_rir = self._live_slot(q.env, q.last_rir, avoid=u.rir)

@@ -445,6 +445,13 @@ class RirStore:
         self.slots, self.cap, self.group = slots, cap, group
         self.truncate_to, self.max_cap, self.on_grow = truncate_to, max_cap, on_grow
         self.on_evict = None                                   # on_evict(key, slot): the entry of `key` is about to be reused
+        self.defer_uploads = False                             # True (AudioEngine): single-row uploads queue up for flush_uploads()
+        self._pending: Dict[int, tuple] = {}
+        self._flush_stage = None
+        self._flush_stage_wav = None
+        self._flush_ev = None
+        self._idx_cache: Dict[tuple, torch.Tensor] = {}
+        self._dev_len = np.full((slots,), -1, np.int32)       # lengths the DEVICE holds for rows written by flush_uploads
         self.host_len = np.zeros((slots,), np.int32)          # host mirror of bank.lengths (branch selection, planning)
         self._slot_of: Dict[object, int] = {}      # insertion order == LRU order (oldest first)
         self._free: List[int] = list(range(slots - group, -1, -group))
@@ -476,9 +483,11 @@ class RirStore:
             for key, slot in list(self._slot_of.items()):
                 self.on_evict(key, slot)
         self._slot_of.clear()
+        self._pending = {}
         self._free = list(range(self.slots - self.group, -1, -self.group))
         self.host_len[:] = 0
         self.bank.lengths.zero_()
+        self._dev_len[:] = -1
         self._clipped[:] = False
 
     # ---- capacity ------------------------------------------------------------------------------------------
@@ -525,6 +534,15 @@ class RirStore:
         n = self._kept_len(r.shape[1])
         self._clipped[slot] = n < r.shape[1]
         self._ensure_cap(n)
+        if self.defer_uploads:
+            # batched mode (AudioEngine): the row crosses PCIe with the step's other new rows, as ONE pinned block and ONE
+            # H2D copy, when the engine flushes before its launch (flush_uploads).  SoundSpaces 2.0 hands every env a new
+            # RIR every step (continuous_simulator.py:419): 128 single-row copies + 128 one-element length fills per step
+            # were the whole cost of its batched and deferred modes
+            self._pending[slot] = (r, n)
+            self.host_len[slot] = n
+            self._stale[slot] = True
+            return
         row_t, row, k = self._stage_row()
         row[:, :n] = r[:, :n]
         row[:, n:] = 0.0
@@ -534,12 +552,89 @@ class RirStore:
             ev.record()
             self._stage_ev[k] = ev
         self.bank.lengths[slot:slot + 1].fill_(n)
+        self._dev_len[slot] = n
         self.host_len[slot] = n
         self._stale[slot] = True
+
+    def flush_uploads(self) -> int:
+        """defer_uploads mode: every row queued by slot() / _upload since the last flush -> pinned staging blocks, one H2D
+        copy per block, one row scatter, one length scatter.  Rows that arrived in wav layout ([L, 2] contiguous: what
+        ``np.transpose`` of the ray tracer's [2][L] lists pickles to) are staged AS THEY ARE - one contiguous memcpy each -
+        and transposed into the planar bank rows on the device; a strided host-side transpose of 128 x
+        72 KB per step was most of the trainer half of SoundSpaces 2.0's deferred mode.  Returns the rows uploaded."""
+        if not self._pending:
+            return 0
+        slots = sorted(self._pending)
+        rows = [self._pending[sl] for sl in slots]
+        self._pending = {}
+        pin = self.device.type == "cuda"
+        if pin and self._flush_ev is not None:
+            self._flush_ev.synchronize()                       # the copies that last read the staging blocks have run
+        wav = [j for j, (r, n) in enumerate(rows) if n > 0 and r.T.flags.c_contiguous and not r.flags.c_contiguous]
+        wav_set = set(wav)
+        pla = [j for j in range(len(rows)) if j not in wav_set]
+        lens = np.asarray([n for _, n in rows], np.int32)
+
+        def stage(which, shape_tail, attr):
+            blk = getattr(self, attr)
+            if blk is None or blk.shape[0] < len(which) or tuple(blk.shape[1:]) != shape_tail:
+                blk = torch.zeros((max(len(which), 64),) + shape_tail, dtype=torch.float32, pin_memory=pin)
+                setattr(self, attr, blk)
+            return blk, blk.numpy()
+
+        def fill(jobs):                                        # (a thread pool for these ~5-us copies was 2.6x SLOWER: GIL hand-offs)
+            for f in jobs:
+                f()
+        jobs = []
+        if pla:
+            pblk, pnp = stage(pla, (2, self.cap), "_flush_stage")
+            for i, j in enumerate(pla):
+                r, n = rows[j]
+
+                def job(i=i, r=r, n=n):
+                    pnp[i, :, :n] = r[:, :n]
+                    pnp[i, :, n:] = 0.0
+                jobs.append(job)
+        if wav:
+            wblk, wnp = stage(wav, (self.cap, 2), "_flush_stage_wav")
+            for i, j in enumerate(wav):
+                r, n = rows[j]
+
+                def job(i=i, r=r, n=n):
+                    wnp[i, :n, :] = r.T[:n]                       # contiguous [n, 2] -> contiguous [n, 2]
+                    wnp[i, n:, :] = 0.0
+                jobs.append(job)
+        fill(jobs)
+        for which, blk_name, transpose in ((pla, "_flush_stage", False), (wav, "_flush_stage_wav", True)):
+            if not which:
+                continue
+            k = len(which)
+            sl = [slots[j] for j in which]
+            dev_blk = getattr(self, blk_name)[:k].to(self.device, non_blocking=True)
+            if transpose:
+                dev_blk = dev_blk.permute(0, 2, 1)                 # [k, cap, 2] -> [k, 2, cap]: transposed by the scatter kernel
+            # live rows alternate between two slot patterns: the index tensors are kept (a list -> device tensor conversion is a
+            # synchronous pageable copy, 0.2 ms), and the length scatter is skipped while the lengths on the device are current
+            key = tuple(sl)
+            idx = self._idx_cache.get(key)
+            if idx is None:
+                if len(self._idx_cache) > 16:
+                    self._idx_cache.clear()
+                idx = self._idx_cache[key] = torch.as_tensor(sl, dtype=torch.long, device=self.device)
+            self.bank.data.index_copy_(0, idx, dev_blk)
+            sl_np = np.asarray(sl)
+            if not np.array_equal(self._dev_len[sl_np], lens[which]):
+                self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens[which]).to(self.device))
+                self._dev_len[sl_np] = lens[which]
+        if pin:
+            self._flush_ev = torch.cuda.Event()
+            self._flush_ev.record()
+        return len(slots)
 
     def sync_spectra(self) -> int:
         """spectral stores: transform the rows loaded since the last call (contiguous runs, one ss_rir_spectra_f32 each;
         synchronous - this is bank-load work, steady-state steps find nothing to do).  Returns the rows transformed."""
+        self.flush_uploads()
         if not self.spectral or self.bank.spectra is None or not self._stale.any():
             return 0
         idx = np.flatnonzero(self._stale)
@@ -661,6 +756,7 @@ class RirStore:
             idx = torch.as_tensor(slots, dtype=torch.long, device=self.device)
             self.bank.data.index_copy_(0, idx, stage.to(self.device, non_blocking=True))
             self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
+            self._dev_len[np.asarray(slots)] = lens
             self.host_len[np.asarray(slots)] = lens
             self._stale[np.asarray(slots)] = True
             self._clipped[np.asarray(slots)] = [n < r.shape[1] for n, r in zip(kept, rows)]
@@ -863,6 +959,7 @@ class AudioEngine:
         self.store = RirStore(rir_slots, rir_cap or sampling_rate, self.renderer.device,
                               truncate_to=None if full else int(sampling_rate), max_cap=rir_max_cap,
                               on_grow=self.renderer.set_rir_bank, group=rir_group, spectral=rir_spectral and not full)
+        self.store.defer_uploads = True            # single-row uploads of a step travel as one block (flushed before every launch)
         self.renderer.set_rir_bank(self.store.bank)
 
     def source_id(self, name: str, clip: np.ndarray) -> int:

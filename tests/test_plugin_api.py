@@ -364,3 +364,36 @@ def test_bucketed_rir_store_routes_by_length_and_never_reallocates_the_short_buc
     assert [st2.bank.bucket_of(g) for g in got] == [0, 1, 0, 0, 1]
     assert [int(st2.host_len[g]) for g in got] == [30, 350, 99, 30, 120]
     assert st2.slot_many(["b", "d"], [loader(1), loader(2)]) == [got[1], got[4]] and len(calls) == 4
+
+
+def test_rir_store_deferred_uploads_travel_as_one_block():
+    """RirStore(defer_uploads=True) - what AudioEngine runs: single-row uploads (live SS2.0 RIRs: a new one per env and step,
+    continuous_simulator.py:419) queue up and reach the bank in ONE staging block at flush_uploads(), which every launch
+    path of the engine calls first; host mirrors (host_len) are current at once."""
+    import torch
+    from ss_amd.renderer import RirStore
+    rng = np.random.default_rng(3)
+    st = RirStore(8, 1000, "cpu")
+    st.defer_uploads = True
+    rirs = {k: rng.standard_normal((int(rng.integers(300, 1000)), 2)).astype(np.float32) for k in "abcde"}
+    slots = {k: st.slot(k, lambda k=k: rirs[k]) for k in "abc"}
+    assert [int(st.host_len[slots[k]]) for k in "abc"] == [rirs[k].shape[0] for k in "abc"]
+    assert not st.bank.data.any() and not st.bank.lengths.any()                    # nothing has crossed yet
+    assert st.flush_uploads() == 3 and st.flush_uploads() == 0
+    for k in "abc":
+        n = rirs[k].shape[0]
+        assert torch.equal(st.bank.data[slots[k], :, :n], torch.from_numpy(rirs[k].T)) and not st.bank.data[slots[k], :, n:].any()
+        assert int(st.bank.lengths[slots[k]]) == n
+    # a live row refreshed twice before the flush: the last array wins; scattered slots; a longer RIR grows the bank first
+    st.slot("a", lambda: rirs["d"], refresh=True)
+    st.slot("a", lambda: rirs["e"], refresh=True)
+    long = rng.standard_normal((1500, 2)).astype(np.float32)
+    sl = st.slot("long", lambda: long)
+    assert st.cap >= 1500 and st.flush_uploads() == 2
+    n = rirs["e"].shape[0]
+    assert torch.equal(st.bank.data[slots["a"], :, :n], torch.from_numpy(rirs["e"].T)) and not st.bank.data[slots["a"], :, n:].any()
+    assert torch.equal(st.bank.data[sl, :, :1500], torch.from_numpy(long.T))
+    assert torch.equal(st.bank.data[slots["b"], :, :rirs["b"].shape[0]], torch.from_numpy(rirs["b"].T))   # untouched rows kept
+    st.slot("c", lambda: rirs["d"], refresh=True)
+    st.clear()
+    assert st.flush_uploads() == 0                                                   # a cleared store forgets what was queued
