@@ -93,10 +93,12 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
 
 /* Fused observation: convolution + spectrogram in ONE launch for rows of up to 3*kB samples (16 kHz: 1 block; 44.1 /
  * 48 kHz, the reference's Replica rate: 3 blocks, STFT streamed behind the output blocks).  audiogoal may be NULL: the
- * waveform then never leaves the CU - cross-faded rows (SS_FLAG_CROSSFADE) included, at either length.  With an audiogoal
- * buffer, rows longer than kB that are cross-faded or have one rendered block (n_valid <= kB: SoundSpaces 2.0 steps at
- * 44.1 kHz) take two launches (convolution, spectrogram), which is 15-20 % faster than their one-launch form.  Pooled
- * blocks that lie behind the rendered samples of a short step are exact zeros and are written, not computed.  For rows longer than kB the library keeps a per-(device, stream) scratch for the block spectra of
+ * waveform then never leaves the CU - cross-faded rows (SS_FLAG_CROSSFADE) included, at either length.  Rows longer than kB
+ * of which ONE block is rendered (n_valid <= kB: every SoundSpaces 2.0 step at 44.1 kHz) are served by the fused loop kernel
+ * in one launch, audiogoal buffer or not (block spectra accumulated in registers; time-domain banks).  With an audiogoal
+ * buffer, cross-faded rows with more than one rendered block take two launches (convolution, spectrogram), which is 20 %
+ * faster than their one-launch form.  Pooled blocks that lie behind the rendered samples of a short step are exact zeros
+ * and are written, not computed.  For rows longer than kB the library keeps a per-(device, stream) scratch for the block spectra of
  * the rows in flight (<= 2 x ceil(rir_cap/kB) x 128 KiB per CU), allocated on the stream's first such call. */
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units,

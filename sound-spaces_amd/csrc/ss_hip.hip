@@ -90,10 +90,32 @@ inline bool fill_unit_tab(ssk::UnitTab<true>& ut, const int* host_desc, int n_un
     return true;
 }
 
+// Rows longer than one block of which only block 0 is rendered (SS2.0 steps at 44.1 kHz: 0.25 s of a 1-s row) and whose live
+// pooled blocks all lie inside that block: the fused LOOP kernel serves them in one launch (k_conv<..., WIDE>: block spectra
+// accumulated in registers, the spectrogram's dead columns written as zeros) - with or without a waveform buffer.
+inline bool wide_one_block_ok(int out_len, int n_valid, int flags, bool spectral = false) {
+    static const bool off = ab_flag("SS_HIP_NO_WIDE");        // (A/B builds only: -DSS_AB)
+    if (off || spectral || out_len <= ssk::kB || n_valid < 0 || n_valid > ssk::kB) return false;
+    if ((flags & SS_FLAG_CROSSFADE) &&
+        (static_cast<int>(0.05 * out_len) < 1 || static_cast<int>(0.05 * out_len) > 2 * ssk::kPrevPairs - 2)) return false;
+    return ssk::live_blocks(n_valid, out_len, t4_of(out_len)) <= 26;
+}
+
 template <bool FUSE>
-int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st) {
+int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st, bool wide = false) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
     p.nb_y = nb_y;
+    if constexpr (FUSE) {
+        if (wide) {
+            if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
+            const dim3 grid(2 * n_units, 1), block(ssk::kT);
+            if (flags & SS_FLAG_CROSSFADE)
+                hipLaunchKernelGGL((ssk::k_conv<true, false, true, false, true>), grid, block, 0, st, p, ssk::UnitTab<false>());
+            else
+                hipLaunchKernelGGL((ssk::k_conv<true, false, false, false, true>), grid, block, 0, st, p, ssk::UnitTab<false>());
+            return hip_err(hipGetLastError());
+        }
+    }
     // the loop-free kernels address bucket 0 only: a bucketed bank qualifies when the caller promises that every index
     // of the launch lies there (SS_FLAG_FIRST_BUCKET; the context's planner works it out per step)
     const bool bucket0 = p.n_buckets == 1 || (flags & SS_FLAG_FIRST_BUCKET);
@@ -483,6 +505,11 @@ int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, co
         p.out = audiogoal;
         p.sgram = spectrogram;
         return launch_conv<true>(p, n_units, 1, flags, n_cus, static_cast<hipStream_t>(stream));
+    }
+    if (wide_one_block_ok(out_len, n_valid, flags)) {    // one rendered block of a longer row: fused loop kernel, one launch
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_conv<true>(p, n_units, 1, flags, n_cus, static_cast<hipStream_t>(stream), true);
     }
     if (obs_rows_ok(out_len, n_valid, (rir_cap + ssk::kB - 1) / ssk::kB, flags, false, audiogoal != nullptr)) {   // rows of 2-3 blocks: fused as well
         p.out = audiogoal;
@@ -1000,7 +1027,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     }
     const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);       // (cross-faded steps take the time-domain rows)
     const int nbh_bank = spectral ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
-    if (spectrogram && !audiogoal && c.out_len > ssk::kB &&
+    if (spectrogram && !audiogoal && c.out_len > ssk::kB && !wide_one_block_ok(c.out_len, c.n_valid, res.flags, spectral) &&
         !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags, spectral, true)) {  // cross-faded / very long rows hand over through memory (the context's own buffer)
         const size_t need = static_cast<size_t>(n) * 2 * c.out_len;
         if (need > c.ag_cap) {
@@ -1356,6 +1383,11 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
         p.out = audiogoal;
         p.sgram = spectrogram;
         return spectral ? launch_conv_spec<true>(p, n_units, 1, flags, st) : launch_conv<true>(p, n_units, 1, flags, n_cus, st);
+    }
+    if (wide_one_block_ok(out_len, n_valid, flags, spectral)) {
+        p.out = audiogoal;
+        p.sgram = spectrogram;
+        return launch_conv<true>(p, n_units, 1, flags, n_cus, st, true);
     }
     if (obs_rows_ok(out_len, n_valid, nbh_max, flags, spectral, audiogoal != nullptr)) {
         p.out = audiogoal;

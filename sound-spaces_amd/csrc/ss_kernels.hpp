@@ -1062,7 +1062,12 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
 }
 
 // Fused STFT phase (out_len <= kB, t4 <= 26): the 1-s row goes from registers into LDS and feeds the STFT directly.
-constexpr int kResFloats = kBins4 * 26;     // pooled spectrogram of one ear (t4 <= 26 on the fused path)
+// WIDE (round 4): rows LONGER than one block of which only block 0 is rendered (n_valid <= kB, out_len > kB: every SoundSpaces
+// 2.0 step at 44.1 kHz, continuous_simulator.py:413-456 - 0.25 s of a 1-s row).  Everything behind n_valid is zero, so
+// at most 26 pooled blocks are live (live_blocks) and they only need samples of block 0; the other t4 - live columns are
+// written as zeros.  One launch, no waveform buffer, block spectra accumulated in registers (each is used once).
+constexpr int kResFloats = kBins4 * 26;     // pooled spectrogram of one ear (<= 26 live blocks on the fused path)
+template <bool WIDE = false>
 __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
                                                  const float* s_win, const c32* s_tw512, c32 wq, float* s_res) {
     // The row goes to LDS with librosa's centre padding materialised around it (256 samples on each side), so that
@@ -1081,9 +1086,13 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     lds_barrier();
     if (t < kNfft / 2) {                                  // the two pads: reflect (excluding the edge sample) or zeros
         const bool refl = p.pad_mode == 0;
-        const float l = refl ? yl[1 + t] : 0.f, r = refl ? yl[len - 2 - t] : 0.f;
+        const float l = refl ? yl[1 + t] : 0.f;
         yl[-1 - t] = l;
-        yl[len + t] = r;
+        if (WIDE) {                                         // the row goes on (as zeros) behind the block: no right edge here;
+            yl[kB + t] = 0.f;                               // the last frame of live block 25 (n_valid > 15744) reads up to
+            yl[kB + kNfft / 2 + t] = 0.f;                   // sample kB + 352
+        }
+        else yl[len + t] = refl ? yl[len - 2 - t] : 0.f;
     }
     lds_barrier();
     const int lane = t & 63, wv = t >> 6;
@@ -1103,14 +1112,22 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     // The pooled values of this ear are collected in LDS and leave together: written straight from the blocks, lane r
     // stores row r of out[unit][r][block][ear] - 64 lanes, 64 different cache lines, 4 bytes each, 26 times per workgroup.
     // From s_res, 32 threads per pooled row write its blocks: every other float of a contiguous range.
+    const int rs = WIDE ? 26 : p.t4;                        // row stride of s_res
     if (one)
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * p.t4 + wv] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * rs + wv] = v; });
     if (two) {
         wave_sync();
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * p.t4 + wv + 16] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * rs + wv + 16] = v; });
     }
     lds_barrier();
     float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
+    if (WIDE) {                                             // t4 columns per pooled row, the live ones from s_res
+        for (int idx = t; idx < kBins4 * p.t4; idx += kT) {
+            const int b = idx / p.t4, k = idx - b * p.t4;
+            o[2 * idx] = k < live ? s_res[b * rs + k] : 0.f;
+        }
+        return;
+    }
     const int k = t & 31;                                   // (t4 <= 26 on this path)
     if (k < p.t4)
         for (int b = t >> 5; b < kBins4; b += kT / 32) o[2 * (b * p.t4 + k)] = k < live ? s_res[b * p.t4 + k] : 0.f;
@@ -1123,9 +1140,10 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
 // of that result (at most two packed pairs per thread) are kept in registers, then the row is convolved with the
 // current RIR (term 0) and the head of the row becomes prev*(fade-n)/fade + cur*n/fade.  One launch, and in the
 // fused kernel the spectrogram is taken from the blended row without it ever leaving the CU.
-template <bool FUSE, bool SIMPLE, bool XFADE = false, bool TAB = false>
+template <bool FUSE, bool SIMPLE, bool XFADE = false, bool TAB = false, bool WIDE = false>
 __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = UnitTab<TAB>()) {
     static_assert(!(SIMPLE && XFADE), "the cross-fade needs the two-term loop kernel");
+    static_assert(!WIDE || (FUSE && !SIMPLE), "WIDE: fused loop kernel for rows of which only block 0 is rendered");
     static_assert(!TAB || SIMPLE, "the unit table serves the loop-free kernel");
     __shared__ c32 lds[FUSE && 16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
     const int t = threadIdx.x;
@@ -1285,7 +1303,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase<WIDE>(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
     }
 }
 

@@ -212,7 +212,9 @@ def audio_obs_into(spec, rir_bank, rir_len, unit_desc, audiogoal, spectrogram_ou
 def audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid: int, out_len: int, pad_mode="reflect",
               want_audiogoal: bool = False, interleaved: bool = False, flags: int = 0):
     N = unit_desc.shape[0]
-    need_ag = want_audiogoal or (out_len > KB and (bool(flags & FLAG_CROSSFADE) or out_len > 3 * KB))
+    from .planning import wide_one_block
+    need_ag = want_audiogoal or (out_len > KB and not wide_one_block(out_len, n_valid)
+                                 and (bool(flags & FLAG_CROSSFADE) or out_len > 3 * KB))
     ag = torch.empty((N, 2, out_len), dtype=torch.float32, device=spec.device) if need_ag else None
     sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
     audio_obs_into(spec, rir_bank, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, interleaved, flags)

@@ -109,6 +109,23 @@ def spectrogram_shape(length: int) -> tuple:
 
 
 # ---- log-mel extension (not in the reference; ss_logmel_f32) -------------------------------------------------------
+def live_pooled_blocks(n_valid: int, length: int) -> int:
+    """Pooled spectrogram columns that can be non-zero when a row of `length` samples is zero from n_valid on
+    (csrc/ss_kernels.hpp::live_blocks: column b is zero once 640 b - 256 >= n_valid, provided the right centre padding
+    mirrors zeros too)."""
+    t4 = spectrogram_shape(length)[1]
+    if n_valid > length - 512:
+        return t4
+    return min(t4, ceil_div(n_valid + 256, 640))
+
+
+def wide_one_block(out_len: int, n_valid: int, spectral: bool = False) -> bool:
+    """Rows longer than one block of which only block 0 is rendered and whose live columns fit the fused phase (SS2.0 steps
+    at 44.1 kHz): the library serves them with the fused loop kernel in ONE launch, waveform buffer or not
+    (csrc/ss_hip.hip::wide_one_block_ok)."""
+    return (not spectral) and out_len > KB and 0 <= n_valid <= KB and live_pooled_blocks(n_valid, out_len) <= 26
+
+
 def _slaney_mel(f):
     """Hz -> mel on the Slaney / auditory-toolbox scale (linear to 1 kHz, log above): librosa's default."""
     f = np.asarray(f, dtype=np.float64)

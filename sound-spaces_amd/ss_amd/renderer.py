@@ -360,14 +360,17 @@ class BatchedAudioRenderer:
     # ---- rendering ---------------------------------------------------------------------------------------
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
-        """One launch on the current stream; two - convolution, then spectrogram, the waveform handed over through memory -
-        for rows longer than one partition block that are cross-faded or have one rendered block (SS2.0 steps at 44.1 kHz:
-        measured faster than the one-launch form the library falls back to without a buffer) and for rows longer than
-        three blocks.  Returns (audiogoal [N,2,sr] or None, spectrogram)."""
+        """One launch on the current stream - including SS2.0 steps at 44.1 kHz (one rendered block of a longer row: the
+        fused loop kernel, k_conv<..., WIDE>); two - convolution, then spectrogram, the waveform handed over through memory -
+        for cross-faded rows with more than one rendered block (measured faster than k_obs_rows<XFADE>) and for rows longer
+        than three blocks.  Returns (audiogoal [N,2,sr] or None, spectrogram)."""
         N = len(plan)
+        xfade = bool(plan.flags & ops.FLAG_CROSSFADE)
+        spectral = (self.rirs.spectra is not None if not isinstance(self.rirs, BucketedRirBank) else bool(self.rirs.spectra)) \
+            and not xfade
         need_ag = (want_audiogoal or audiogoal_out is not None or
-                   (self.out_len > P.KB and (bool(plan.flags & ops.FLAG_CROSSFADE) or self.n_valid <= P.KB
-                                             or self.out_len > 3 * P.KB)))
+                   (self.out_len > P.KB and not P.wide_one_block(self.out_len, self.n_valid, spectral)
+                    and (xfade or self.n_valid <= P.KB or self.out_len > 3 * P.KB)))
         ag = audiogoal_out
         if need_ag and ag is None:
             ag = torch.empty((N, 2, self.out_len), dtype=torch.float32, device=self.device)

@@ -159,7 +159,10 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
     if (xfade) simple = 0;
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
-    if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
+    // WIDE: a row longer than one block of which only block 0 is rendered (the library's wide_one_block_ok)
+    const bool wide = fuse && out_len > ssk::kB && n_valid <= ssk::kB && ssk::live_blocks(n_valid, out_len, p.t4) <= 26;
+    if (wide && simple) return -3;
+    if (fuse && !wide && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (persist > 0) {                                  // k_conv_rows: `persist` workgroups walk the 2*n_units rows
         if (fuse || !simple || nb_y != 1 || es != 1 || (cap & 1) || cap > ssk::kB) return -2;
         gridDim = dim3{(unsigned)persist, 1, 1};
@@ -178,7 +181,8 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
         {
             blockIdx = dim3{(unsigned)(b % (2 * n_units)), (unsigned)(b / (2 * n_units)), 0};
             int rc = run_block(ssk::kT, [&] {
-                if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
+                if (wide) { if (xfade) ssk::k_conv<true, false, true, false, true>(p); else ssk::k_conv<true, false, false, false, true>(p); }
+                else if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
                 else if (fuse) { if (simple) ssk::k_conv<true, true>(p); else ssk::k_conv<true, false>(p); }
                 else { if (simple) ssk::k_conv<false, true>(p); else ssk::k_conv<false, false>(p); }
             });
@@ -281,7 +285,10 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     p.h_blocks = h_blocks; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
     apply_bucket2(p);
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
-    if (fuse && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
+    // WIDE: a row longer than one block of which only block 0 is rendered (the library's wide_one_block_ok)
+    const bool wide = fuse && out_len > ssk::kB && n_valid <= ssk::kB && ssk::live_blocks(n_valid, out_len, p.t4) <= 26;
+    if (wide && simple) return -3;
+    if (fuse && !wide && (nb_y != 1 || out_len > ssk::kB || p.t4 > 26)) return -1;
     if (simple && (nb_y != 1 || h_blocks != 1)) return -2;
     p.nb_y = nb_y;
     if (persist > 0) {                                  // k_conv_spec_rows: `persist` workgroups walk the units

@@ -1097,8 +1097,8 @@ def test_continuous_steps_at_44k_both_forms(name):
     assert not ag[0][:, int(sr * d["step_time"]):].any()
     check(ag[0][:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
-    # ... and the one-launch form the library uses when the caller has no waveform buffer (k_obs_rows, zero pooled blocks
-    # written, not computed); the renderer itself takes two launches for rows with one rendered block (measured faster)
+    # ... and without a waveform buffer: the same ONE launch (round 4: the fused loop kernel k_conv<..., WIDE> serves rows with one
+    # rendered block - block spectra accumulated in registers, dead pooled columns written as zeros - buffer or not)
     from ss_amd import ops
     plan = r.plan([UnitRequest(0, d["sample_index"], 0, wrap=d["sample_index"] - d["rir"].shape[0] >= 0)])
     sg1 = torch.full_like(sg, float("nan"))
@@ -1110,9 +1110,10 @@ def test_continuous_steps_at_44k_both_forms(name):
 @pytest.mark.parametrize("step_time,len_prev,sample_index", [(0.25, 20000, 50000), (0.25, 40000, 9000), (1.0, 30000, 70000)])
 def test_crossfaded_rows_at_44k_both_forms(step_time, len_prev, sample_index):
     """SS2.0 CROSSFADE at the reference's Replica rate (continuous_simulator.py:47-53, 413-426) against the oracle: the
-    two-launch form the renderer and the context use (loop kernel, k_spectrogram told where a short step's zeros begin)
-    and the ONE-launch form of ss_audio_obs_f32 without a waveform buffer (k_obs_rows<XFADE>); previous RIR of 1-3
-    blocks in either branch; a unit without a previous RIR in the same launch."""
+    0.25-s steps (one rendered block) take ONE launch everywhere (k_conv<FUSE, loop, XFADE, WIDE>); 1-s steps: the two-launch
+    form the renderer and the context use (loop kernel, k_spectrogram) and the one-launch form of ss_audio_obs_f32 without a
+    waveform buffer (k_obs_rows<XFADE>); previous RIR of 1-3 blocks in either branch; a unit without a previous RIR in the
+    same launch."""
     from ss_amd import ops
     from ss_amd.renderer import UnitRequest
     from ss_amd.context import AudioContext
@@ -1158,9 +1159,44 @@ def test_crossfaded_rows_at_44k_both_forms(step_time, len_prev, sample_index):
 
 
 @pytest.mark.gpu
+def test_wide_one_block_route_every_step_length():
+    """Rows of 44100 samples rendered up to n_valid <= 16384 (SS2.0 steps of any length up to one block): the fused loop
+    kernel in one launch (k_conv<..., WIDE>) against the oracle - both pad modes, with and without
+    an audiogoal buffer, and one sample past the rule (16385: k_obs_rows); written zeros exact.  continuous_simulator.py:413-456."""
+    from ss_amd import ops
+    from ss_amd.renderer import UnitRequest
+    sr = 44100
+    rng = np.random.default_rng(6)
+    srcs = [O.tile_short_source(s, sr) for s in O.synth_sources(rng, sr, k=2, seconds=1)]
+    rirs = O.synth_rir(rng, sr, length=30000, n=2)
+    idx = 20000
+    a = O.convolve_with_rir(srcs[0], np.ascontiguousarray(rirs[0].T), sr, idx, 1.0)
+    b = O.convolve_with_rir(srcs[1], np.ascontiguousarray(rirs[1].T), sr, idx, 1.0)
+    for nv, pad in ((1, "reflect"), (383, "constant"), (11025, "reflect"), (11025, "constant"), (15999, "reflect"),
+                    (16384, "reflect"), (16385, "reflect")):
+        r = make_renderer(sr, srcs, [np.ascontiguousarray(h.T) for h in rirs], step_time=(nv + 0.5) / sr, wrap=True, pad_mode=pad)
+        assert r.n_valid == nv
+        units = [UnitRequest(0, idx, 0, wrap=False), UnitRequest(1, idx, 1, wrap=False), UnitRequest(silent=True)]
+        plan = r.plan(units)
+        sg = torch.full((3,) + r.spectrogram_shape, float("nan"), device=DEV)
+        ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg, r.n_valid, r.out_len, r.pad_mode, flags=plan.flags)
+        ag2, sg2 = r.render(plan, want_audiogoal=True)
+        assert torch.equal(sg, sg2)
+        sg, ag2 = sg.cpu().numpy(), ag2.cpu().numpy()
+        for n, ref in enumerate((a, b)):
+            ref = ref.copy()
+            ref[:, nv:] = 0
+            ref_s = O.compute_spectrogram(ref.astype(np.float32), pad_mode=pad)
+            check(ag2[n], ref)
+            check(sg[n], ref_s)
+            assert (sg[n][ref_s == 0] == 0).all()
+        assert not sg[2].any() and not ag2[2].any()
+
+
+@pytest.mark.gpu
 def test_crossfade_44k_reference_run_vector_both_forms():
-    """cont_crossfade_44k (the reference's own _compute_audiogoal with CROSSFADE on, 44.1 kHz): renderer (two launches) and
-    ss_audio_obs_f32 without a waveform buffer (k_obs_rows<XFADE>, one launch)."""
+    """cont_crossfade_44k (the reference's own _compute_audiogoal with CROSSFADE on, 44.1 kHz, a 0.25-s step): renderer and
+    ss_audio_obs_f32 without a waveform buffer - one launch either way (k_conv<FUSE, loop, XFADE, WIDE>)."""
     from ss_amd.renderer import UnitRequest
     d = case_inputs("cont_crossfade_44k")
     sr = d["sr"]
@@ -1172,7 +1208,7 @@ def test_crossfade_44k_reference_run_vector_both_forms():
     check(ag[0].cpu().numpy()[:, ::stride], ref_a)
     check(sg[0].cpu().numpy(), ref_s)
     plan = r.plan(u)
-    sg1 = torch.full_like(sg, float("nan"))                              # k_obs_rows<XFADE>: one launch, no waveform
+    sg1 = torch.full_like(sg, float("nan"))                              # one launch, no waveform
     ops.audio_obs_into(r._spec, r.rirs.data, r.rirs.lengths, plan.desc, None, sg1, r.n_valid, r.out_len, r.pad_mode,
                        flags=plan.flags)
     check(sg1[0].cpu().numpy(), ref_s)

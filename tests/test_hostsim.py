@@ -615,6 +615,82 @@ def test_zero_pooled_blocks_are_written_not_computed_at_any_step_length(sr, n_va
             assert (sg[0][ref_s == 0] == 0).all()                         # the written zeros are exact
 
 
+# ---- k_conv<FUSE, loop, XFADE?, WIDE>: one launch for rows of which only block 0 is rendered (SS2.0 steps at 44.1 kHz) ------
+@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k", "cont_crossfade_44k"])
+def test_wide_one_block_kernel_vs_reference_run_vectors(name):
+    """The reference's ContinuousSoundSpacesSim._compute_audiogoal at 44.1 kHz (continuous_simulator.py:413-456, CROSSFADE
+    :47-53): a 0.25-s step renders 11025 samples of a 44100-sample row - block 0 only.  The fused LOOP kernel serves it in
+    one launch (block spectra accumulated in registers, 18 live pooled columns, 51 written as zeros)."""
+    d = case_inputs(name)
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs(name)
+    src3 = O.tile_short_source(d["source"], sr)
+    ns = int(sr * d["step_time"])
+    xf = "last_rir" in d
+    if xf:
+        bank = np.concatenate([planar(d["rir"]), planar(d["last_rir"])])
+        lens = [d["rir"].shape[0], d["last_rir"].shape[0]]
+        unit = dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=True, last_rir=1)
+    else:
+        bank, lens = planar(d["rir"]), [d["rir"].shape[0]]
+        unit = dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0,
+                    wrap=d["sample_index"] - d["rir"].shape[0] >= 0)
+    out, sg = hs.run([src3], bank, lens, [unit], ns, sr, fuse=True, simple=False, crossfade=xf)
+    assert not out[0][:, ns:].any()
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
+
+
+@pytest.mark.parametrize("len_prev,sample_index", [(20000, 50000), (40000, 9000)])
+def test_wide_one_block_crossfade_equals_oracle_and_rows_kernel(len_prev, sample_index):
+    sr = 44100
+    rng = np.random.default_rng(78)
+    src3 = O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=1)[0], sr)
+    cur = np.ascontiguousarray(O.synth_rir(rng, sr, length=20000, n=1)[0].T)
+    prev = np.ascontiguousarray(O.synth_rir(rng, sr, length=len_prev, n=1)[0].T)
+    ns = sr // 4
+    cap = max(20000, len_prev)
+    bank = np.concatenate([planar(cur, cap), planar(prev, cap)])
+    wrap_cur, wrap_prev = sample_index - 20000 >= 0, sample_index - len_prev >= 0
+    t0 = P.window_start_continuous(sample_index)
+    units = [dict(sound=0, t0=t0, rir=0, wrap=wrap_cur, last_rir=1, last_wrap=wrap_prev), dict(sound=0, t0=t0, rir=0, wrap=wrap_cur),
+             dict(rir=-1)]
+    out, sg = hs.run([src3], bank, [20000, len_prev], units, ns, sr, crossfade=True, fuse=True, simple=False)
+    ref = O.compute_audiogoal_continuous(src3, cur, sr, sample_index, 0.25, last_rir=prev, use_crossfade=True)
+    plain = O.convolve_with_rir(src3, cur, sr, sample_index, 0.25)
+    check(out[0], ref)
+    check(out[1], plain)
+    check(sg[0], O.compute_spectrogram(ref.astype(np.float32)))
+    check(sg[1], O.compute_spectrogram(plain.astype(np.float32)))
+    assert not out[2].any() and not sg[2].any()
+    out_r, sg_r = hs.run([src3], bank, [20000, len_prev], units, ns, sr, crossfade=True, row_wgs=2)
+    assert np.abs(out - out_r).max() <= 2e-6 * np.abs(out_r).max() and np.abs(sg - sg_r).max() <= 2e-6 * sg_r.max()
+
+
+def test_wide_one_block_every_step_length_up_to_one_block():
+    """n_valid from 1 sample to a full block (16384: 26 live pooled columns, the most the fused phase holds), a distractor
+    term, both pad modes: the WIDE kernel against the oracle, zero columns exact."""
+    sr = 44100
+    rng = np.random.default_rng(6)
+    srcs = [O.tile_short_source(s, sr) for s in O.synth_sources(rng, sr, k=2, seconds=1)]
+    rirs = O.synth_rir(rng, sr, length=30000, n=2)
+    bank = np.ascontiguousarray(rirs)
+    idx = 20000
+    a = O.convolve_with_rir(srcs[0], np.ascontiguousarray(rirs[0].T), sr, idx, 1.0)
+    b = O.convolve_with_rir(srcs[1], np.ascontiguousarray(rirs[1].T), sr, idx, 1.0)
+    t0 = P.window_start_continuous(idx)
+    for nv, pad in ((1, 0), (383, 1), (11025, 0), (11025, 1), (15999, 0), (16384, 0)):
+        units = [dict(sound=0, t0=t0, rir=0, wrap=False), dict(sound=0, t0=t0, rir=0, wrap=False, dis_sound=1, dis_t0=t0, dis_rir=1)]
+        out, sg = hs.run(srcs, bank, [30000, 30000], units, nv, sr, fuse=True, simple=False, pad_mode=pad)
+        for n, ref in enumerate((a, a + b)):
+            ref = ref.copy()
+            ref[:, nv:] = 0
+            ref_s = O.compute_spectrogram(ref.astype(np.float32), pad_mode=("reflect", "constant")[pad])
+            check(out[n], ref)
+            check(sg[n], ref_s)
+            assert (sg[n][ref_s == 0] == 0).all()
+
+
 # ---- the 512-thread / 32-values-per-thread core (ss_fft_core32.hpp, ss_kernels32.hpp) ---------------------------------
 @pytest.mark.parametrize("name", SIM_CASES)
 def test_core32_sim_branches_vs_reference_vectors(name):
