@@ -250,8 +250,10 @@ class DeferredResolver:
         self._pose_free: List[int] = []
         self._pose_cap = 0
         self.native_steps = 0
-        if self.columns_ok and store.on_evict is None:
-            store.on_evict = self._evicted
+        if self.columns_ok:                       # every resolver over this store hears about evictions (their pair tables
+            prev = store.on_evict                 # name store slots)
+            store.on_evict = self._evicted if prev is None else \
+                (lambda key, slot, a=prev, b=self._evicted: (a(key, slot), b(key, slot)))
 
     def _sound(self, name, clip) -> int:
         if clip is not None:
@@ -413,8 +415,8 @@ class DeferredResolver:
             buf = self._records(requests)
             if buf is None:
                 return None
-        n = len(requests)
-        recs = np.frombuffer(buf, np.int64).reshape(n, REC_N)
+        recs = np.frombuffer(buf, np.int64).reshape(-1, REC_N)
+        n = recs.shape[0]
         live = recs[:, REC_SILENT] == 0
         has_dis = live & (recs[:, REC_DIS_SOUND] >= 0)
         any_dis = bool(has_dis.any())
@@ -427,6 +429,8 @@ class DeferredResolver:
                 new |= has_dis & (dsound < 0)
             if not new.any():
                 break
+            if requests is None:                            # (callers without request objects register names themselves)
+                raise KeyError("deferred audio: a record names a sound or RIR directory that was never registered")
             for i in np.flatnonzero(new):                   # first use of a sound / a RIR directory
                 q = requests[i]
                 if sound[i] < 0 and name_key(q.sound) not in self._key_names:
@@ -525,32 +529,39 @@ class DeferredResolver:
                  spectrogram_out=None, audiogoal_out=None):
         buf = self._records(requests) if self.columns_ok else None
         if buf is not None:
-            import torch
-            r = self.engine.renderer
-            n = len(requests)
-            want_audiogoal = want_audiogoal or audiogoal_out is not None
-            if want_spectrogram and spectrogram_out is None:
-                spectrogram_out = torch.empty((n,) + tuple(r.spectrogram_shape), dtype=torch.float32, device=r.device)
-            if want_audiogoal and audiogoal_out is None:
-                audiogoal_out = torch.empty((n, 2, r.out_len), dtype=torch.float32, device=r.device)
-            sg, ag = (spectrogram_out if want_spectrogram else None), (audiogoal_out if want_audiogoal else None)
-            done = False
-            if hasattr(self.engine, "observe_requests"):   # lookups + planner + launch in one C call
-                done = self.engine.observe_requests(buf, n, self._request_tables(), spectrogram_out=sg, audiogoal_out=ag) == 0
-                self.native_steps += done
-            if not done:                                    # something to register / load (or an engine without the C path)
-                self.engine.observe_columns(self._columns(requests, buf), spectrogram_out=sg, audiogoal_out=ag)
-            self.column_steps += 1
-            out = {}
-            if want_spectrogram:
-                out["spectrogram"] = spectrogram_out
-            if want_audiogoal:
-                out["audiogoal"] = audiogoal_out
-            return out
+            return self.resolve_records(buf, len(requests), requests, want_audiogoal, want_spectrogram, spectrogram_out,
+                                        audiogoal_out)
         self.walk_steps += 1
         return self.engine.observe(self.units(requests), want_audiogoal=want_audiogoal or audiogoal_out is not None,
                                    want_spectrogram=want_spectrogram, spectrogram_out=spectrogram_out,
                                    audiogoal_out=audiogoal_out)
+
+    def resolve_records(self, buf: bytes, n: int, requests: Optional[Sequence[AudioRequest]] = None,
+                        want_audiogoal: bool = False, want_spectrogram: bool = True, spectrogram_out=None, audiogoal_out=None):
+        """One step from its packed records (n x REC_N int64 words as bytes; `requests` only serves first-use registration
+        of sounds / RIR directories and may be None when the caller registers them itself - the in-process
+        ``VectorAudioObserver`` does)."""
+        import torch
+        r = self.engine.renderer
+        want_audiogoal = want_audiogoal or audiogoal_out is not None
+        if want_spectrogram and spectrogram_out is None:
+            spectrogram_out = torch.empty((n,) + tuple(r.spectrogram_shape), dtype=torch.float32, device=r.device)
+        if want_audiogoal and audiogoal_out is None:
+            audiogoal_out = torch.empty((n, 2, r.out_len), dtype=torch.float32, device=r.device)
+        sg, ag = (spectrogram_out if want_spectrogram else None), (audiogoal_out if want_audiogoal else None)
+        done = False
+        if hasattr(self.engine, "observe_requests"):       # lookups + planner + launch in one C call
+            done = self.engine.observe_requests(buf, n, self._request_tables(), spectrogram_out=sg, audiogoal_out=ag) == 0
+            self.native_steps += done
+        if not done:                                        # something to register / load (or an engine without the C path)
+            self.engine.observe_columns(self._columns(requests, buf), spectrogram_out=sg, audiogoal_out=ag)
+        self.column_steps += 1
+        out = {}
+        if want_spectrogram:
+            out["spectrogram"] = spectrogram_out
+        if want_audiogoal:
+            out["audiogoal"] = audiogoal_out
+        return out
 
     def resolve_observations(self, observations: Sequence[dict], rollouts=None, replace: bool = True):
         """Replacement for the audio half of ``batch_obs`` (ss_baselines/common/utils.py:126-153): `observations` is

@@ -330,15 +330,121 @@ class VectorAudioObserver:
         reduced on the device from the batch's audiogoal."""
         self.engine, self.backends = engine, backends
         self.want_audiogoal, self.want_intensity = want_audiogoal or want_intensity, want_intensity
+        self._rec = None                          # record path (see _record_state): None = undecided, False = not applicable
+        self.record_steps = self.walk_steps = 0
+
+    # ---- record path: the step's state read with C-level attribute getters, packed into the int64 records of
+    # ss_amd.deferred and handed to the C++ context in ONE call (lookups, planner, launch: ss_ctx_observe_requests) ----
+    def _record_state(self):
+        """SoundSpaces 1.0 simulators on RIR files, one reader, an engine with the column surface (AudioEngine, rir_group=1):
+        per step the envs are walked by ``operator.attrgetter`` (one C call per simulator) instead of ``unit_request()``
+        (a Python method, a UnitRequest, two store lookups and a Python planner row per env: 3.6 us per env)."""
+        import operator
+        from .deferred import DeferredResolver
+        bs = self.backends
+        if not bs or not all(type(b) is HipSimAudio for b in bs):
+            return False
+        cfgs = [b.sim.config for b in bs]
+        if not all(c.USE_RENDERED_OBSERVATIONS for c in cfgs) or any(b.rir_reader != bs[0].rir_reader for b in bs):
+            return False
+        dis = {bool(c.AUDIO.HAS_DISTRACTOR_SOUND) for c in cfgs}
+        if len(dis) != 1 or len({int(c.AUDIO.RIR_SAMPLING_RATE) for c in cfgs}) != 1:
+            return False
+        try:
+            res = DeferredResolver(self.engine, rir_reader=bs[0].rir_reader, fast=True)
+        except ValueError:
+            return False
+        attrs = ["_episode_step_count", "_duration", "_current_sound", "_receiver_position_index", "_source_position_index",
+                 "azimuth_angle", "binaural_rir_dir"]
+        if True in dis:
+            attrs += ["_current_distractor_sound", "_distractor_position_index"]
+        return dict(res=res, sims=[b.sim for b in bs], getter=operator.attrgetter(*attrs), dis=True in dis, sr=bs[0].sr,
+                    snd={}, tbl={})
+
+    def _learn_sounds(self, st, names) -> None:
+        from .deferred import name_key
+        res, sr = st["res"], st["sr"]
+        for sim, nm in zip(st["sims"], names):
+            if nm in st["snd"]:
+                continue
+            clip = sim._source_sound_dict[nm]
+            key = name_key(nm)
+            if key not in res._key_names:
+                res._learn_sound(nm, np.ascontiguousarray(clip, dtype=np.float32))
+            st["snd"][nm] = (key, int(np.shape(clip)[0]) != sr)
+
+    def _observe_records(self, st, spectrogram_out, audiogoal_out):
+        from .deferred import (REC_DIS_SOUND, REC_DIS_SRC, REC_ENV, REC_N, REC_RECV, REC_SILENT, REC_SOUND, REC_SRC, REC_T0,
+                               REC_TABLE, name_key)
+        sims, res, sr = st["sims"], st["res"], st["sr"]
+        n = len(sims)
+        cols = list(zip(*map(st["getter"], sims)))
+        names = cols[2]
+        snd = st["snd"]
+        try:
+            info = [snd[nm] for nm in names]
+        except KeyError:
+            self._learn_sounds(st, names)
+            info = [snd[nm] for nm in names]
+        pairs = list(zip(cols[6], cols[5]))
+        tbl = st["tbl"]
+        try:
+            tkeys = [tbl[p] for p in pairs]
+        except KeyError:
+            for p in pairs:
+                if p not in tbl:
+                    d = os.path.join(p[0], str(p[1]))                              # simulator.py:615-616
+                    if name_key(d) not in res._key_names:
+                        res._learn_table(os.path.join(d, "_"))
+                    tbl[p] = name_key(d)
+            tkeys = [tbl[p] for p in pairs]
+        recs = np.zeros((n, REC_N), np.int64)
+        silent = np.asarray(cols[0], np.int64) > np.asarray(cols[1], np.int64)      # simulator.py:610
+        keys, multi = zip(*info)
+        recs[:, REC_SILENT] = silent
+        recs[:, REC_SOUND] = keys
+        recs[:, REC_TABLE] = tkeys
+        recs[:, REC_RECV] = cols[3]
+        recs[:, REC_SRC] = cols[4]
+        recs[:, REC_DIS_SOUND] = -1
+        recs[:, REC_ENV] = np.arange(n)
+        if True in multi:                                                           # multi-second clips: simulator.py:634-635
+            for i in np.flatnonzero(np.asarray(multi) & ~silent):
+                sim = sims[i]
+                idx = sim._audio_index
+                sim._audio_index = (idx + 1) % sim._audio_length
+                recs[i, REC_T0] = idx * sr
+        if st["dis"]:                                                               # simulator.py:649-664
+            dnames = cols[7]
+            try:
+                dinfo = [snd[nm] for nm in dnames]
+            except KeyError:
+                self._learn_sounds(st, dnames)
+                dinfo = [snd[nm] for nm in dnames]
+            recs[:, REC_DIS_SOUND] = [k for k, _ in dinfo]
+            recs[:, REC_DIS_SRC] = cols[8]
+        if silent.any():                                                            # (as DeferredSimAudio's silent record)
+            recs[silent, REC_SOUND:REC_DIS_SOUND] = 0
+            recs[silent, REC_DIS_SOUND] = -1
+            recs[silent, REC_DIS_SRC] = 0
+        return res.resolve_records(recs.tobytes(), n, None, self.want_audiogoal or audiogoal_out is not None, True,
+                                   spectrogram_out, audiogoal_out)
 
     def observe(self, spectrogram_out=None, audiogoal_out=None):
         """-> {"spectrogram": device tensor [N,65,T4,2], ("audiogoal": [N,2,sr])}; cache-free (every env renders its
         current pose), i.e. the reference's HAS_DISTRACTOR_SOUND / continuous behaviour."""
-        if hasattr(self.engine, "begin_batch"):
-            self.engine.begin_batch()                 # no RIR slot of this step may be evicted by another env of it
-        units = [b.unit_request() for b in self.backends]
-        out = self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
-                                  want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+        if self._rec is None:
+            self._rec = self._record_state()
+        if self._rec:
+            out = self._observe_records(self._rec, spectrogram_out, audiogoal_out)
+            self.record_steps += 1
+        else:
+            if hasattr(self.engine, "begin_batch"):
+                self.engine.begin_batch()             # no RIR slot of this step may be evicted by another env of it
+            units = [b.unit_request() for b in self.backends]
+            out = self.engine.observe(units, want_audiogoal=self.want_audiogoal or audiogoal_out is not None,
+                                      want_spectrogram=True, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+            self.walk_steps += 1
         if self.want_intensity:
             from .sensors import Intensity
             out["intensity"] = Intensity.compute_intensity(out["audiogoal"], 150).reshape(-1, 1)

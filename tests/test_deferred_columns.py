@@ -166,3 +166,66 @@ def test_deferred_pose_cache_equals_the_eager_adapter_step_for_step(engine_cls):
         assert torch.allclose(out["audiogoal"][0], torch.from_numpy(np.asarray(e_ag, np.float32)), atol=1e-6), step
         assert sim._audio_index == twin._audio_index, step
     assert hits == 4                                                             # steps 1, 3, 5 (cached pose outlives the sound), 8
+
+
+# ---- batched (in-process) mode on the same records: VectorAudioObserver's record path -------------------------------------
+@pytest.mark.parametrize("has_distractor,slots", [(False, 64), (True, 64), (False, 6)])
+def test_vector_audio_observer_record_path_equals_the_unit_walk(has_distractor, slots):
+    """``VectorAudioObserver`` over SoundSpaces 1.0 simulators on RIR files reads the step's state with C-level attribute
+    getters and hands packed records to the column path (no ``unit_request()`` per env): results equal the per-env walk
+    step for step - sound changes, silence after ``_duration``, a 3-s clip (``_audio_index`` advanced on the simulator exactly
+    as simulator.py:634-635 does), a distractor, a store too small for the poses visited (eviction)."""
+    from ss_amd import sim_audio
+    sounds, files = make_world()
+    n_env, steps = 3, 10
+
+    def world(engine):
+        sims = [FakeSim(SR, sounds, files, has_distractor) for _ in range(n_env)]
+        for s in sims:
+            s._current_distractor_sound = "dist.wav"
+        backs = [sim_audio.attach(s, engine, rir_reader=files.get) for s in sims]
+        return sims, sim_audio.VectorAudioObserver(engine, backs, want_audiogoal=True)
+
+    fast_eng, slow_eng = OracleColumnEngine(SR, slots=slots), OracleEngine(SR)
+    sims_a, obs_a = world(fast_eng)
+    sims_b, obs_b = world(slow_eng)
+    trajs = [trajectory(r, steps) for r in range(n_env)]
+    for k in range(steps):
+        for sims in (sims_a, sims_b):
+            for r, s in enumerate(sims):
+                apply(s, k, trajs[r][k])
+        a, b = obs_a.observe(), obs_b.observe()
+        assert torch.allclose(a["audiogoal"], b["audiogoal"], atol=1e-6), k
+        assert torch.allclose(a["spectrogram"], b["spectrogram"], atol=1e-6), k
+        assert [s._audio_index for s in sims_a] == [s._audio_index for s in sims_b]
+        if k > 6:
+            assert not a["audiogoal"].any()                                   # _episode_step_count > _duration: silent
+    assert obs_a.record_steps == steps and obs_a.walk_steps == 0 and fast_eng.column_calls == steps
+    assert obs_b.record_steps == 0 and obs_b.walk_steps == steps
+    if slots == 6:
+        assert fast_eng.store.misses > 6
+
+
+def test_two_resolvers_over_one_store_both_hear_evictions():
+    """A DeferredResolver and a VectorAudioObserver (which owns a resolver) on ONE engine: both pair tables name store
+    slots, so both must drop a pair the store evicts."""
+    sounds, files = make_world()
+    eng = OracleColumnEngine(SR, slots=6)
+    r1 = DeferredResolver(eng, rir_reader=files.get)
+    r2 = DeferredResolver(eng, rir_reader=files.get)
+    sims = [FakeSim(SR, sounds, files) for _ in range(2)]
+    for i, s in enumerate(sims):
+        attach_deferred(s, env_rank=i)
+    ref = DeferredResolver(OracleEngine(SR), rir_reader=files.get, fast=False)
+    trajs = [trajectory(r, 12) for r in range(2)]
+    for k in range(12):
+        for r, s in enumerate(sims):
+            apply(s, k, trajs[r][k])
+            s._duration = 100
+        reqs = [s.get_current_spectrogram_observation(None) for s in sims]
+        want = ref.resolve(reqs)["spectrogram"]
+        for res in ((r1, r2) if k % 2 else (r2, r1)):
+            assert torch.allclose(res.resolve(reqs)["spectrogram"], want, atol=1e-6), k
+    for res in (r1, r2):
+        for key, slot in zip(res._pair_keys.tolist(), res._pair_slots.tolist()):
+            assert eng.store._slot_of[("ix", key)] == slot

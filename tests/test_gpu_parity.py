@@ -1215,6 +1215,55 @@ def test_crossfade_44k_reference_run_vector_both_forms():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("has_distractor", [False, True])
+def test_batched_observer_record_path_on_gpu(has_distractor):
+    """In-process vector envs (ss_baselines/common/sync_vector_env.py): ``VectorAudioObserver`` packs the step's simulator
+    state into request records and makes ONE ``ss_ctx_observe_requests`` call; results equal the per-env ``unit_request()``
+    walk through the Python planner and the oracle; a store of 8 slots for 4 envs wandering over 32 poses."""
+    from fakes import FakeSim
+    from ss_amd import sim_audio
+    from ss_amd.renderer import AudioEngine
+    from test_deferred import SR, apply, make_world, trajectory
+    sounds, files = make_world()
+    n_env, steps = 4, 10
+
+    def world(slots):
+        eng = AudioEngine(SR, device=DEV, rir_slots=slots)
+        sims = [FakeSim(SR, sounds, files, has_distractor) for _ in range(n_env)]
+        for s in sims:
+            s._current_distractor_sound = "dist.wav"
+        return sims, sim_audio.VectorAudioObserver(eng, [sim_audio.attach(s, eng, rir_reader=files.get) for s in sims],
+                                                   want_audiogoal=True)
+    sims_a, obs_a = world(16 if has_distractor else 8)
+    sims_b, obs_b = world(64)
+    obs_b._rec = False                                                       # the walk
+    trajs = [trajectory(r, steps) for r in range(n_env)]
+    for k in range(steps):
+        for sims in (sims_a, sims_b):
+            for r, s in enumerate(sims):
+                apply(s, k, trajs[r][k])
+        idx = [s._audio_index for s in sims_a]
+        a, b = obs_a.observe(), obs_b.observe()
+        torch.cuda.synchronize()
+        assert torch.allclose(a["audiogoal"], b["audiogoal"], atol=2e-6 * float(b["audiogoal"].abs().max()) + 1e-12), k
+        assert torch.allclose(a["spectrogram"], b["spectrogram"], atol=1e-5), k
+        assert [s._audio_index for s in sims_a] == [s._audio_index for s in sims_b]
+        s0 = sims_a[0]
+        if k <= 6:
+            rir = files[f"rirs/replica/apartment_0/{s0.azimuth_angle}/{s0._receiver_position_index}_{s0._source_position_index}.wav"]
+            drir = files[f"rirs/replica/apartment_0/{s0.azimuth_angle}/{s0._receiver_position_index}_{s0._distractor_position_index}.wav"]
+            ref = O.compute_audiogoal(sounds[s0._current_sound], rir, SR, audio_index=idx[0],
+                                      distractor=sounds["dist.wav"] if has_distractor else None,
+                                      distractor_rir=drir if has_distractor else None)
+            check(a["audiogoal"][0].cpu().numpy(), ref)
+            check(a["spectrogram"][0].cpu().numpy(), O.compute_spectrogram(ref.astype(np.float32)))
+        else:
+            assert not a["audiogoal"].any() and not a["spectrogram"].any()
+    assert obs_a.record_steps == steps and obs_a.walk_steps == 0 and obs_b.record_steps == 0
+    assert obs_a._rec["res"].native_steps > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("spectral", [False, True])
 def test_deferred_column_path_on_gpu(spectral):
     """DeferredResolver on the C++ context (ss_amd/deferred.py::_columns -> AudioEngine.observe_columns -> ss_ctx_observe): the
