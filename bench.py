@@ -319,6 +319,31 @@ def measure_deferred_path(torch, np, dev, sr, n_envs, bank, sources, steps, warm
                      "both_halves_serial_env_steps_per_s": round(n_envs * steps / dt, 1)}
     out["resident_pairs"] = int(res._pair_keys.shape[0])
     out["column_steps"], out["walk_steps"] = res.column_steps, res.walk_steps
+    # batched in-process mode over the SAME engine (the reference's SyncVectorEnv arrangement, simulators untouched):
+    # VectorAudioObserver reads the simulators with attrgetter, packs the step into the same records and makes the same C call
+    from ss_amd import sim_audio
+    sims_b = [DSim(sounds, n_nodes, rng) for _ in range(n_envs)]
+    for s_ in sims_b:
+        s_._duration = 10 ** 9
+    vobs = sim_audio.VectorAudioObserver(eng, [sim_audio.attach(s_, eng, rir_reader=reader) for s_ in sims_b])
+    h_us = []
+    for k in range(total):
+        if k == warmup:
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+        a, nd = acts[k], nodes[k]
+        for i, sim in enumerate(sims_b):
+            sim.move(a[i], int(nd[i]))
+        t0 = time.perf_counter()
+        vobs.observe_into(rollouts)
+        rollouts.step = (rollouts.step + 1) % T
+        if k >= warmup:
+            h_us.append(1e6 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t_start
+    hm = float(np.median(h_us))
+    out["batched_in_process"] = {"observe_into_host_us": round(hm, 2), "env_steps_per_s_with_sim_moves": round(n_envs * steps / dt, 1),
+                                 "record_steps": vobs.record_steps, "walk_steps": vobs.walk_steps}
     out["note"] = ("AudioRequest per env (packed record: CRC keys of sound / RIR directory, receiver, source, clip window) -> "
                    "DeferredResolver._columns (numpy: searchsorted over resident pairs) -> AudioEngine.observe_columns -> "
                    "ss_ctx_observe (C++ planner, window cache, descriptor ring, launch) into rollouts.observations['spectrogram']"
@@ -640,11 +665,12 @@ def main():
                 ctx.observe_prepared_features(columns[k], rows.data_ptr(), ag.data_ptr(), main_stream, feat_sets[k & 1])
             elif use_ctx:                                          # (unit columns converted to the C struct once, above)
                 ctx.observe_prepared(columns[k], rows.data_ptr(), None if ag is None else ag.data_ptr(), main_stream)
+            elif feat_sets is not None:                            # same two launches as the product path, pre-planned units:
+                r.render_audiogoal(plans[k], out=ag)               # convolution (waveform written), then k_features, which
+                fk = feat_sets[k & 1]["keep"]                      # also pools the spectrogram from the spectra it holds
+                ops_mod.audio_features_into(ag, rows, fk[0], fk[3], fk[1], fk[2])
             else:
                 r.render(plans[k], spectrogram_out=rows, audiogoal_out=ag)
-                if feat_sets is not None:                          # same two launches as the product path, pre-planned units
-                    fk = feat_sets[k & 1]["keep"]
-                    ops_mod.audio_features_into(ag, None, fk[0], fk[3], fk[1], fk[2])
 
         def step(k, plans=descs, columns=preps):
             st = streams[k % S]
@@ -822,15 +848,19 @@ def main():
         if savi:
             bpu = 2 * (2 * L * 4) + 2 * sr * 4 + 65 * t4 * 2 * 4        # two RIRs read, waveform and spectrogram written
             kname = kname.replace("<FUSE=true>", "<FUSE=true,loop>")    # distractor terms: the two-term loop instantiation
-        traffic_kernels = [kname] + (["k_features<" + ",".join(feats) + ">"] if feats else [])
-        if feats:                                             # k_features: the waveform read once more, the features written
+        if feats:                                             # k_features: the waveform read once more, the features written;
+            # the pooled spectrogram comes from k_features too (it holds every frame's spectrum), the convolution launch drops
+            # its fused STFT phase: k_conv<FUSE=false,loop> + k_features<spectrogram,...>
+            kname = kname.replace("<FUSE=true", "<FUSE=false")
+        traffic_kernels = [kname] + (["k_features<" + ",".join(["spectrogram"] + feats) + ">"] if feats else [])
+        if feats:
             T_fr = 1 + sr // 160
             bpu += 2 * sr * 4 + (64 * T_fr * 2 * 4 if "logmel" in feats else 0) + (65 * T_fr * 4 if "gccphat" in feats else 0)
-            kname += " + k_features<" + ",".join(feats) + "> (two launches per step: avg_launch_ms is their sum)"
+            kname += " + k_features<" + ",".join(["spectrogram"] + feats) + "> (two launches per step: avg_launch_ms is their sum)"
         ach = bpu * N / (kernel_ms * 1e-3) / 1e9
         workload = (("savi semantic_audionav shape: 21 sounds of 1-20 s, a distractor on every env (2 convolutions + add), "
                      "audiogoal AND spectrogram written" + (", + " + " + ".join(feats) + " (64 mels / 65 lags per frame) from one "
-                                                            "k_features launch per step" if feats else "") + "; " if savi else "") +
+                                                            "k_features launch per step, which also pools the spectrogram" if feats else "") + "; " if savi else "") +
                     f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, " +
                     ("" if savi else f"1-s source clips ({args.sounds} sounds), ") +
                     f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident"

@@ -259,7 +259,9 @@ int ss_ctx_observe(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, 
 /* One step plus its STFT-derived extension features (BASELINE.json configs[4]: savi, "GCC-PHAT + log-mel fused sensor"): as
  * ss_ctx_observe, then ss_audio_features_f32 over the step's waveform on the SAME stream (in overlap mode: the same internal
  * lane), so the features need no join of their own.  audiogoal must be given (the features read it); logmel / gccphat of
- * `f` may each be NULL. */
+ * `f` may each be NULL.  When a spectrogram is asked for as well it is pooled by the feature kernel (which holds every
+ * frame's spectrum of both ears anyway) and the convolution launch runs without its fused STFT phase: 96.5 instead of 108 us
+ * per 256-env savi step. */
 typedef struct ss_features {
     float* logmel;            /* [n, n_mels, 1 + sr/160, 2] or NULL */
     const int* mel_start;     /* device, [n_mels]          (ss_logmel_f32's band-sparse filter bank) */

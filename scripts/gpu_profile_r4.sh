@@ -78,13 +78,29 @@ for k, (ctr, nbytes) in known.items():
     v2 = seen[k].get(other)
     if v2 and k in calib:
         calib[k]["other_counter_bytes"] = sum(v2) / len(v2) * 1024.0      # (a write kernel that also fetches: read-for-ownership)
-names = {"k_conv<true, true, false, false>": "k_conv<FUSE=true>", "k_conv<true, true, false, true>": "k_conv<FUSE=true>",
-         "k_obs_rows<false>": "k_obs_rows<SPECTRAL=false>", "k_obs_rows<false, false>": "k_obs_rows<SPECTRAL=false>",
-         "k_conv<true, false, false, false>": "k_conv<FUSE=true,loop>", "k_features<true, false, true>": "k_features<logmel,gccphat>"}
+class Names(dict):                       # rocprofv3's template spelling -> bench.py's kernel names
+    def _name(self, k):
+        if k.startswith("k_obs_rows<false"):
+            return "k_obs_rows<SPECTRAL=false>"
+        if k.startswith("k_conv<"):          # <FUSE, SIMPLE, XFADE, TAB, WIDE>
+            b = [x.strip() == "true" for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            if len(b) >= 3 and not b[2]:
+                return "k_conv<FUSE=%s%s>" % ("true" if b[0] else "false", "" if b[1] else ",loop")
+        if k.startswith("k_features<"):      # <MEL, SG, GCC>
+            b = [x.strip() == "true" for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            return "k_features<" + ",".join(n for n, on in zip(("spectrogram", "logmel", "gccphat"), (b[1], b[0], b[2])) if on) + ">"
+        return None
+    def __contains__(self, k):
+        return self._name(k) is not None
+    def __getitem__(self, k):
+        return self._name(k)
+names = Names()
 # the pattern that carries (nearly) all of a kernel's bytes on each side: RIR rows are 8-B/lane nt loads; the stash of k_obs_rows
 # goes out as 16-B nt stores and comes back as 16-B loads next to 8-B row loads (fetch side mixed: both factors are given)
 dominant = {"k_conv<FUSE=true>": ("rd8_nt", "wr4"), "k_conv<FUSE=true,loop>": ("rd8_nt", "wr8_nt"),
-            "k_obs_rows<SPECTRAL=false>": ("rd16", "wr16_nt"), "k_features<logmel,gccphat>": ("rd16", "wr4")}
+            "k_conv<FUSE=false,loop>": ("rd8_nt", "wr8_nt"), "k_conv<FUSE=false>": ("rd8_nt", "wr8_nt"),
+            "k_obs_rows<SPECTRAL=false>": ("rd16", "wr16_nt"), "k_features<logmel,gccphat>": ("rd16", "wr4"),
+            "k_features<spectrogram,logmel,gccphat>": ("rd16", "wr4")}
 kernels = {}
 for cfg in ("headline", "cfg2", "cfg4"):
     d = os.path.join(out, "pmc_" + cfg)
@@ -98,7 +114,7 @@ for cfg in ("headline", "cfg2", "cfg4"):
     except Exception:
         continue
     for k, cs in agg.items():
-        if k in names and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        if k in names and names[k] in dominant and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             nm = names[k]
             f_kib = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]); w_kib = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
             rd, wr = dominant[nm]

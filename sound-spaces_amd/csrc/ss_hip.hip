@@ -1112,11 +1112,19 @@ int ss_ctx_join(ss_ctx* h, void* stream) {
     return 0;
 }
 
-static int ctx_features_on(ss_ctx* h, int n, const float* audiogoal, const ss_features* f, void* stream) {
+static int ctx_features_on(ss_ctx* h, int n, const float* audiogoal, float* spectrogram, const ss_features* f, void* stream) {
     if (!f) return 0;
     const ssctx::Context& c = h->c;
-    return ss_audio_features_f32(audiogoal, n, c.out_len, c.pad_mode, nullptr, f->logmel, f->mel_start, f->mel_w, f->n_mels,
+    return ss_audio_features_f32(audiogoal, n, c.out_len, c.pad_mode, spectrogram, f->logmel, f->mel_start, f->mel_w, f->n_mels,
                                  f->max_len, f->mel_eps, f->gccphat, f->max_lag, f->gcc_eps, stream);
+}
+
+// A step with extension features: k_features has every frame's spectrum of both ears in registers anyway, so the pooled
+// spectrogram comes from IT (+4.7 us per 256 units) and the convolution launch drops its fused STFT phase (-7 us per round of
+// 256 rows): the waveform is the hand-over either way (the features need it in memory).
+static bool features_take_spectrogram(const ss_features* f, const float* audiogoal, const float* spectrogram) {
+    static const bool off = ab_flag("SS_HIP_FEAT_KEEP_FUSED");       // (A/B builds only)
+    return !off && f && audiogoal && spectrogram;
 }
 
 static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, const ss_features* f,
@@ -1126,9 +1134,10 @@ static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audio
     if (n == 0) return 0;
     ssctx::Context& c = h->c;
     if ((!c.rir && !c.hspec && c.buckets.empty()) || !c.rir_len || !c.src_dev) return SS_EINVAL;
+    const bool sg_late = features_take_spectrogram(f, audiogoal, spectrogram);
     if (c.n_lanes <= 1) {
-        const int rc = ctx_observe_on(h, units, n, audiogoal, spectrogram, stream, -1);
-        return rc ? rc : ctx_features_on(h, n, audiogoal, f, stream);
+        const int rc = ctx_observe_on(h, units, n, audiogoal, sg_late ? nullptr : spectrogram, stream, -1);
+        return rc ? rc : ctx_features_on(h, n, audiogoal, sg_late ? spectrogram : nullptr, f, stream);
     }
     // overlap mode: this step goes to the next internal stream, behind whatever the caller's stream holds right now (the
     // consumers of the output rows it overwrites, uploads of RIR rows it reads); the caller's stream sees the result after
@@ -1139,8 +1148,8 @@ static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audio
     if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
     if (e != hipSuccess) return hip_err(e);
     c.lane_dirty[lane] = true;
-    const int rc = ctx_observe_on(h, units, n, audiogoal, spectrogram, c.lane_stream[lane], lane);
-    return rc ? rc : ctx_features_on(h, n, audiogoal, f, c.lane_stream[lane]);
+    const int rc = ctx_observe_on(h, units, n, audiogoal, sg_late ? nullptr : spectrogram, c.lane_stream[lane], lane);
+    return rc ? rc : ctx_features_on(h, n, audiogoal, sg_late ? spectrogram : nullptr, f, c.lane_stream[lane]);
 }
 
 int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
