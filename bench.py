@@ -326,6 +326,11 @@ def measure_deferred_path(torch, np, dev, sr, n_envs, bank, sources, steps, warm
     for s_ in sims_b:
         s_._duration = 10 ** 9
     vobs = sim_audio.VectorAudioObserver(eng, [sim_audio.attach(s_, eng, rir_reader=reader) for s_ in sims_b])
+    for lo in range(0, len(poses), n_envs):                   # scene load for THIS observer's pair table (rows are resident)
+        for sim, (r_, s_, az) in zip(sims_b, poses[lo:lo + n_envs]):
+            sim._receiver_position_index, sim._source_position_index, sim._rotation_angle = r_, s_, 90 * az
+        vobs.observe()
+    torch.cuda.synchronize()
     h_us = []
     for k in range(total):
         if k == warmup:
