@@ -45,7 +45,8 @@ extern "C" {
  *   out[:, n] = conv(term 0)[n]                                         beyond
  * (rows are 1 s long in both simulators, so out_len is the sampling rate); units whose term 1 is absent
  * (first step of an episode, `_last_rir is None`) are not blended.  One launch; with ss_audio_obs_f32 the spectrogram
- * is taken from the blended row. */
+ * is taken from the blended row.  F <= 2414 (sampling rates up to 48 kHz): the ramp waits in LDS while the row is convolved
+ * with the current RIR; longer ramps are refused (SS_EINVAL). */
 #define SS_FLAG_CROSSFADE 2
 /* length-bucketed banks (ss_rir_bucket): every bank index the launch references lies in bucket 0, so the loop-free
  * kernels may serve it (the context's planner sets it per step) */

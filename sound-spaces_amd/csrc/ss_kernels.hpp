@@ -80,7 +80,7 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 
 // STFT geometry of SpectrogramSensor.compute_spectrogram (nav.py:88-93)
 constexpr int kNfft = 512, kHop = 160, kPool = 4, kBins4 = 65;   // 257 bins -> 65 pooled rows
-constexpr int kPrevPairs = 1104;          // XFADE: packed pairs of the cross-fade ramp kept per row (fade_len <= 2206)
+constexpr int kPrevPairs = 1208;          // XFADE: packed pairs of the cross-fade ramp kept per row (fade_len <= 2414: 48 kHz)
 constexpr int kFrameStride = 272;         // transpose tiles (16 x 17 complex per frame); = 16 mod 32 so that the four
                                           // frames of a wave start 32 banks apart (ds_read/write_b64 rules)
 constexpr int kNatStride = 288;           // natural-order spectra per frame; = 0 mod 32 (ds_read_b128 lane groups)
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
             for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
         }
     }
-    // XFADE: the head (samples 0..fade_len <= 4095) of the row convolved with the previous RIR waits here, in the LDS
+    // XFADE: the head (samples 0..fade_len <= 2 kPrevPairs - 2) of the row convolved with the previous RIR waits here, in the LDS
     // the FFT buffer leaves free, while the row is convolved with the current RIR: kept in registers it spilled
     // (the loop kernel already carries the accumulator across the passes at the 128-VGPR cap)
     __shared__ c32 s_prev[XFADE ? kPrevPairs : 1];
@@ -1843,8 +1843,10 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
     __shared__ c32 s_tw512[kTw512Lds];
     // pooled results of an STFT phase | context handed from block j to j+1; before block 0's STFT phase both are free and
     // hold the head of the cross-faded row convolved with the previous RIR (kPrevPairs packed pairs)
-    __shared__ __attribute__((aligned(8))) float s_rt[kRowsResFloats + kTailFloats + 1];
-    static_assert((kRowsResFloats + kTailFloats) * sizeof(float) >= kPrevPairs * sizeof(c32), "s_prev overlay");
+    constexpr int kRtFloats = XFADE && 2 * kPrevPairs > kRowsResFloats + kTailFloats + 1 ? 2 * kPrevPairs
+                                                                                       : kRowsResFloats + kTailFloats + 1;
+    __shared__ __attribute__((aligned(8))) float s_rt[kRtFloats];
+    static_assert(!XFADE || kRtFloats * sizeof(float) >= kPrevPairs * sizeof(c32), "s_prev overlay");
     float* s_res = s_rt;
     float* s_tail = s_rt + kRowsResFloats + (kRowsResFloats & 1);        // (even offset: 8-byte aligned packed reads)
     c32* s_prev = reinterpret_cast<c32*>(s_rt);

@@ -1408,3 +1408,106 @@ def test_core32_kernels_vs_oracle_and_1024_thread_core():
             full = np.zeros((2, sr), np.float32)
             full[:, :n_valid] = ref
             check(g1[u], O.compute_spectrogram(full))
+
+
+# ---- randomized sweep through the product path (context API) ---------------------------------------------------------------
+SWEEP_SS1 = [(16000, 0), (16000, 1), (22050, 2), (44100, 3), (48000, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,seed", SWEEP_SS1)
+def test_randomized_sweep_soundspaces1_through_the_context(sr, seed):
+    """Random steps of SoundSpaces-1.0 semantics (simulator.py:608-666) through ``ss_ctx_observe`` against the oracle: clips of
+    1-4 s at a random ``_audio_index``, ragged RIRs from 37 samples to 2.5 s (and an empty file), silent units, a distractor on
+    a random subset, at 16 / 22.05 / 44.1 / 48 kHz (1, 2, 3 and 3 partition blocks per row: loop-free, loop, and rows kernels
+    chosen by the library)."""
+    from ss_amd.context import AudioContext
+    rng = np.random.default_rng(1000 + seed)
+    secs = [1, 2, 4, 1]
+    src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in secs]
+    lens = [37, sr // 3, sr - 1, sr, sr + 1, int(1.7 * sr), int(2.5 * sr), 0]
+    long = O.synth_rir(rng, sr, length=max(lens), n=len(lens)) * np.exp(-np.arange(max(lens)) / (0.4 * sr))[None, None, :]
+    rirs = [np.ascontiguousarray(long[i, :, :L].astype(np.float32).T) for i, L in enumerate(lens)]      # (heads of long RIRs)
+    assert all(np.isfinite(h).all() for h in rirs)
+    bank = make_renderer(sr, src, rirs).rirs
+    ctx = AudioContext(sr)
+    for i, c in enumerate(src):
+        ctx.add_source(f"s{i}", c)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    for step in range(3):
+        n = 14
+        snd = rng.integers(0, len(src), n)
+        idx = np.array([rng.integers(0, secs[s_]) for s_ in snd])
+        rir = rng.integers(0, len(rirs), n)
+        rir[rng.random(n) < 0.15] = -1                                        # silent (simulator.py:610)
+        with_dis = (step > 0) & (rng.random(n) < 0.5) & (rir >= 0)
+        dsnd = np.where(with_dis, rng.integers(0, len(src), n), 0)
+        drir = np.where(with_dis, rng.integers(0, len(rirs) - 1, n), -1)
+        t0 = np.array([P.window_start_sim(len(src[s_]), sr, int(i_)) for s_, i_ in zip(snd, idx)])
+        sg = torch.full((n,) + ctx.spectrogram_shape, float("nan"), device=DEV)
+        ag = torch.full((n, 2, sr), float("nan"), device=DEV)
+        kw = dict(dis_sound=dsnd, dis_rir=drir) if step > 0 else {}
+        ctx.observe(snd, t0, rir, spectrogram_out=sg, audiogoal_out=ag, **kw)
+        torch.cuda.synchronize()
+        sg, ag = sg.cpu().numpy(), ag.cpu().numpy()
+        for u in range(n):
+            if rir[u] < 0:
+                assert not ag[u].any() and not sg[u].any()
+                continue
+            h = rirs[rir[u]] if lens[rir[u]] else O.zero_rir(sr)
+            kwd = {}
+            if with_dis[u]:
+                hd = rirs[drir[u]] if lens[drir[u]] else O.zero_rir(sr)
+                kwd = dict(distractor=src[dsnd[u]], distractor_rir=hd)
+            ref = O.compute_audiogoal(src[snd[u]], h, sr, audio_index=int(idx[u]), **kwd).astype(np.float32)
+            check(ag[u], ref)
+            check(sg[u], O.compute_spectrogram(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr,step_time,seed", [(16000, 0.25, 0), (16000, 0.1, 1), (16000, 1.0, 2), (44100, 0.25, 3),
+                                               (44100, 0.4, 4), (44100, 1.0, 5), (48000, 0.25, 6)])
+def test_randomized_sweep_soundspaces2_through_the_context(sr, step_time, seed):
+    """Random steps of SoundSpaces-2.0 semantics (continuous_simulator.py:413-456, CROSSFADE :47-53) through ``ss_ctx_observe``:
+    a random sample index (early and steady branch, wrap-around at the clip end), ragged live RIRs, a previous RIR on a random
+    subset, step lengths that end inside block 0 (one launch of the fused loop kernel, also at 44.1 / 48 kHz), in block 1
+    (0.4 s at 44.1 kHz) and full rows."""
+    from ss_amd.context import AudioContext
+    rng = np.random.default_rng(2000 + seed)
+    src = [O.tile_short_source(O.synth_sources(rng, sr, k=1, seconds=s_)[0], sr) for s_ in (1, 2)]
+    lens = [211, sr // 4, sr // 2 + 3, sr, int(1.3 * sr)]
+    long = O.synth_rir(rng, sr, length=max(lens), n=len(lens)) * np.exp(-np.arange(max(lens)) / (0.3 * sr))[None, None, :]
+    rirs = [np.ascontiguousarray(long[i, :, :L].astype(np.float32).T) for i, L in enumerate(lens)]
+    assert all(np.isfinite(h).all() for h in rirs)
+    bank = make_renderer(sr, src, rirs, step_time=step_time, wrap=True).rirs
+    ctx = AudioContext(sr, step_time=step_time, wrap=True)
+    for i, c in enumerate(src):
+        ctx.add_source(f"s{i}", c)
+    ctx.set_rir_bank(bank.data, bank.lengths)
+    ns = int(sr * step_time)
+    for step in range(3):
+        n = 10
+        snd = rng.integers(0, len(src), n)
+        index = np.array([int(rng.integers(0, len(src[s_]))) for s_ in snd])
+        index[0] = 0
+        rir = rng.integers(0, len(rirs), n)
+        rir[1] = -1
+        last = np.where((step > 0) & (rng.random(n) < 0.6) & (rir >= 0), rng.integers(0, len(rirs), n), -1)
+        wrap = np.array([index[u] - lens[rir[u]] >= 0 if rir[u] >= 0 else False for u in range(n)], np.uint8)
+        lwrap = np.array([index[u] - lens[last[u]] >= 0 if last[u] >= 0 else False for u in range(n)], np.uint8)
+        sg = torch.full((n,) + ctx.spectrogram_shape, float("nan"), device=DEV)
+        ag = torch.full((n, 2, sr), float("nan"), device=DEV)
+        kw = dict(last_rir=last, last_wrap=lwrap) if step > 0 else {}
+        ctx.observe(snd, index, rir, spectrogram_out=sg, audiogoal_out=ag, wrap=wrap, **kw)
+        torch.cuda.synchronize()
+        sg, ag = sg.cpu().numpy(), ag.cpu().numpy()
+        for u in range(n):
+            if rir[u] < 0:
+                assert not ag[u].any() and not sg[u].any()
+                continue
+            ref = O.compute_audiogoal_continuous(src[snd[u]], rirs[rir[u]], sr, int(index[u]), step_time,
+                                                 last_rir=rirs[last[u]] if last[u] >= 0 else None,
+                                                 use_crossfade=last[u] >= 0).astype(np.float32)
+            assert not ag[u][:, ns:].any()
+            check(ag[u], ref)
+            check(sg[u], O.compute_spectrogram(ref))
