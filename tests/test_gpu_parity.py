@@ -1411,16 +1411,18 @@ def test_core32_kernels_vs_oracle_and_1024_thread_core():
 
 
 # ---- randomized sweep through the product path (context API) ---------------------------------------------------------------
-SWEEP_SS1 = [(16000, 0), (16000, 1), (22050, 2), (44100, 3), (48000, 4)]
+SWEEP_SS1 = [(16000, 0, "plain"), (16000, 1, "plain"), (22050, 2, "plain"), (44100, 3, "plain"), (48000, 4, "plain"),
+             (16000, 5, "spectral"), (44100, 6, "spectral"), (16000, 7, "big"), (16000, 8, "constant_pad"), (44100, 9, "constant_pad")]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sr,seed", SWEEP_SS1)
-def test_randomized_sweep_soundspaces1_through_the_context(sr, seed):
+@pytest.mark.parametrize("sr,seed,variant", SWEEP_SS1)
+def test_randomized_sweep_soundspaces1_through_the_context(sr, seed, variant):
     """Random steps of SoundSpaces-1.0 semantics (simulator.py:608-666) through ``ss_ctx_observe`` against the oracle: clips of
     1-4 s at a random ``_audio_index``, ragged RIRs from 37 samples to 2.5 s (and an empty file), silent units, a distractor on
     a random subset, at 16 / 22.05 / 44.1 / 48 kHz (1, 2, 3 and 3 partition blocks per row: loop-free, loop, and rows kernels
-    chosen by the library)."""
+    chosen by the library).  Variants: the spectral form of the bank, 330 units per step (more rows than CUs: persistent
+    workgroups) with audiogoal-only and spectrogram-only calls, librosa's constant padding."""
     from ss_amd.context import AudioContext
     rng = np.random.default_rng(1000 + seed)
     secs = [1, 2, 4, 1]
@@ -1429,13 +1431,17 @@ def test_randomized_sweep_soundspaces1_through_the_context(sr, seed):
     long = O.synth_rir(rng, sr, length=max(lens), n=len(lens)) * np.exp(-np.arange(max(lens)) / (0.4 * sr))[None, None, :]
     rirs = [np.ascontiguousarray(long[i, :, :L].astype(np.float32).T) for i, L in enumerate(lens)]      # (heads of long RIRs)
     assert all(np.isfinite(h).all() for h in rirs)
+    pad = "constant" if variant == "constant_pad" else "reflect"
     bank = make_renderer(sr, src, rirs).rirs
-    ctx = AudioContext(sr)
+    ctx = AudioContext(sr, pad_mode=pad)
     for i, c in enumerate(src):
         ctx.add_source(f"s{i}", c)
     ctx.set_rir_bank(bank.data, bank.lengths)
+    if variant == "spectral":
+        bank.build_spectra()
+        ctx.set_rir_spectra(bank.spectra)
     for step in range(3):
-        n = 14
+        n = 330 if variant == "big" else 14
         snd = rng.integers(0, len(src), n)
         idx = np.array([rng.integers(0, secs[s_]) for s_ in snd])
         rir = rng.integers(0, len(rirs), n)
@@ -1447,10 +1453,14 @@ def test_randomized_sweep_soundspaces1_through_the_context(sr, seed):
         sg = torch.full((n,) + ctx.spectrogram_shape, float("nan"), device=DEV)
         ag = torch.full((n, 2, sr), float("nan"), device=DEV)
         kw = dict(dis_sound=dsnd, dis_rir=drir) if step > 0 else {}
-        ctx.observe(snd, t0, rir, spectrogram_out=sg, audiogoal_out=ag, **kw)
+        if variant == "big":                                                  # one output per call: the conv-only and the
+            ctx.observe(snd, t0, rir, audiogoal_out=ag, **kw)                 # spectrogram-only launches
+            ctx.observe(snd, t0, rir, spectrogram_out=sg, **kw)
+        else:
+            ctx.observe(snd, t0, rir, spectrogram_out=sg, audiogoal_out=ag, **kw)
         torch.cuda.synchronize()
         sg, ag = sg.cpu().numpy(), ag.cpu().numpy()
-        for u in range(n):
+        for u in (range(n) if n < 50 else range(0, n, 7)):
             if rir[u] < 0:
                 assert not ag[u].any() and not sg[u].any()
                 continue
@@ -1461,7 +1471,8 @@ def test_randomized_sweep_soundspaces1_through_the_context(sr, seed):
                 kwd = dict(distractor=src[dsnd[u]], distractor_rir=hd)
             ref = O.compute_audiogoal(src[snd[u]], h, sr, audio_index=int(idx[u]), **kwd).astype(np.float32)
             check(ag[u], ref)
-            check(sg[u], O.compute_spectrogram(ref))
+            check(sg[u], O.compute_spectrogram(ref, pad_mode=pad))
+        assert not np.isnan(ag).any() and not np.isnan(sg).any()
 
 
 @pytest.mark.gpu
