@@ -64,6 +64,35 @@ for direct in (True, False, True, False):
     print("eager (outputs %s): %.1f us per call" % ("written straight into pinned host memory" if direct else
                                                     "to a device buffer + one async D2H copy", 1e6 * (time.perf_counter() - t0) / 2000))
 sim_audio.EAGER_DIRECT_HOST = True
+# attach(..., lazy_audiogoal=True): a task with a SpectrogramSensor only - the waveform is neither written nor fetched
+sim2 = Sim()
+sim_audio.attach(sim2, eng, rir_reader=lambda path: files[path], lazy_audiogoal=True)
+sen2 = sensors.SpectrogramSensor(sim=sim2, config=NS())
+
+
+def call2():
+    k[0] += 1
+    sim2._receiver_position_index = k[0] % 8
+    sim2._source_position_index = (k[0] // 8) % 8
+    sim2.azimuth_angle = 90 * (k[0] % 4)
+    sim2._spectrogram_cache.clear(); sim2._audiogoal_cache.clear()
+    return sen2.get_observation(observations=None, episode=None)
+
+
+for rep in range(2):
+    for _ in range(200):
+        call2()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        call2()
+    print("eager (lazy_audiogoal=True: spectrogram only, written straight into pinned host memory): %.1f us per call"
+          % (1e6 * (time.perf_counter() - t0) / 2000))
+    for _ in range(200):
+        call()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        call()
+    print("eager (default: audiogoal + spectrogram): %.1f us per call" % (1e6 * (time.perf_counter() - t0) / 2000))
 pr = cProfile.Profile(); pr.enable()
 for _ in range(2000):
     call()

@@ -120,7 +120,8 @@ at::Tensor ctx_observe(int64_t handle, const at::Tensor& sound, const at::Tensor
 // One eager observation (batch 1): plan + launch + ONE device-to-host copy of [audiogoal 2*sr | spectrogram 65*T4*2] into
 // pinned memory + stream synchronise.  dev / host are flat float32 buffers of at least 2*sr (+ 65*T4*2) elements.
 void eager_obs(int64_t handle, int64_t sound, int64_t t0, int64_t rir, int64_t dis_sound, int64_t dis_rir, int64_t last_rir,
-               int64_t wrap, int64_t last_wrap, at::Tensor dev, at::Tensor host, int64_t sr, bool want_spectrogram) {
+               int64_t wrap, int64_t last_wrap, at::Tensor dev, at::Tensor host, int64_t sr, bool want_spectrogram,
+               bool want_audiogoal) {
     // (pinned memory is the caller's contract: Tensor::is_pinned() asks the driver on every call, ~5 us of a 50-us observation)
     TORCH_CHECK(!host.is_cuda() && host.scalar_type() == at::kFloat && host.is_contiguous(),
                 "host: expected a (pinned) contiguous float32 CPU tensor");
@@ -141,10 +142,16 @@ void eager_obs(int64_t handle, int64_t sound, int64_t t0, int64_t rir, int64_t d
     u.wrap = &w;
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev.device());
     hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.device().index()).stream();
-    check_rc(ss_ctx_observe(ctx_of(handle), &u, 1, d, want_spectrogram ? d + n_ag : nullptr, st), "ss_ctx_observe");
+    // want_audiogoal false (a task with a SpectrogramSensor only): the waveform never leaves the CU - no 128 KB over PCIe
+    TORCH_CHECK(want_audiogoal || want_spectrogram, "eager_obs: nothing to compute");
+    check_rc(ss_ctx_observe(ctx_of(handle), &u, 1, want_audiogoal ? d : nullptr, want_spectrogram ? d + n_ag : nullptr, st),
+             "ss_ctx_observe");
     hipError_t e = hipSuccess;
-    if (!direct)
-        e = hipMemcpyAsync(host.data_ptr<float>(), d, sizeof(float) * static_cast<size_t>(n_ag + n_sg), hipMemcpyDeviceToHost, st);
+    if (!direct) {
+        const int64_t lo = want_audiogoal ? 0 : n_ag;
+        e = hipMemcpyAsync(host.data_ptr<float>() + lo, d + lo, sizeof(float) * static_cast<size_t>(n_ag + n_sg - lo),
+                           hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     TORCH_CHECK(e == hipSuccess, "eager_obs: ", hipGetErrorString(e));
 }
@@ -159,7 +166,7 @@ TORCH_LIBRARY(ss_hip, m) {
     m.def("ctx_register(int handle, int ptr) -> ()", &ctx_register);
     m.def("ctx_unregister(int handle) -> ()", &ctx_unregister);
     m.def("eager_obs(int ctx, int sound, int t0, int rir, int dis_sound, int dis_rir, int last_rir, int wrap, int last_wrap, "
-          "Tensor(a!) dev, Tensor(b!) host, int sr, bool want_spectrogram) -> ()");
+          "Tensor(a!) dev, Tensor(b!) host, int sr, bool want_spectrogram, bool want_audiogoal=True) -> ()");
     m.def("native_ops() -> int", []() -> int64_t { return 1; });
 }
 

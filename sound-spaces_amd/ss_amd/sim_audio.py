@@ -71,27 +71,28 @@ def same_rir(a: np.ndarray, b: np.ndarray) -> bool:
     return bool(np.array_equal(a, b))
 
 
-def _render_to_host(backend, req, want_spectrogram: bool):
-    """One unit through the engine and back to the host as (audiogoal [2, sr], spectrogram or None), numpy arrays owned by
-    the caller (the reference's are too: they end up in the simulator's caches).  Both outputs land in ONE device buffer and
-    cross PCIe as ONE async copy into pinned memory - two ``.cpu()`` calls, i.e. two synchronising copies through pageable
-    memory, were 56 of the 92 us of an eager observation."""
+def _render_to_host(backend, req, want_spectrogram: bool, want_audiogoal: bool = True):
+    """One unit through the engine and back to the host as (audiogoal [2, sr] or None, spectrogram or None), numpy arrays owned
+    by the caller (the reference's are too: they end up in the simulator's caches).  Both outputs land in ONE pinned buffer
+    (written by the kernels themselves, or as one async copy) - two ``.cpu()`` calls, i.e. two synchronising copies through
+    pageable memory, were 56 of the 92 us of an eager observation.  want_audiogoal False: the waveform never leaves the CU."""
     eng, sr = backend.engine, backend.sr
     if not hasattr(eng, "renderer"):                             # an engine without device buffers of its own (test doubles)
         out = eng.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram)
-        return (out["audiogoal"][0].cpu().numpy(), out["spectrogram"][0].cpu().numpy() if want_spectrogram else None)
-    from .planning import spectrogram_shape
-    import torch
-    n_ag = 2 * sr
-    shp = spectrogram_shape(sr)
-    n_sg = shp[0] * shp[1] * shp[2]
+        return (out["audiogoal"][0].cpu().numpy() if want_audiogoal else None,
+                out["spectrogram"][0].cpu().numpy() if want_spectrogram else None)
     st = getattr(backend, "_stage", None)
     if st is None:
-        st = backend._stage = (torch.empty(n_ag + n_sg, dtype=torch.float32, device=eng.renderer.device),
-                               torch.empty(n_ag + n_sg, dtype=torch.float32).pin_memory())
-    dbuf, hbuf = st
+        import torch
+        from . import ops
+        from .planning import spectrogram_shape
+        shp = spectrogram_shape(sr)
+        n_ag, n_sg = 2 * sr, shp[0] * shp[1] * shp[2]
+        dbuf = torch.empty(n_ag + n_sg, dtype=torch.float32, device=eng.renderer.device)
+        hbuf = torch.empty(n_ag + n_sg, dtype=torch.float32).pin_memory()
+        st = backend._stage = (dbuf, hbuf, hbuf.numpy(), shp, n_ag, n_sg, torch, ops)
+    dbuf, hbuf, h, shp, n_ag, n_sg, torch, ops = st
     n = n_ag + n_sg if want_spectrogram else n_ag
-    from . import ops
     if ops.NATIVE_OPS and hasattr(eng, "context") and not getattr(eng, "_no_native_eager", False):
         # ONE C++ dispatch (csrc/ss_torch_ops.cpp::eager_obs): the library's planner + window cache + launch
         # (ss_ctx_observe on a one-unit step), one async copy of both outputs into pinned memory, stream synchronise
@@ -99,28 +100,39 @@ def _render_to_host(backend, req, want_spectrogram: bool):
             ctx = eng._sync_context_bank()
         except NotImplementedError:                              # (length-bucketed stores keep the renderer path)
             eng._no_native_eager = True
-            return _render_to_host(backend, req, want_spectrogram)
+            return _render_to_host(backend, req, want_spectrogram, want_audiogoal)
         wrap = 1 if req.wrap is None else int(bool(req.wrap))
         torch.ops.ss_hip.eager_obs(ctx.handle, int(req.sound), int(req.t0), int(req.rir), int(req.dis_sound), int(req.dis_rir),
                                    int(req.last_rir), wrap, wrap if req.last_wrap is None else int(bool(req.last_wrap)),
-                                   dbuf[:0] if EAGER_DIRECT_HOST else dbuf, hbuf, sr, want_spectrogram)
+                                   dbuf[:0] if EAGER_DIRECT_HOST else dbuf, hbuf, sr, want_spectrogram, want_audiogoal)
     else:
         eng.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram, audiogoal_out=dbuf[:n_ag].view(1, 2, sr),
                     spectrogram_out=dbuf[n_ag:].view((1,) + shp) if want_spectrogram else None)
         hbuf[:n].copy_(dbuf[:n], non_blocking=True)
         torch.cuda.current_stream(dbuf.device).synchronize()     # (an event record + synchronize measured 10 us slower)
-    h = hbuf.numpy()
-    return h[:n_ag].reshape(2, sr).copy(), (h[n_ag:n].reshape(shp).copy() if want_spectrogram else None)
+    return (h[:n_ag].reshape(2, sr).copy() if want_audiogoal else None,
+            h[n_ag:n].reshape(shp).copy() if want_spectrogram else None)
 
 
 class HipSimAudio:
     _ids = __import__("itertools").count()
 
-    def __init__(self, sim, engine, rir_reader: Callable[[str], Optional[np.ndarray]] = wav_rir_reader):
-        """engine: ss_amd.renderer.AudioEngine (or any object with source_id / rir_slot / observe)."""
+    def __init__(self, sim, engine, rir_reader: Callable[[str], Optional[np.ndarray]] = wav_rir_reader,
+                 lazy_audiogoal: bool = False):
+        """engine: ss_amd.renderer.AudioEngine (or any object with source_id / rir_slot / observe).
+
+        lazy_audiogoal (opt-in, for tasks whose only audio sensor is the SpectrogramSensor - av_nav's default): a spectrogram
+        request computes and fetches the spectrogram ONLY (the waveform stays on the CU: no 128 KB over PCIe, no host copy);
+        the simulator's ``_audiogoal_cache`` is then filled on demand - an AudioGoalSensor read of a pose whose spectrogram
+        was rendered re-renders the waveform from the SAME request (same clip window, ``_audio_index`` not advanced again:
+        the reference computes both at once, simulator.py:690-701) - and from the first such read on both are fetched
+        together again, as without the option."""
         self.sim = sim
         self.engine = engine
         self.rir_reader = rir_reader
+        self.lazy_audiogoal = bool(lazy_audiogoal)
+        self._ag_wanted = False                      # an audiogoal read has been seen: fetch both outputs per launch
+        self._pending = {}                           # pose -> (spectrogram it belongs to, request) awaiting an audiogoal read
         self._env_id = next(HipSimAudio._ids)        # stable key of this env's live RIR row (USE_RENDERED_OBSERVATIONS False)
         for name in ("_audiogoal_cache", "_spectrogram_cache"):
             if not isinstance(getattr(sim, name, None), dict):
@@ -169,23 +181,34 @@ class HipSimAudio:
         return (sim._source_position_index, sim._receiver_position_index, sim.azimuth_angle)       # :683
 
     # ---- the reference API ----------------------------------------------------------------------------------
-    def _compute(self, want_spectrogram: bool):
+    def _compute(self, want_spectrogram: bool, want_audiogoal: bool = True, keep=None):
         if hasattr(self.engine, "begin_batch"):
             self.engine.begin_batch()
         req = self.unit_request()
+        if keep is not None:
+            keep.append(req)
         if req.silent:
             # simulator.py:610-612: np.zeros((2, sr)) - FLOAT64, and so is the spectrogram nav.py:86-100 makes of it; no launch
             from .planning import spectrogram_shape
             return np.zeros((2, self.sr)), (np.zeros(spectrogram_shape(self.sr)) if want_spectrogram else None)
-        return _render_to_host(self, req, want_spectrogram)
+        return _render_to_host(self, req, want_spectrogram, want_audiogoal)
 
     def get_current_audiogoal_observation(self):
         sim = self.sim
+        self._ag_wanted = True
         if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :679-681
             return self._compute(False)[0]
         key = self._joint_index()
         if key not in sim._audiogoal_cache:
-            sim._audiogoal_cache[key] = self._compute(False)[0]
+            pend = self._pending.pop(key, None) if self._pending else None
+            if pend is not None and sim._spectrogram_cache.get(key) is pend[0]:
+                # lazy_audiogoal: this pose's spectrogram was rendered without its waveform; the waveform of THAT request
+                # (the simulator has not dropped its caches since: the spectrogram is still the cached one)
+                if hasattr(self.engine, "begin_batch"):
+                    self.engine.begin_batch()
+                sim._audiogoal_cache[key] = _render_to_host(self, pend[1], False)[0]
+            else:
+                sim._audiogoal_cache[key] = self._compute(False)[0]
         return sim._audiogoal_cache[key]
 
     def get_current_spectrogram_observation(self, audiogoal2spectrogram=None):
@@ -197,7 +220,7 @@ class HipSimAudio:
         if sim.config.AUDIO.HAS_DISTRACTOR_SOUND:                                                    # :691-693
             if foreign:
                 return audiogoal2spectrogram(self.get_current_audiogoal_observation())
-            return self._compute(True)[1]
+            return self._compute(True, want_audiogoal=not (self.lazy_audiogoal and not self._ag_wanted))[1]
         key = self._joint_index()
         if key not in sim._spectrogram_cache:
             if foreign:
@@ -205,6 +228,16 @@ class HipSimAudio:
             elif key in sim._audiogoal_cache:        # waveform already cached (AudioGoalSensor ran first)
                 from .sensors import SpectrogramSensor
                 sim._spectrogram_cache[key] = SpectrogramSensor.compute_spectrogram(sim._audiogoal_cache[key])
+            elif self.lazy_audiogoal and not self._ag_wanted:
+                keep = []
+                ag, sg = self._compute(True, want_audiogoal=False, keep=keep)
+                sim._spectrogram_cache[key] = sg
+                if ag is not None:                   # (silent step: the zeros cost nothing)
+                    sim._audiogoal_cache[key] = ag
+                else:
+                    if len(self._pending) > 4096:    # (the simulator clears its caches per episode; this map follows lazily)
+                        self._pending.clear()
+                    self._pending[key] = (sg, keep[0])
             else:                                    # one fused launch fills both caches
                 ag, sg = self._compute(True)
                 sim._audiogoal_cache[key] = ag
@@ -212,10 +245,10 @@ class HipSimAudio:
         return sim._spectrogram_cache[key]
 
 
-def attach(sim, engine, rir_reader=wav_rir_reader) -> HipSimAudio:
+def attach(sim, engine, rir_reader=wav_rir_reader, lazy_audiogoal: bool = False) -> HipSimAudio:
     """Install the HIP audio path on a live SoundSpacesSim: the task sensors (the reference's or ss_amd's) keep
-    calling ``sim.get_current_*_observation`` and now reach the GPU renderer."""
-    backend = HipSimAudio(sim, engine, rir_reader)
+    calling ``sim.get_current_*_observation`` and now reach the GPU renderer.  lazy_audiogoal: see ``HipSimAudio``."""
+    backend = HipSimAudio(sim, engine, rir_reader, lazy_audiogoal)
     sim.get_current_audiogoal_observation = backend.get_current_audiogoal_observation
     sim.get_current_spectrogram_observation = backend.get_current_spectrogram_observation
     sim._compute_audiogoal = lambda: backend._compute(False)[0]

@@ -722,6 +722,34 @@ def test_fast_vector_observer_on_gpu(native):
             check(s_out[i], O.compute_spectrogram(ref.astype(np.float32)))
 
 
+def test_eager_lazy_audiogoal_on_gpu():
+    """``attach(..., lazy_audiogoal=True)`` on the real engine (torch.ops.ss_hip.eager_obs with want_audiogoal=False: the
+    kernel writes the spectrogram only): a multi-second clip of the reference-run fixtures at two ``_audio_index`` values, the waveform
+    of the first pose asked for afterwards."""
+    from fakes import FakeSim, NS
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    d = case_inputs("multi_L1.0_i0")
+    sr = d["sr"]
+    rir90, rir180 = d["rir"], np.ascontiguousarray(d["rir"][::-1] * 0.5)
+    files = {"rirs/replica/apartment_0/90/3_7.wav": rir90, "rirs/replica/apartment_0/180/3_7.wav": rir180}
+    sim = FakeSim(sr, {"telephone.wav": d["source"]}, files)
+    eng = AudioEngine(sr, device=DEV, rir_slots=16)
+    back = sim_audio.attach(sim, eng, rir_reader=sim.reader, lazy_audiogoal=True)
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    s0 = sg_sensor.get_observation(observations=None, episode=None)               # azimuth 90, _audio_index 0
+    sim._rotation_angle = 180
+    s1 = sg_sensor.get_observation(observations=None, episode=None)               # azimuth 180, _audio_index 1
+    assert not sim._audiogoal_cache and sim._audio_index == 2
+    a0 = O.compute_audiogoal(d["source"], rir90, sr, audio_index=0).astype(np.float32)
+    a1 = O.compute_audiogoal(d["source"], rir180, sr, audio_index=1).astype(np.float32)
+    check(s0, O.compute_spectrogram(a0))
+    check(s1, O.compute_spectrogram(a1))
+    sim._rotation_angle = 270                                                     # back at azimuth 90
+    check(sensors.AudioGoalSensor(sim=sim, config=NS()).get_observation(observations=None, episode=None), a0)
+    assert sim._audio_index == 2
+
+
 def test_plugin_boundary_end_to_end_on_gpu():
     """The reference-shaped call chain sensor -> sim.get_current_spectrogram_observation -> HIP engine, with the real
     AudioEngine (RIR store + renderer) behind a stand-in simulator object."""

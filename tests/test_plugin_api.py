@@ -101,6 +101,47 @@ def test_multisecond_index_advances_once_per_compute():
     assert sim._audio_index == before
 
 
+def test_lazy_audiogoal_option_defers_the_waveform_without_changing_what_is_observed():
+    """``attach(..., lazy_audiogoal=True)`` (tasks with a SpectrogramSensor only): spectrogram requests fetch no waveform; an
+    audiogoal read of a pose rendered that way returns the waveform of THAT request (same clip window of a 3-s sound,
+    ``_audio_index`` not advanced again, as the reference computes both at once, simulator.py:690-701) and switches the
+    adapter back to fetching both; a cache reset (reconfigure, :395-397) drops what was pending."""
+    sim_a, eng_a, back_a, sounds, rirs = make(seconds=3)
+    sim_b, eng_b, _, _, _ = make(seconds=3)
+    back_b = sim_audio.attach(sim_b, eng_b, rir_reader=sim_b.reader, lazy_audiogoal=True)
+    poses = [(270, 3), (180, 3), (270, 3), (0, 3)]                                 # azimuth 90, 180, 90 again (cache hit), 0 (no file)
+    for rot, recv in poses:
+        for sim in (sim_a, sim_b):
+            sim._rotation_angle, sim._receiver_position_index = rot, recv
+        sa = back_a.get_current_spectrogram_observation()
+        sb = back_b.get_current_spectrogram_observation()
+        assert np.allclose(sa, sb, atol=1e-6) and sim_a._audio_index == sim_b._audio_index
+    assert len(sim_a._audiogoal_cache) == 3 and len(sim_b._audiogoal_cache) == 0 and len(back_b._pending) == 3
+    # the waveform of the FIRST pose (rendered at _audio_index 0), asked for three steps later
+    for sim in (sim_a, sim_b):
+        sim._rotation_angle = 270
+    before = sim_b._audio_index
+    aa, ab = back_a.get_current_audiogoal_observation(), back_b.get_current_audiogoal_observation()
+    assert np.allclose(aa, ab, atol=1e-6) and sim_b._audio_index == before and back_b._ag_wanted
+    ref = O.compute_audiogoal(sounds["telephone.wav"], rirs["rirs/replica/apartment_0/90/3_7.wav"], SR, audio_index=0)
+    assert O.relerr(ab, ref) < 1e-5
+    # from now on both outputs per launch, exactly as without the option
+    for sim in (sim_a, sim_b):
+        sim._audiogoal_cache, sim._spectrogram_cache = dict(), dict()              # reconfigure
+        sim._rotation_angle = 180
+    calls = eng_b.calls
+    sb = back_b.get_current_spectrogram_observation()
+    assert eng_b.calls == calls + 1 and len(sim_b._audiogoal_cache) == 1
+    # a pending entry of a dropped cache is not used: the audiogoal is rendered from the CURRENT state
+    sim_c, eng_c, _, _, _ = make(seconds=3)
+    back_c = sim_audio.attach(sim_c, eng_c, rir_reader=sim_c.reader, lazy_audiogoal=True)
+    back_c.get_current_spectrogram_observation()                                   # _audio_index 0 -> 1, pending
+    sim_c._audiogoal_cache, sim_c._spectrogram_cache = dict(), dict()
+    a = back_c.get_current_audiogoal_observation()                                 # fresh compute at _audio_index 1
+    assert sim_c._audio_index == 2
+    assert O.relerr(a, O.compute_audiogoal(sounds["telephone.wav"], rirs["rirs/replica/apartment_0/90/3_7.wav"], SR, audio_index=1)) < 1e-5
+
+
 def test_distractor_bypasses_caches():
     sim, eng, backend, sounds, rirs = make(has_distractor=True)
     sim._current_distractor_sound = "dist.wav"
