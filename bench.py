@@ -372,7 +372,7 @@ def measured_traffic(units, sr, kernel):
     (scripts/calib_traffic.hip)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r4", "traffic.json")))
-        have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.srchash")).read().strip()
+        have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.kernelhash")).read().strip()
         e = tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
             fc, wc = float(e.get("fetch_correction", 1.0)), float(e.get("write_correction", 1.0))

@@ -132,7 +132,7 @@ for cfg in ("headline", "cfg2", "cfg4"):
                 "note": "per-dispatch means of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB x 1024; separate passes), each multiplied by the "
                         "factor measured in the SAME pass script on a known byte count in the kernel's dominant access pattern "
                         "(scripts/calib_traffic.hip; factors under 'calibration')"}
-src_hash = open("sound-spaces_amd/csrc/.libss_hip.srchash").read().strip()
+src_hash = open("sound-spaces_amd/csrc/.libss_hip.kernelhash").read().strip()     # device code only (build.py::kernel_hash)
 json.dump({"source_hash": src_hash, "command": "bench.py [--config cfg2|cfg4] --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1",
            "calibration": calib, "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps({"calibration": calib, "kernels": kernels}, indent=1))

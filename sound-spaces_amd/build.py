@@ -16,15 +16,23 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wal
 
 
 STAMP = os.path.join(CSRC, ".libss_hip.srchash")
+# the device code alone (everything hipcc compiles into libss_hip.so): the key of profiles/rN/traffic.json - PMC counters of a
+# kernel stay valid when only the host-side op layer (ss_torch_ops.cpp) changes
+KERNEL_SOURCES = [s for s in SOURCES if s != "ss_torch_ops.cpp"]
+KERNEL_STAMP = os.path.join(CSRC, ".libss_hip.kernelhash")
 
 
-def _source_hash():
+def _source_hash(sources=None):
     import hashlib
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for s in SOURCES:
+    for s in (SOURCES if sources is None else sources):
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def kernel_hash():
+    return _source_hash(KERNEL_SOURCES)
 
 
 def up_to_date():
@@ -36,6 +44,9 @@ def up_to_date():
 
 def build(force=False, verbose=True):
     if not force and up_to_date():
+        if not os.path.exists(KERNEL_STAMP):
+            with open(KERNEL_STAMP, "w") as f:
+                f.write(kernel_hash() + "\n")
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + ["ss_hip.hip", "-o", SO]
@@ -48,6 +59,8 @@ def build(force=False, verbose=True):
     build_torch_ops(verbose)
     with open(STAMP, "w") as f:
         f.write(_source_hash() + "\n")
+    with open(KERNEL_STAMP, "w") as f:
+        f.write(kernel_hash() + "\n")
     return SO
 
 
