@@ -232,6 +232,28 @@ __device__ __forceinline__ void stft_load_padded(const float* padded, int tf, in
     }
 }
 
+// the same with the lane's 16 window pairs already in registers (they depend on q alone: a wave that loads two blocks reads
+// them once - LDS reads are what the hand-off of the fused kernels waits for: 16 fewer of 64 per lane)
+__device__ __forceinline__ void stft_window_pairs(const float* win, int q, c32 (&w)[16]) {
+    const c32* w2 = reinterpret_cast<const c32*>(win) + q;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = lds_ld(w2 + 16 * j);
+}
+__device__ __forceinline__ void stft_load_padded_w(const float* padded, int tf, int n_frames, int q, const c32 (&w)[16],
+                                                   c32 (&x)[16]) {
+    if (tf >= n_frames) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = mk2(0.f, 0.f);
+    } else {
+        const c32* y2 = reinterpret_cast<const c32*>(padded + kHop * tf) + q;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const c32 s = lds_ld(y2 + 16 * j);
+            x[j] = mk2(w[j].x * s.x, w[j].y * s.y);
+        }
+    }
+}
+
 // phase B: everything after the load, for ONE wave: sc = this wave's private scratch (kWaveScratch complex),
 // so all synchronisation is wave-scope (no workgroup barrier).  Pooled log1p values go out through STORE(b, value).
 // wq = exp(-2 pi i q / 256) (= twM[64 q], loaded once by the caller); tw512 = LDS copy of the table exp(-2 pi i k / 512), entry k at posN(k).
@@ -1106,8 +1128,17 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     const int live = live_blocks(p.n_valid, len, p.t4);
     const bool one = wv < live, two = wv + 16 < live;
     const float* padded = reinterpret_cast<const float*>(lds);   // frame tf = floats [160 tf, 160 tf + 512)
+#if defined(SS_NO_WINREG)                                          // (A/B arm: the window pairs read from LDS per block)
     stft_load_padded(padded, 4 * wv + (lane >> 4), one ? p.n_frames : 0, lane & 15, s_win, x0);
     stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
+#else
+    {
+        c32 w[16];
+        stft_window_pairs(s_win, lane & 15, w);
+        stft_load_padded_w(padded, 4 * wv + (lane >> 4), one ? p.n_frames : 0, lane & 15, w, x0);
+        stft_load_padded_w(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, w, x1);
+    }
+#endif
     lds_barrier();
     // The pooled values of this ear are collected in LDS and leave together: written straight from the blocks, lane r
     // stores row r of out[unit][r][block][ear] - 64 lanes, 64 different cache lines, 4 bytes each, 26 times per workgroup.
@@ -1819,8 +1850,8 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     c32 x0[16], x1[16];
     const bool one = wv < cnt, two = wv + 16 < cnt;
     const int live = p.n_frames - kPool * b0;             // frames of this phase that exist (relative index < live)
-    stft_load_padded(buf, 4 * wv + (lane >> 4), one ? live : 0, lane & 15, s_win, x0);
-    stft_load_padded(buf, 4 * (wv + 16) + (lane >> 4), two ? live : 0, lane & 15, s_win, x1);
+    stft_load_padded(buf, 4 * wv + (lane >> 4), one ? live : 0, lane & 15, s_win, x0);      // (the window pairs in registers for
+    stft_load_padded(buf, 4 * (wv + 16) + (lane >> 4), two ? live : 0, lane & 15, s_win, x1);  // both rounds spill here: 8-16 VGPRs)
     lds_barrier();
     if (one) stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * cnt + wv] = v; });
     if (two) {
