@@ -229,6 +229,8 @@ class HipSimAudio:
                 from .sensors import SpectrogramSensor
                 sim._spectrogram_cache[key] = SpectrogramSensor.compute_spectrogram(sim._audiogoal_cache[key])
             elif self.lazy_audiogoal and not self._ag_wanted:
+                if self._pending and not sim._spectrogram_cache:      # the simulator dropped its caches (:395-397): so do we
+                    self._pending.clear()
                 keep = []
                 ag, sg = self._compute(True, want_audiogoal=False, keep=keep)
                 sim._spectrogram_cache[key] = sg
