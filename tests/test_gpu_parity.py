@@ -1550,3 +1550,20 @@ def test_randomized_sweep_soundspaces2_through_the_context(sr, step_time, seed):
             assert not ag[u][:, ns:].any()
             check(ag[u], ref)
             check(sg[u], O.compute_spectrogram(ref))
+
+
+@pytest.mark.gpu
+def test_overlap_mode_soak_under_window_cache_churn():
+    """scripts/soak_ctx.py: 1200 steps with eight in flight on two overlap lanes, 167 (sound, second) keys against a window cache
+    that has to evict on most steps - every output bit-identical to a single-stream context's (the overlap mode's
+    eviction guard)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_ctx.py"), "150", "6"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"'evictions': (\d+)", r.stdout)
+    assert m and int(m.group(1)) > 100, r.stdout[-500:]
