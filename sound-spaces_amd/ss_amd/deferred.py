@@ -251,9 +251,10 @@ class DeferredResolver:
         self._pose_cap = 0
         self.native_steps = 0
         if self.columns_ok:                       # every resolver over this store hears about evictions (their pair tables
-            prev = store.on_evict                 # name store slots)
-            store.on_evict = self._evicted if prev is None else \
-                (lambda key, slot, a=prev, b=self._evicted: (a(key, slot), b(key, slot)))
+            if hasattr(store, "add_evict_hook"):  # name store slots); held weakly: a dropped resolver drops out
+                store.add_evict_hook(self._evicted)
+            else:
+                store.on_evict = self._evicted
 
     def _sound(self, name, clip) -> int:
         if clip is not None:

@@ -448,6 +448,7 @@ class RirStore:
         self.slots, self.cap, self.group = slots, cap, group
         self.truncate_to, self.max_cap, self.on_grow = truncate_to, max_cap, on_grow
         self.on_evict = None                                   # on_evict(key, slot): the entry of `key` is about to be reused
+        self._evict_hooks: List = []                           # ... and the same for any number of listeners (add_evict_hook)
         self.defer_uploads = False                             # True (AudioEngine): single-row uploads queue up for flush_uploads()
         self._pending: Dict[int, tuple] = {}
         self._flush_stage = None
@@ -474,6 +475,24 @@ class RirStore:
         self._stage_ev: List = []
         self._stage_k = 0
 
+    def add_evict_hook(self, method) -> None:
+        """Call ``method(key, slot)`` (a BOUND method, held weakly: a listener that is garbage-collected drops out) whenever an
+        entry is about to be reused - every resolver that keeps a table of store slots registers here."""
+        import weakref
+        self._evict_hooks.append(weakref.WeakMethod(method))
+
+    def _notify_evict(self, key, slot) -> None:
+        if self.on_evict is not None:
+            self.on_evict(key, slot)
+        if self._evict_hooks:
+            alive = []
+            for ref in self._evict_hooks:
+                fn = ref()
+                if fn is not None:
+                    fn(key, slot)
+                    alive.append(ref)
+            self._evict_hooks = alive
+
     # ---- batches -----------------------------------------------------------------------------------------
     def begin_batch(self) -> None:
         """Slots handed out from here on belong to one launch: none of them may be evicted for another key of the same
@@ -482,9 +501,9 @@ class RirStore:
 
     def clear(self) -> None:
         """Forget every entry (the rows are rewritten on the next miss)."""
-        if self.on_evict is not None:
+        if self.on_evict is not None or self._evict_hooks:
             for key, slot in list(self._slot_of.items()):
-                self.on_evict(key, slot)
+                self._notify_evict(key, slot)
         self._slot_of.clear()
         self._pending = {}
         self._free = list(range(self.slots - self.group, -1, -self.group))
@@ -668,8 +687,8 @@ class RirStore:
                 raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
                                    "(an entry handed out for this launch would be overwritten); raise rir_slots")
         del self._slot_of[victim]
-        if self.on_evict is not None:
-            self.on_evict(victim, slot)
+        if self.on_evict is not None or self._evict_hooks:
+            self._notify_evict(victim, slot)
         return slot
 
     def touch_slots(self, slots: np.ndarray) -> None:
