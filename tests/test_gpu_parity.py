@@ -1567,3 +1567,15 @@ def test_overlap_mode_soak_under_window_cache_churn():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"'evictions': (\d+)", r.stdout)
     assert m and int(m.group(1)) > 100, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+def test_no_device_memory_leaks_over_long_runs():
+    """scripts/leak_check.py: free HBM before / after 30 000 overlapped steps, 60 create / observe at 44.1 kHz with overlap /
+    destroy cycles of a context (the per-stream stash of k_obs_rows), 1 500 deferred SoundSpaces-2.0 steps."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "leak_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
