@@ -241,6 +241,26 @@ def main():
     add("cont_crossfade_44k", y, sr=sr2, src_seed=14, src_k=2, src_sel=0, rir_seed=16, rir_len=20000, rir_n=2, rir_sel=0,
         last_rir_sel=1, sample_index=50000, step_time=0.25)
 
+    # ---- 48 kHz (round 4: the one-launch kernel for rows with one rendered block serves 44.1 AND 48 kHz steps; the cross-fade
+    # ramp of int(0.05 * 48000) + 1 = 2401 samples is the longest the kernels hold): a plain step in either branch, a
+    # cross-faded step, and a SoundSpaces-1.0 multi-second clip (three blocks per row)
+    sr3 = 48000
+    srcs48 = O.synth_sources(np.random.default_rng(24), sr3, k=2, seconds=1)
+    src3_48 = O.tile_short_source(srcs48[0], sr3)
+    rc48 = O.synth_rir(np.random.default_rng(25), sr3, length=26000, n=2)
+    for name, si in (("early", 5000), ("steady", 61000)):
+        y = run_cont(sr3, src3_48, wav_layout(rc48[0]), si)
+        add(f"cont_{name}_48k", y, sr=sr3, src_seed=24, src_k=2, src_sel=0, rir_seed=25, rir_len=26000, rir_n=2,
+            rir_sel=0, sample_index=si, step_time=0.25)
+    y = run_cont(sr3, src3_48, wav_layout(rc48[0]), 61000, last_rir=wav_layout(rc48[1]).astype(np.float64), use_crossfade=True)
+    add("cont_crossfade_48k", y, sr=sr3, src_seed=24, src_k=2, src_sel=0, rir_seed=25, rir_len=26000, rir_n=2, rir_sel=0,
+        last_rir_sel=1, sample_index=61000, step_time=0.25)
+    src48_3 = O.synth_sources(np.random.default_rng(26), sr3, k=1, seconds=3)[0]
+    rir48 = O.synth_rir(np.random.default_rng(27), sr3, n=1)
+    y, nxt = run_sim(sr3, src48_3, wav_layout(rir48[0]), audio_index=1)
+    add("sim48k_multi_i1", y, sr=sr3, src_seed=26, seconds=3, rir_seed=27, rir_n=1, rir_sel=0, rir_len=sr3, audio_index=1,
+        next_index=int(nxt))
+
     # ---- early branch running past the clip end (:433-437): a 3.1-s RIR (irTime allows up to 4 s), index < L, and
     # index + num_sample > len(source): the slice source[:index+num_sample] just ends, i.e. ZEROS past the clip end,
     # not the wrap-around of the steady branch
@@ -288,6 +308,7 @@ def main():
         out[name + "/spectrogram"] = spec(out[name + "/audiogoal"]).astype(np.float32)
     out["ones16k/spectrogram_shape"] = np.asarray(spec(np.ones((2, 16000))).shape)
     out["ones44k/spectrogram_shape"] = np.asarray(spec(np.ones((2, 44100))).shape)
+    out["ones48k/spectrogram_shape"] = np.asarray(spec(np.ones((2, 48000))).shape)
 
     # keep the fixture small: full audiogoal for 3 cases, every 5th sample for the rest
     full = {"clip1s", "multi_L1.0_i2", "cont_crossfade"}

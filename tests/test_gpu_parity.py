@@ -1112,7 +1112,7 @@ def test_reference_run_vectors_at_44k_one_launch(name):
     check(sg2[0].cpu().numpy(), ref_s)
 
 
-@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k"])
+@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k", "cont_early_48k", "cont_steady_48k"])
 def test_continuous_steps_at_44k_both_forms(name):
     from ss_amd.renderer import UnitRequest
     d = case_inputs(name)
@@ -1222,13 +1222,15 @@ def test_wide_one_block_route_every_step_length():
 
 
 @pytest.mark.gpu
-def test_crossfade_44k_reference_run_vector_both_forms():
-    """cont_crossfade_44k (the reference's own _compute_audiogoal with CROSSFADE on, 44.1 kHz, a 0.25-s step): renderer and
-    ss_audio_obs_f32 without a waveform buffer - one launch either way (k_conv<FUSE, loop, XFADE, WIDE>)."""
+@pytest.mark.parametrize("name", ["cont_crossfade_44k", "cont_crossfade_48k"])
+def test_crossfade_44k_reference_run_vector_both_forms(name):
+    """cont_crossfade_44k / _48k (the reference's own _compute_audiogoal with CROSSFADE on, a 0.25-s step; 48 kHz: the longest
+    ramp the kernels hold): renderer and ss_audio_obs_f32 without a waveform buffer - one launch either way
+    (k_conv<FUSE, loop, XFADE, WIDE>)."""
     from ss_amd.renderer import UnitRequest
-    d = case_inputs("cont_crossfade_44k")
+    d = case_inputs(name)
     sr = d["sr"]
-    ref_a, ref_s, stride = case_outputs("cont_crossfade_44k")
+    ref_a, ref_s, stride = case_outputs(name)
     r = make_renderer(sr, [O.tile_short_source(d["source"], sr)], [d["rir"], d["last_rir"]], step_time=d["step_time"], wrap=True)
     u = [UnitRequest(0, d["sample_index"], 0, wrap=True, last_rir=1, last_wrap=True)]
     from ss_amd import ops
@@ -1579,3 +1581,25 @@ def test_no_device_memory_leaks_over_long_runs():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "leak_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_run_vector_at_48k():
+    """sim48k_multi_i1 (the reference's _compute_audiogoal at 48 kHz, 3-s clip, second 1) through the renderer and the context."""
+    from ss_amd.context import AudioContext
+    from ss_amd.renderer import UnitRequest
+    d = case_inputs("sim48k_multi_i1")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("sim48k_multi_i1")
+    r = make_renderer(sr, [d["source"]], [d["rir"]])
+    t0 = P.window_start_sim(len(d["source"]), sr, d["audio_index"])
+    ag, sg = r.render(r.plan([UnitRequest(0, t0, 0)]), want_audiogoal=True)
+    check(ag[0].cpu().numpy()[:, ::stride], ref_a)
+    check(sg[0].cpu().numpy(), ref_s)
+    ctx = AudioContext(sr)
+    ctx.add_source("s", d["source"])
+    ctx.set_rir_bank(r.rirs.data, r.rirs.lengths)
+    sg2 = torch.empty_like(sg)
+    ctx.observe([0], [t0], [0], spectrogram_out=sg2)
+    torch.cuda.synchronize()
+    check(sg2[0].cpu().numpy(), ref_s)

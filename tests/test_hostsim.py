@@ -616,7 +616,8 @@ def test_zero_pooled_blocks_are_written_not_computed_at_any_step_length(sr, n_va
 
 
 # ---- k_conv<FUSE, loop, XFADE?, WIDE>: one launch for rows of which only block 0 is rendered (SS2.0 steps at 44.1 kHz) ------
-@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k", "cont_crossfade_44k"])
+@pytest.mark.parametrize("name", ["cont_early_44k", "cont_steady_44k", "cont_crossfade_44k", "cont_early_48k", "cont_steady_48k",
+                                  "cont_crossfade_48k"])
 def test_wide_one_block_kernel_vs_reference_run_vectors(name):
     """The reference's ContinuousSoundSpacesSim._compute_audiogoal at 44.1 kHz (continuous_simulator.py:413-456, CROSSFADE
     :47-53): a 0.25-s step renders 11025 samples of a 44100-sample row - block 0 only.  The fused LOOP kernel serves it in
@@ -630,7 +631,7 @@ def test_wide_one_block_kernel_vs_reference_run_vectors(name):
     if xf:
         bank = np.concatenate([planar(d["rir"]), planar(d["last_rir"])])
         lens = [d["rir"].shape[0], d["last_rir"].shape[0]]
-        unit = dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=True, last_rir=1)
+        unit = dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0, wrap=True, last_rir=1)   # (both steady)
     else:
         bank, lens = planar(d["rir"]), [d["rir"].shape[0]]
         unit = dict(sound=0, t0=P.window_start_continuous(d["sample_index"]), rir=0,
@@ -689,6 +690,18 @@ def test_wide_one_block_every_step_length_up_to_one_block():
             check(out[n], ref)
             check(sg[n], ref_s)
             assert (sg[n][ref_s == 0] == 0).all()
+
+
+def test_fused_rows_48k_reference_run_vector():
+    """sim48k_multi_i1: the reference's _compute_audiogoal at 48 kHz (3-s clip, second 1: the steady branch hears the tail of
+    second 0) - three blocks per row through k_obs_rows."""
+    d = case_inputs("sim48k_multi_i1")
+    sr = d["sr"]
+    ref_a, ref_s, stride = case_outputs("sim48k_multi_i1")
+    t0 = P.window_start_sim(len(d["source"]), sr, d["audio_index"])
+    out, sg = hs.run([d["source"]], planar(d["rir"]), [d["rir"].shape[0]], [dict(sound=0, t0=t0, rir=0)], sr, sr, row_wgs=2)
+    check(out[0][:, ::stride], ref_a)
+    check(sg[0], ref_s)
 
 
 # ---- the 512-thread / 32-values-per-thread core (ss_fft_core32.hpp, ss_kernels32.hpp) ---------------------------------
