@@ -24,7 +24,7 @@ for NAME in headline headline_driver_protocol cfg1 cfg2 cfg4 cfg4_no_features re
   [ "$NAME" = headline_driver_protocol ] && continue
   [ "$NAME" = cfg4_no_features ] && continue
   D="$OUT/trace_$NAME"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --regions 1 > "$OUT/bench_under_rocprof_$NAME.json" 2>/dev/null )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --regions 1 --sustain 0 > "$OUT/bench_under_rocprof_$NAME.json" 2>/dev/null )
   python - "$D" > "$OUT/stats_$NAME.txt" <<'PY'
 import csv, glob, os, sys
 print("# rocprofv3 --kernel-trace --stats, bench.py single-stream run (--no-secondary --streams 1): kernels of libss_hip.so")
@@ -37,7 +37,7 @@ PY
 done
 for NAME in headline cfg2 cfg4; do
   ARGS=${CFG[$NAME]}
-  CMD="python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1"
+  CMD="python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1 --sustain 0"
   D="$OUT/pmc_$NAME"
   i=0
   for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -133,7 +133,7 @@ for cfg in ("headline", "cfg2", "cfg4"):
                         "factor measured in the SAME pass script on a known byte count in the kernel's dominant access pattern "
                         "(scripts/calib_traffic.hip; factors under 'calibration')"}
 src_hash = open("sound-spaces_amd/csrc/.libss_hip.kernelhash").read().strip()     # device code only (build.py::kernel_hash)
-json.dump({"source_hash": src_hash, "command": "bench.py [--config cfg2|cfg4] --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1",
+json.dump({"source_hash": src_hash, "command": "bench.py [--config cfg2|cfg4] --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1 --sustain 0",
            "calibration": calib, "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps({"calibration": calib, "kernels": kernels}, indent=1))
 PY
