@@ -101,10 +101,22 @@ inline bool wide_one_block_ok(int out_len, int n_valid, int flags, bool spectral
     return ssk::live_blocks(n_valid, out_len, t4_of(out_len)) <= 26;
 }
 
+// Small steps (fewer rows than CUs): a fused one-block row is rendered by 2^k workgroups on as many CUs, each running the
+// row's convolution and its share of the pooled STFT blocks (ConvParams::parts_log2) - as long as the grid still fits the
+// chip in one round of one workgroup per CU.  26 pooled blocks: k <= 3 (shares of 13 / 7 / 4 blocks).
+inline int parts_log2_for(int n_rows, int n_cus) {
+    static const int forced = ab_int("SS_HIP_PARTS_LOG2", -1);        // (A/B builds only: -DSS_AB)
+    if (forced >= 0) return forced < 3 ? forced : 3;
+    int k = 0;
+    while (k < 3 && (n_rows << (k + 1)) <= n_cus) ++k;
+    return k;
+}
+
 template <bool FUSE>
 int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, hipStream_t st, bool wide = false) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1)) return SS_EINVAL;
     p.nb_y = nb_y;
+    p.parts_log2 = FUSE && !wide ? parts_log2_for(2 * n_units, n_cus) : 0;
     if constexpr (FUSE) {
         if (wide) {
             if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
@@ -122,7 +134,7 @@ int launch_conv(ssk::ConvParams p, int n_units, int nb_y, int flags, int n_cus, 
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && !(flags & SS_FLAG_CROSSFADE) && nb_y == 1 &&
                         p.rir_cap <= ssk::kB && bucket0;
     if ((flags & SS_FLAG_CROSSFADE) && (p.fade_len < 1 || p.fade_len > 2 * ssk::kPrevPairs - 2)) return SS_EINVAL;
-    const dim3 grid(2 * n_units, nb_y), block(ssk::kT);
+    const dim3 grid((2 * n_units) << p.parts_log2, nb_y), block(ssk::kT);
     // more rows than CUs: persistent workgroups that prefetch the next row's RIR under the current row's FFT passes
     const bool planar = p.rir_elem_stride == 1 && !(p.rir_cap & 1) && !(reinterpret_cast<size_t>(p.rir) & 7) &&
                         !(p.rir_unit_stride & 1) && !(p.rir_chan_stride & 1) && p.rir_cap >= 2;
@@ -337,6 +349,7 @@ static int fill_conv(ssk::ConvParams& p, int* n_cus, const float* spec, const fl
     p.stash_nbh = 0;
     p.stash_terms = 0;
     p.n_terms = 2;
+    p.parts_log2 = 0;
     p.n_buckets = 1;
     for (auto& b : p.bk) b = ssk::BankBucket{nullptr, nullptr, 0x7fffffff, 0, 0, 0};
 #if defined(SS_LADDER)                                     // profiling builds only (scripts/gpu_ladder.sh compiles with -DSS_LADDER)
@@ -629,6 +642,7 @@ template <bool FUSE>
 static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags, hipStream_t st, int n_cus = 0) {
     if (nb_y < 1 || nb_y > 3 || (FUSE && nb_y != 1) || (flags & SS_FLAG_CROSSFADE)) return SS_EINVAL;
     p.nb_y = nb_y;
+    p.parts_log2 = FUSE && n_cus > 0 ? parts_log2_for(2 * n_units, n_cus) : 0;
     const bool simple = (flags & SS_FLAG_NO_DISTRACTOR) && nb_y == 1 && p.h_blocks == 1 &&
                         (p.n_buckets == 1 || (flags & SS_FLAG_FIRST_BUCKET));
     static const bool no_rows = ab_flag("SS_HIP_NO_ROW_KERNEL");
@@ -638,7 +652,7 @@ static int launch_conv_spec(ssk::ConvParams p, int n_units, int nb_y, int flags,
             return hip_err(hipGetLastError());
         }
     }
-    const dim3 grid(2 * n_units * nb_y), block(ssk::kT);
+    const dim3 grid((2 * n_units * nb_y) << p.parts_log2), block(ssk::kT);
     if (simple) {
         ssk::UnitTab<true> ut;
         if (fill_unit_tab(ut, g_host_desc, n_units)) hipLaunchKernelGGL((ssk::k_conv_spec<FUSE, true, true>), grid, block, 0, st, p, ut);
@@ -682,7 +696,7 @@ int ss_audio_obs_spec_f32(const float* spec, const float* hspec, const int* rir_
     if (out_len <= ssk::kB && p.t4 <= 26) {
         p.out = audiogoal;
         p.sgram = spectrogram;
-        return launch_conv_spec<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream));
+        return launch_conv_spec<true>(p, n_units, 1, flags, static_cast<hipStream_t>(stream), n_cus);
     }
     if (obs_rows_ok(out_len, n_valid, h_blocks, flags, true, audiogoal != nullptr)) {
         p.out = audiogoal;
@@ -1391,7 +1405,7 @@ int ss_audio_obs_buckets_f32(const float* spec, const ss_rir_bucket* buckets, in
     if (out_len <= ssk::kB && p.t4 <= 26) {
         p.out = audiogoal;
         p.sgram = spectrogram;
-        return spectral ? launch_conv_spec<true>(p, n_units, 1, flags, st) : launch_conv<true>(p, n_units, 1, flags, n_cus, st);
+        return spectral ? launch_conv_spec<true>(p, n_units, 1, flags, st, n_cus) : launch_conv<true>(p, n_units, 1, flags, n_cus, st);
     }
     if (wide_one_block_ok(out_len, n_valid, flags, spectral)) {
         p.out = audiogoal;

@@ -887,6 +887,13 @@ struct ConvParams {
     int h_blocks;
     int xcd_map;                 // != 0: launch slots are dealt to the XCDs in contiguous ranges (row_slot)
     int nb_y;                    // output blocks per row; k_conv_spec: grid = 2N * nb_y, slot = (row, j), j fastest
+    // Small steps (fewer rows than CUs; the reference steps 5-10 envs per GPU: ss_baselines/av_nav/config/audionav/*/
+    // train_telephone/audiogoal_depth_ddppo.yaml:3): a (unit, ear) row is rendered by 2^parts_log2 workgroups on as many CUs.
+    // Each of them runs the whole convolution of the row (redundant, on CUs that would idle) and then ONLY ITS SHARE of the
+    // pooled STFT blocks, which are independent of each other: the STFT phase - 26 blocks on 16 waves = two rounds at four
+    // waves per SIMD, VALU-bound - becomes one round of <= 13 / 7 / 4 blocks.  Fused one-block kernels only; 0 = one
+    // workgroup per row.
+    int parts_log2;
     // k_obs_rows (rows longer than one block, fused): per-workgroup scratch for the block spectra H' of the row being
     // rendered, [gridDim.x][stash_terms][stash_nbh][8192] f32x4 (time-domain bank only); stash_terms = 1 when the
     // launch has no distractor terms
@@ -1089,9 +1096,12 @@ __device__ __forceinline__ void store_row_block(const ConvParams& p, int t, size
 // at most 26 pooled blocks are live (live_blocks) and they only need samples of block 0; the other t4 - live columns are
 // written as zeros.  One launch, no waveform buffer, block spectra accumulated in registers (each is used once).
 constexpr int kResFloats = kBins4 * 26;     // pooled spectrogram of one ear (<= 26 live blocks on the fused path)
+// pooled blocks [part * per, (part + 1) * per) of a row belong to workgroup `part` of its 2^parts_log2 (ConvParams::parts_log2)
+__host__ __device__ constexpr int part_blocks(int t4, int parts_log2) { return (t4 + (1 << parts_log2) - 1) >> parts_log2; }
+
 template <bool WIDE = false>
 __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, const c32 (&y)[8],
-                                                 const float* s_win, const c32* s_tw512, c32 wq, float* s_res) {
+                                                 const float* s_win, const c32* s_tw512, c32 wq, float* s_res, int part = 0) {
     // The row goes to LDS with librosa's centre padding materialised around it (256 samples on each side), so that
     // every frame is an aligned, branch-free read.  (With the padding resolved per sample at load time, the three
     // waves that own the first / last frames ran a ~300-instruction edge path on top of their two blocks; two of them
@@ -1126,17 +1136,21 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     // Short steps (SS2.0: 0.25 s of a 1-s row): pooled blocks that are exactly zero (live_blocks) are written, not computed
     // (16 kHz, 0.25 s: 7 live blocks of 26).  live == t4 otherwise.
     const int live = live_blocks(p.n_valid, len, p.t4);
-    const bool one = wv < live, two = wv + 16 < live;
+    // this workgroup's share of the pooled blocks: [b_lo, b_lo + per) (one workgroup per row: all of them)
+    const int per = WIDE ? 26 : part_blocks(p.t4, p.parts_log2), b_lo = WIDE ? 0 : part * per;
+    const int b_end = min(live, b_lo + per);
+    const int bw = b_lo + wv;                               // this wave's blocks: bw and bw + 16
+    const bool one = bw < b_end, two = bw + 16 < b_end;
     const float* padded = reinterpret_cast<const float*>(lds);   // frame tf = floats [160 tf, 160 tf + 512)
 #if defined(SS_NO_WINREG)                                          // (A/B arm: the window pairs read from LDS per block)
-    stft_load_padded(padded, 4 * wv + (lane >> 4), one ? p.n_frames : 0, lane & 15, s_win, x0);
-    stft_load_padded(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
+    stft_load_padded(padded, 4 * bw + (lane >> 4), one ? p.n_frames : 0, lane & 15, s_win, x0);
+    stft_load_padded(padded, 4 * (bw + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, s_win, x1);
 #else
     {
         c32 w[16];
         stft_window_pairs(s_win, lane & 15, w);
-        stft_load_padded_w(padded, 4 * wv + (lane >> 4), one ? p.n_frames : 0, lane & 15, w, x0);
-        stft_load_padded_w(padded, 4 * (wv + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, w, x1);
+        stft_load_padded_w(padded, 4 * bw + (lane >> 4), one ? p.n_frames : 0, lane & 15, w, x0);
+        stft_load_padded_w(padded, 4 * (bw + 16) + (lane >> 4), two ? p.n_frames : 0, lane & 15, w, x1);
     }
 #endif
     lds_barrier();
@@ -1145,10 +1159,10 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     // From s_res, 32 threads per pooled row write its blocks: every other float of a contiguous range.
     const int rs = WIDE ? 26 : p.t4;                        // row stride of s_res
     if (one)
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * rs + wv] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * rs + bw] = v; });
     if (two) {
         wave_sync();
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * rs + wv + 16] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * rs + bw + 16] = v; });
     }
     lds_barrier();
     float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
@@ -1159,8 +1173,8 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
         }
         return;
     }
-    const int k = t & 31;                                   // (t4 <= 26 on this path)
-    if (k < p.t4)
+    const int k = b_lo + (t & 31);                          // (t4 <= 26 on this path)
+    if ((t & 31) < per && k < p.t4)
         for (int b = t >> 5; b < kBins4; b += kT / 32) o[2 * (b * p.t4 + k)] = k < live ? s_res[b * p.t4 + k] : 0.f;
 }
 
@@ -1181,7 +1195,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
     // grid (2N rows, nb_y output blocks).  (Putting the blocks of a row next to each other in slot order, as k_conv_spec
     // does, was measured 10 % SLOWER here at 44.1 kHz: 91 vs 82 us per 128 units.)
     const int slot = row_slot(blockIdx.x, gridDim.x, p.xcd_map);
-    const int unit = slot >> 1, ch = slot & 1, j = SIMPLE ? 0 : blockIdx.y;
+    // fused one-block rows may be rendered by 2^parts_log2 workgroups each (ConvParams::parts_log2): slot = (row, part)
+    constexpr bool PARTS = FUSE && !WIDE;
+    const int part = PARTS ? slot & ((1 << p.parts_log2) - 1) : 0, row = PARTS ? slot >> p.parts_log2 : slot;
+    if (PARTS && part && part * part_blocks(p.t4, p.parts_log2) >= p.t4) return;     // no pooled block left for this part
+    const int unit = row >> 1, ch = row & 1, j = SIMPLE ? 0 : blockIdx.y;
     const int* d = p.desc + 8 * unit;
     const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
     // fused path: the STFT's window and exp(-2 pi i k/512) tables are staged in the 21 KiB of LDS the FFT buffer
@@ -1330,11 +1348,11 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
             }
         }
     }
-    store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    if (part == 0) store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase<WIDE>(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase<WIDE>(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res, part);
     }
 }
 
@@ -1397,7 +1415,10 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p, UnitTab<TAB> u
 #if defined(SS_LADDER)
     if (p.dbg == 10) return;                            // SS_HIP_DBG=10: the launch alone (dispatch of 2N x 1024 threads)
 #endif
-    const int slot = row_slot(blockIdx.x, grid, p.xcd_map);
+    const int slot_all = row_slot(blockIdx.x, grid, p.xcd_map);
+    // fused rows (one output block) may be rendered by 2^parts_log2 workgroups each (ConvParams::parts_log2)
+    const int part = FUSE ? slot_all & ((1 << p.parts_log2) - 1) : 0, slot = FUSE ? slot_all >> p.parts_log2 : slot_all;
+    if (FUSE && part && part * part_blocks(p.t4, p.parts_log2) >= p.t4) return;
     // (the division of two uniform values is done on the vector unit: bring the quotient back to a scalar register)
     const int row = SIMPLE ? slot : __builtin_amdgcn_readfirstlane(slot / p.nb_y), j = SIMPLE ? 0 : slot - row * p.nb_y;
     const int unit = row >> 1, ch = row & 1;
@@ -1493,11 +1514,11 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p, UnitTab<TAB> u
         return;
     }
 #endif
-    store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    if (part == 0) store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res, part);
     }
 }
 

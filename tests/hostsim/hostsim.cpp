@@ -99,6 +99,7 @@ ssk::Tables host_tables() {
 
 // a second length bucket for the next hs_conv / hs_obs_rows call (cleared by it): entries >= first live in `rir` [n,2,cap]
 static int g_spec_n_valid = -1;
+static int g_parts_log2 = 0;          // the next fused one-block hs_conv / hs_conv_spec call: 2^k workgroups per row (cleared by it)
 static const float* g_b2_rir = nullptr;
 static int g_b2_first = 0, g_b2_cap = 0;
 static void apply_bucket2(ssk::ConvParams& p) {
@@ -128,6 +129,7 @@ extern "C" {
 void hs_set_bucket2(const float* rir, int first, int cap) { g_b2_rir = rir; g_b2_first = first; g_b2_cap = cap; }
 // the next hs_spectrogram call: rows are known to be zero from sample n_valid on (the library's own two-launch path)
 void hs_set_spec_n_valid(int n_valid) { g_spec_n_valid = n_valid; }
+void hs_set_parts_log2(int k) { g_parts_log2 = k; }
 
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
@@ -153,7 +155,7 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
     p.n_frames = 1 + out_len / ssk::kHop;
     p.t4 = (p.n_frames + 3) / 4;
     p.pad_mode = pad_mode;
-    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
+    p.hspec = nullptr; p.h_blocks = 0; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2; p.parts_log2 = 0;
     apply_bucket2(p);
     p.fade_len = static_cast<int>(0.05 * out_len);
     const bool xfade = simple == 2;                     // simple: 0 = loop kernel, 1 = SIMPLE, 2 = loop kernel + XFADE
@@ -176,10 +178,13 @@ int hs_conv(int fuse, int simple, const float* spec, const float* rir, const int
         return 0;
     }
     p.nb_y = nb_y;
-    gridDim = dim3{(unsigned)(2 * n_units), (unsigned)nb_y, 1};
-    for (int b = 0; b < 2 * n_units * nb_y; ++b) {
+    p.parts_log2 = fuse && !wide ? g_parts_log2 : 0;
+    g_parts_log2 = 0;
+    const int gx = (2 * n_units) << p.parts_log2;
+    gridDim = dim3{(unsigned)gx, (unsigned)nb_y, 1};
+    for (int b = 0; b < gx * nb_y; ++b) {
         {
-            blockIdx = dim3{(unsigned)(b % (2 * n_units)), (unsigned)(b / (2 * n_units)), 0};
+            blockIdx = dim3{(unsigned)(b % gx), (unsigned)(b / gx), 0};
             int rc = run_block(ssk::kT, [&] {
                 if (wide) { if (xfade) ssk::k_conv<true, false, true, false, true>(p); else ssk::k_conv<true, false, false, false, true>(p); }
                 else if (xfade) { if (fuse) ssk::k_conv<true, false, true>(p); else ssk::k_conv<false, false, true>(p); }
@@ -282,7 +287,7 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
     p.pad_mode = pad_mode;
     p.fade_len = 0;
     p.hspec = reinterpret_cast<const ssk::f32x4*>(hspec);
-    p.h_blocks = h_blocks; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2;
+    p.h_blocks = h_blocks; p.xcd_map = 0; p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0; p.n_terms = 2; p.parts_log2 = 0;
     apply_bucket2(p);
     const int nb_y = n_valid == 0 ? 1 : (n_valid + ssk::kB - 1) / ssk::kB;
     // WIDE: a row longer than one block of which only block 0 is rendered (the library's wide_one_block_ok)
@@ -301,8 +306,10 @@ int hs_conv_spec(int fuse, int simple, const float* spec, const float* hspec, co
         }
         return 0;
     }
-    gridDim = dim3{(unsigned)(2 * n_units * nb_y), 1, 1};
-    for (int b = 0; b < 2 * n_units * nb_y; ++b) {
+    p.parts_log2 = fuse ? g_parts_log2 : 0;
+    g_parts_log2 = 0;
+    gridDim = dim3{(unsigned)((2 * n_units * nb_y) << p.parts_log2), 1, 1};
+    for (int b = 0; b < (2 * n_units * nb_y) << p.parts_log2; ++b) {
         {
             blockIdx = dim3{(unsigned)b, 0, 0};
             int rc = run_block(ssk::kT, [&] {

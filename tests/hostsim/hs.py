@@ -34,7 +34,7 @@ def _p(a, t):
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
         interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False,
-        bucket2=None, core32=False, tab=False):
+        bucket2=None, core32=False, tab=False, parts_log2=0):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -125,6 +125,9 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
                            int(out_len), int(pad_mode), int(row_wgs), int(no_dis and not crossfade), int(row_stash), int(crossfade))
         assert rc == 0, rc
         return (out if want_audiogoal else None), sg
+    if parts_log2:                                       # fused one-block rows rendered by 2^k workgroups each (ConvParams::parts_log2)
+        assert fuse and not row_wgs and not core32 and not persist
+        L.hs_set_parts_log2(int(parts_log2))
     if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)
         assert not crossfade and not interleaved
         hb = P.ceil_div(cap, P.KB)

@@ -1603,3 +1603,39 @@ def test_reference_run_vector_at_48k():
     ctx.observe([0], [t0], [0], spectrogram_out=sg2)
     torch.cuda.synchronize()
     check(sg2[0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.parametrize("n_units", [1, 2, 16, 32, 64])
+@pytest.mark.parametrize("group", ["one_block_rirs", "all"])
+def test_split_rows_small_steps_vs_reference_run_vectors(n_units, group):
+    """Small steps (the reference steps 5-10 envs per GPU: ss_baselines/av_nav/config/audionav/replica/train_telephone/
+    audiogoal_depth_ddppo.yaml:3): with fewer rows than CUs a fused row is rendered by 2 / 4 / 8 workgroups (ConvParams::
+    parts_log2: the convolution in each, the pooled STFT blocks shared out).  Every unit of the step is one of the
+    reference-run cases (simulator.py:629-647 through nav.py:86-100); `one_block_rirs` keeps the loop-free kernel, `all`
+    (a 1.5-s RIR among them) takes the loop kernel; with and without the waveform, time-domain and spectral bank."""
+    from ss_amd.renderer import UnitRequest
+    names = [c for c in SIM_CASES if group == "all" or case_inputs(c)["rir"].shape[0] <= 16384]
+    assert len(names) >= 3
+    ins = [case_inputs(c) for c in names]
+    sr = ins[0]["sr"]
+    for spectral in (False, True):
+        r = make_renderer(sr, [d["source"] for d in ins], [d["rir"] for d in ins])
+        if spectral:
+            r.rirs.build_spectra()
+        units = []
+        for n in range(n_units):
+            k = n % len(names)
+            units.append(UnitRequest(k, P.window_start_sim(len(ins[k]["source"]), sr, ins[k].get("audio_index", 0)), k))
+        if n_units > 2:
+            units[1] = UnitRequest(silent=True)
+        ag, sg = r.render(r.plan(units), want_audiogoal=True)
+        sg_only = r.render(r.plan(units))[1]
+        ag, sg, sg_only = ag.cpu().numpy(), sg.cpu().numpy(), sg_only.cpu().numpy()
+        for n in range(n_units):
+            if n_units > 2 and n == 1:
+                assert not ag[n].any() and not sg[n].any() and not sg_only[n].any()
+                continue
+            ref_a, ref_s, stride = case_outputs(names[n % len(names)])
+            check(ag[n][:, ::stride], ref_a)
+            check(sg[n], ref_s)
+            check(sg_only[n], ref_s)

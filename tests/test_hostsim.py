@@ -745,3 +745,25 @@ def test_core32_equals_1024_thread_core_on_a_mixed_batch():
             assert O.relerr(sg, s_ref2) <= 2e-6, O.relerr(sg, s_ref2)
             assert not a[1].any() and not a[3].any()          # silent unit / empty RIR: exact zeros
             assert not a[:, :, n_valid:].any()
+
+
+@pytest.mark.parametrize("parts_log2", [1, 2, 3])
+@pytest.mark.parametrize("variant", ["simple", "loop", "spectral", "short_step"])
+def test_split_rows_equal_one_workgroup_per_row(parts_log2, variant):
+    """Small steps: a fused one-block row rendered by 2^k workgroups (ConvParams::parts_log2: the whole convolution in each,
+    the pooled STFT blocks shared out) is BIT-identical to the one-workgroup row: the audiogoal comes from part 0, every
+    pooled column from exactly one part."""
+    d = case_inputs("clip1s_ragged")
+    sr = d["sr"]
+    bank = planar(d["rir"])
+    units = [dict(sound=0, t0=0, rir=0), dict(sound=0, t0=0, rir=-1), dict(sound=0, t0=0, rir=0)]     # (one silent unit)
+    n_valid = 4000 if variant == "short_step" else sr
+    kw = dict(fuse=True, simple=variant != "loop", spectral=variant == "spectral")
+    a1, s1 = hs.run([d["source"]], bank, [d["rir"].shape[0]], units, n_valid, sr, **kw)
+    a2, s2 = hs.run([d["source"]], bank, [d["rir"].shape[0]], units, n_valid, sr, parts_log2=parts_log2, **kw)
+    np.testing.assert_array_equal(a1, a2)
+    np.testing.assert_array_equal(s1, s2)
+    if variant != "short_step":
+        _, ref_s, _ = case_outputs("clip1s_ragged")
+        check(s2[0], ref_s)
+        assert not s2[1].any()
