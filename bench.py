@@ -48,26 +48,46 @@ def bytes_per_unit(sr, rir_len, t4):
 # CPU baseline: the oracle (scipy.signal.fftconvolve x2 + numpy restatement of librosa.stft/block_reduce),
 # one process per core like habitat.VectorEnv, timed for a bounded wall-clock budget.  Runs BEFORE CUDA init.
 def _cpu_worker(args):
-    seed, sr, seconds = args
+    """One reference-style env process: the oracle's restatement of simulator.py:608-666 + nav.py:86-100 on the CONFIG's own
+    shape - `savi`: clips of 1-20 s (every windowing branch), a distractor on every step (two more fftconvolve calls + add);
+    `feats`: the extension features of BASELINE configs[4] (textbook log-mel / GCC-PHAT of the oracle) on top."""
+    seed, sr, seconds, workload, feats = args
     os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     from oracle import ss_oracle as O
     rng = np.random.default_rng(seed)
-    src = O.synth_sources(rng, sr, k=4)
+    savi = workload == "savi"
+    if savi:
+        secs = [1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20]
+        src = [O.synth_sources(rng, sr, k=1, seconds=sec)[0] for sec in secs]
+    else:
+        src = O.synth_sources(rng, sr, k=4)
     rirs = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, sr, n=8)]
-    n, t_conv, t_spec = 0, 0.0, 0.0
+    n, t_conv, t_spec, t_feat = 0, 0.0, 0.0, 0.0
     t0 = time.perf_counter()
     t_end = t0 + seconds
     while time.perf_counter() < t_end:
         ta = time.perf_counter()
-        a = O.compute_audiogoal(src[n % 4], rirs[n % 8], sr)
+        if savi:
+            k = int(rng.integers(0, len(src)))
+            idx = int(rng.integers(0, secs[k]))
+            a = O.compute_audiogoal(src[k], rirs[n % 8], sr, audio_index=idx, distractor=src[n % 3],
+                                    distractor_rir=rirs[(n + 3) % 8])
+        else:
+            a = O.compute_audiogoal(src[n % 4], rirs[n % 8], sr)
         tb = time.perf_counter()
         O.compute_spectrogram(a)
         tc = time.perf_counter()
+        if "logmel" in feats:
+            O.compute_logmel(a, sr)
+        if "gccphat" in feats:
+            O.compute_gcc_phat(a)
+        td = time.perf_counter()
         t_conv += tb - ta
         t_spec += tc - tb
+        t_feat += td - tc
         n += 1
-    return n, time.perf_counter() - t0, t_conv, t_spec
+    return n, time.perf_counter() - t0, t_conv, t_spec, t_feat
 
 
 def usable_cores():
@@ -89,23 +109,34 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(sr, seconds):
+def cpu_baseline(sr, seconds, workload="audiogoal", feats=(), rotations=1):
     cores = usable_cores()
-    one = _cpu_worker((0, sr, min(4.0, seconds)))
+    feats = tuple(feats)
+    one = _cpu_worker((0, sr, min(4.0, seconds), workload, feats))
     with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(100 + i, sr, seconds) for i in range(cores)])
+        res = pool.map(_cpu_worker, [(100 + i, sr, seconds, workload, feats) for i in range(cores)])
     total = sum(r[0] / r[1] for r in res)
     one_rate = one[0] / one[1]
     n_all = sum(r[0] for r in res)
+    shape = ("savi: clips of 1-20 s, distractor on every step (4 fftconvolve calls + add)" if workload == "savi"
+             else "1-s clip, 1-s RIR")
+    stages_one = {"fftconvolve_x2": round(1e3 * one[2] / one[0], 3), "spectrogram": round(1e3 * one[3] / one[0], 3)}
+    stages_all = {"fftconvolve_x2": round(1e3 * sum(r[2] for r in res) / n_all, 3),
+                  "spectrogram": round(1e3 * sum(r[3] for r in res) / n_all, 3)}
+    if workload == "savi":
+        stages_one["fftconvolve_x4"] = stages_one.pop("fftconvolve_x2")
+        stages_all["fftconvolve_x4"] = stages_all.pop("fftconvolve_x2")
+    if feats:
+        stages_one["features"] = round(1e3 * one[4] / one[0], 3)
+        stages_all["features"] = round(1e3 * sum(r[4] for r in res) / n_all, 3)
     return {"value": round(total, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
             "one_core": round(one_rate, 1), "scaling_efficiency": round(total / (one_rate * cores), 3),
-            "stage_ms_one_core": {"fftconvolve_x2": round(1e3 * one[2] / one[0], 3),
-                                  "spectrogram": round(1e3 * one[3] / one[0], 3)},
-            "stage_ms_all_cores": {"fftconvolve_x2": round(1e3 * sum(r[2] for r in res) / n_all, 3),
-                                   "spectrogram": round(1e3 * sum(r[3] for r in res) / n_all, 3)},
-            "sample": f"oracle (scipy fftconvolve x2 + numpy STFT/pool/log1p), {cores} processes (sched affinity / cgroup "
-                      f"quota; os.cpu_count() = {os.cpu_count()}) x {seconds:.0f} s, sr={sr}, 1-s clip, 1-s RIR, caches "
-                      f"off; 1 core alone: {one_rate:.1f} env-steps/s"}
+            "stage_ms_one_core": stages_one, "stage_ms_all_cores": stages_all,
+            "sample": f"oracle (scipy fftconvolve + numpy STFT/pool/log1p"
+                      f"{' + ' + '/'.join(feats) if feats else ''}), {cores} processes (sched affinity / cgroup "
+                      f"quota; os.cpu_count() = {os.cpu_count()}) x {seconds:.0f} s, sr={sr}, {shape}, caches off"
+                      f"{'; a unit = one (env, rotation) observation, the ' + str(rotations) + ' rotations of an env are ' + str(rotations) + ' units' if rotations > 1 else ''}"
+                      f"; 1 core alone: {one_rate:.1f} env-steps/s"}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -477,11 +508,13 @@ def main():
                          "samples (the format SURVEY 8(d) defines the metric and its algorithmic bytes on); 'spectral' = block "
                          "spectra computed once at bank load (ss_rir_spectra_f32), no forward FFT per step, 2x the bytes per "
                          "RIR.  The other format is timed in the same run and reported beside it")
-    ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg4"], default="headline",
+    ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg3", "cfg4"], default="headline",
                     help="BASELINE.json configs[] presets: cfg1 = 32 envs @16 kHz; cfg2 = 128 envs x 4 rotations @44.1 kHz "
                          "(512 units / launch); cfg4 = savi: 256 envs, 21 sounds of 1-20 s, distractor, audiogoal + "
-                         "spectrogram.  (cfg3 = --scaling strong --envs 128 on 8 GPUs.)  Explicit flags override nothing here: "
-                         "a preset sets --envs/--sr/--rotations/--workload")
+                         "spectrogram + the fused log-mel / GCC-PHAT sensor; cfg3 = av_nav DD-PPO: 8 x 16 envs @16 kHz - with "
+                         "--gpus 8 the node's run (16 envs per rank, all-gather of the spectrograms), with --gpus 1 (default) ONE "
+                         "rank's shard of it: 16 envs per step on one GPU.  A preset sets --envs/--sr/--rotations/--workload "
+                         "(cfg3 also --scaling)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernels: the multi-rank launch / exchange / JSON flow on CPU tensors over gloo (tests only; "
                          "the line says dry_run and its value is not a measurement)")
@@ -501,6 +534,14 @@ def main():
         args.envs, args.sr, args.rotations = 32, 16000, 1
     elif args.config == "cfg2":
         args.envs, args.sr, args.rotations = 128, 44100, 4
+    elif args.config == "cfg3":
+        # BASELINE configs[3]: 8 x 16 envs sharded over 8 GPUs.  --gpus 8: 128 envs split over the ranks; fewer GPUs: 16 envs
+        # per rank (the per-GPU shard of the node's run - what one GPU of the node does per step)
+        args.sr, args.rotations = 16000, 1
+        if args.gpus == 8:
+            args.envs, args.scaling = 128, "strong"
+        else:
+            args.envs, args.scaling = 16, "weak"
     elif args.config == "cfg4":
         args.envs, args.sr, args.rotations, args.workload = 256, 16000, 1, "savi"
 
@@ -536,8 +577,8 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:                # rank 0 of ANY world size: an N > 1 line carries it too (the
-        cpu = cpu_baseline(sr, args.cpu_seconds)          # other ranks wait at the first barrier); before any CUDA context
-                                                          # exists (fork-safe)
+        cpu = cpu_baseline(sr, args.cpu_seconds, args.workload, feats, args.rotations)   # other ranks wait at the first barrier);
+                                                          # before any CUDA context exists (fork-safe); the CONFIG's own shape
 
     import numpy as np
     import torch

@@ -333,6 +333,11 @@ typedef struct ss_request_tables {
     const long long* pair_slots;   /* bank slot of the pair's RIR */
     const unsigned char* stale;    /* optional, [n_slots]: != 0 = the row must be reloaded before it is used */
     int n_sounds, n_tables, n_pairs, n_slots;
+    /* optional: the caller's LRU clock.  last_used[slot] = tick is written for every bank slot (< n_slots) a request of the
+     * step resolves to, so that a store evicting by recency still knows which rows the C path used (the lookups never pass
+     * through the store).  NULL: nothing is written. */
+    long long* last_used;
+    long long tick;
 } ss_request_tables;
 int ss_ctx_observe_requests(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, float* audiogoal,
                             float* spectrogram, int* miss_out, int* n_miss, void* stream);
@@ -346,6 +351,22 @@ int ss_ctx_plan(ss_ctx* ctx, const ss_units* units, int n, int* unit_desc_out, i
                 int* new_windows_out, int new_windows_cap);
 /* out8 = {cache hits, misses, evictions, grows, capacity (keys), keys resident, pool slots per key, steps planned} */
 int ss_ctx_stats(ss_ctx* ctx, long long* out8);
+
+/* ---- RIR files -> staging rows (the step BEFORE the path: SURVEY 8(f)2) ---------------------------------------------
+ * Replaces the reference's per-miss `scipy.io.wavfile.read(binaural_rir_file)` (soundspaces/simulator.py:615-618, float32
+ * stereo files under <binaural_rir_dir>/<azimuth>/<recv>_<src>.wav) for bulk loads and the per-step pose misses of the
+ * vector modes: n files are parsed (RIFF header, "fmt " / "data" chunks) and their first `keep` frames (keep < 0: all) are
+ * read() straight into row i of `dst` on up to n_threads plain threads - HOST pointers here, typically a pinned staging
+ * block that one H2D copy then moves.  Row i starts at dst + i * row_stride floats (row_stride >= 2 * cap) and is
+ * wav-interleaved [cap][2] (planar = 0: the file's own layout, no transpose; the kernels read such rows with
+ * rir_elem_stride = 2) or planar [2][cap] (planar = 1); rows are zero beyond the frames kept.
+ * status_out[i]: 0 loaded; 1 not a plain little-endian float32 stereo RIFF/WAVE file (integer PCM, RIFX, malformed ...):
+ * NOT interpreted here - route that file through the Python reader, which keeps scipy's semantics (ValueError -> zero RIR,
+ * :619-621); 2 no frames (-> zero RIR, :622-624); 3 cannot be opened; 4 more frames to keep than `cap` (nothing read:
+ * grow the rows and retry).  kept_out[i] = frames stored, frames_out[i] = frames in the file.  Rows with a non-zero
+ * status are zero-filled.  Returns 0 / SS_EINVAL. */
+int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep, int planar,
+                         int* kept_out, int* frames_out, int* status_out, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libss_hip.so")
 TORCH_SO = os.path.join(CSRC, "libss_torch_ops.so")
-SOURCES = ["ss_torch_ops.cpp", "ss_hip.hip", "ss_kernels.hpp", "ss_fft_core.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp", "ss_features.hpp", "ss_tables.hpp", "ss_context.hpp", os.path.join("..", "..", "include", "ss_hip.h")]
+SOURCES = ["ss_torch_ops.cpp", "ss_hip.hip", "ss_kernels.hpp", "ss_fft_core.hpp", "ss_kernels32.hpp", "ss_fft_core32.hpp", "ss_features.hpp", "ss_tables.hpp", "ss_context.hpp", "ss_wavio.hpp", os.path.join("..", "..", "include", "ss_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

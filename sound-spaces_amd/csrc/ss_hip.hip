@@ -16,6 +16,7 @@
 #include "ss_kernels32.hpp"
 #include "ss_features.hpp"
 #include "ss_tables.hpp"
+#include "ss_wavio.hpp"
 
 namespace {
 
@@ -1275,6 +1276,7 @@ static int requests_to_units(ss_ctx* h, const long long* recs, int n, const ss_r
         if (recv < 0 || src < 0 || recv >= (1 << 20) || src >= (1 << 20)) return -1;
         const long long s = find_key(tb->pair_keys, tb->pair_slots, tb->n_pairs, (table << 40) | (recv << 20) | src);
         if (s < 0 || (tb->stale && s < tb->n_slots && tb->stale[s])) return -1;
+        if (tb->last_used && s < tb->n_slots) tb->last_used[s] = tb->tick;      // the caller's LRU clock
         return static_cast<int>(s);
     };
     for (int i = 0; i < n; ++i) {
@@ -1455,3 +1457,12 @@ int ss_ctx_set_rir_buckets(ss_ctx* h, const ss_rir_bucket* buckets, int n_bucket
 }
 
 }  // extern "C"
+
+// ---- RIR files -> staging rows (host only; see ss_wavio.hpp) ------------------------------------------------------
+extern "C" int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep,
+                                    int planar, int* kept_out, int* frames_out, int* status_out, int n_threads) {
+    if (n == 0) return 0;
+    if (!paths || !dst || !kept_out || !frames_out || !status_out || n < 0 || cap < 1 || row_stride < 2LL * cap) return SS_EINVAL;
+    sswav::read_many(paths, n, dst, row_stride, cap, keep, planar != 0, kept_out, frames_out, status_out, n_threads);
+    return 0;
+}

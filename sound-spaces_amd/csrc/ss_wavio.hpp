@@ -1,0 +1,125 @@
+// ss_wavio.hpp — the RIR miss path's file reader (host C++, no HIP): many float32 binaural wav files straight into a
+// staging block, on a pool of plain threads (no interpreter lock, no per-file array objects, no transposes).
+//
+// Reference: SoundSpacesSim._compute_audiogoal reads `<binaural_rir_dir>/<azimuth>/<recv>_<src>.wav` with
+// scipy.io.wavfile.read on EVERY cache-missing step (soundspaces/simulator.py:615-618, "# float32"), from a data set of
+// 867 GB (soundspaces/README.md:9); an unreadable file (ValueError) and an empty one become the zero RIR (:619-624).
+// Here: a file is parsed once (RIFF header, "fmt " and "data" chunks), its first `keep` frames are read() directly into
+// the caller's row - wav-interleaved [frames][2], the layout the file already has - and the row is zero-filled behind
+// them.  Anything that is not a plain little-endian IEEE-float32 stereo RIFF/WAVE file is NOT interpreted here: it is
+// reported (status) and the caller routes that one file through the Python reader, which reproduces scipy's behaviour
+// (integer PCM, RIFX, malformed chunks -> ValueError -> zero RIR) exactly.
+#pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace sswav {
+
+enum Status : int {
+    kOk = 0,            // row filled
+    kUnsupported = 1,   // not a plain float32 stereo RIFF/WAVE file: the caller's Python reader decides (scipy semantics)
+    kEmpty = 2,         // readable, zero frames            -> zero RIR (simulator.py:622-624)
+    kMissing = 3,       // open() failed                    -> the caller raises / maps to the zero RIR (lenient)
+    kTooLong = 4,       // more frames to keep than the row holds: nothing read, the caller grows its rows and retries
+};
+
+inline bool read_exact(int fd, void* buf, size_t n) {
+    char* p = static_cast<char*>(buf);
+    while (n) {
+        const ssize_t r = ::read(fd, p, n);
+        if (r < 0) { if (errno == EINTR) continue; return false; }
+        if (r == 0) return false;
+        p += r; n -= static_cast<size_t>(r);
+    }
+    return true;
+}
+inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
+inline uint16_t le16(const unsigned char* p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
+
+// One file -> one row.  dst: [cap][2] floats (interleaved) or, planar, dst[c * cap + n].  keep < 0: the whole file.
+// frames_out: frames the FILE holds (the caller learns whether the row was clipped); returns the Status, *kept = frames stored.
+inline int read_one(const char* path, float* dst, int cap, int keep, bool planar, int* kept, int* frames_out,
+                    std::vector<float>& scratch) {
+    *kept = 0; *frames_out = 0;
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return kMissing;
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    unsigned char h[12];
+    if (!read_exact(fd, h, 12) || std::memcmp(h, "RIFF", 4) != 0 || std::memcmp(h + 8, "WAVE", 4) != 0) return kUnsupported;
+    bool have_fmt = false;
+    int channels = 0, bits = 0, tag = 0, block_align = 0;
+    for (;;) {
+        unsigned char ch[8];
+        if (!read_exact(fd, ch, 8)) return kUnsupported;          // no data chunk / truncated header: scipy's call
+        const uint32_t sz = le32(ch + 4);
+        if (std::memcmp(ch, "fmt ", 4) == 0) {
+            unsigned char f[40];
+            if (sz < 16 || sz > 40 || !read_exact(fd, f, sz)) return kUnsupported;
+            tag = le16(f); channels = le16(f + 2); block_align = le16(f + 12); bits = le16(f + 14);
+            if (tag == 0xFFFE && sz >= 26) tag = le16(f + 24);    // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
+            if (sz & 1) { unsigned char pad; if (!read_exact(fd, &pad, 1)) return kUnsupported; }
+            have_fmt = true;
+        } else if (std::memcmp(ch, "data", 4) == 0) {
+            if (!have_fmt || tag != 3 || bits != 32 || channels != 2 || block_align != 8) return kUnsupported;
+            struct stat st;
+            if (::fstat(fd, &st) != 0) return kUnsupported;
+            const off_t pos = ::lseek(fd, 0, SEEK_CUR);
+            if (pos < 0 || static_cast<uint64_t>(st.st_size - pos) < sz) return kUnsupported;   // truncated data chunk
+            const int frames = static_cast<int>(sz / 8);
+            *frames_out = frames;
+            if (frames == 0) return kEmpty;
+            const int n = keep >= 0 && keep < frames ? keep : frames;
+            if (n > cap) return kTooLong;
+            if (!planar) {
+                if (!read_exact(fd, dst, static_cast<size_t>(n) * 8)) return kUnsupported;
+                std::memset(dst + static_cast<size_t>(n) * 2, 0, static_cast<size_t>(cap - n) * 8);
+            } else {
+                scratch.resize(static_cast<size_t>(n) * 2);
+                if (!read_exact(fd, scratch.data(), static_cast<size_t>(n) * 8)) return kUnsupported;
+                for (int c = 0; c < 2; ++c) {
+                    float* row = dst + static_cast<size_t>(c) * cap;
+                    for (int i = 0; i < n; ++i) row[i] = scratch[2 * static_cast<size_t>(i) + c];
+                    std::memset(row + n, 0, static_cast<size_t>(cap - n) * 4);
+                }
+            }
+            *kept = n;
+            return kOk;
+        } else {                                                   // LIST, fact, ...: skipped (word-aligned)
+            if (::lseek(fd, static_cast<off_t>(sz) + (sz & 1), SEEK_CUR) < 0) return kUnsupported;
+        }
+    }
+}
+
+// n files -> n rows of `row_stride` floats each, on up to n_threads threads (files are dealt out dynamically).
+// Rows whose file did not load (status != kOk) are zero-filled, kept = 0.
+inline void read_many(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep, bool planar,
+                      int* kept, int* frames, int* status, int n_threads) {
+    std::atomic<int> next{0};
+    auto work = [&] {
+        std::vector<float> scratch;
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) return;
+            float* row = dst + static_cast<size_t>(i) * static_cast<size_t>(row_stride);
+            status[i] = read_one(paths[i], row, cap, keep, planar, &kept[i], &frames[i], scratch);
+            if (status[i] != kOk) std::memset(row, 0, static_cast<size_t>(cap) * 8);
+        }
+    };
+    const int nt = n_threads < 1 ? 1 : (n_threads > n ? n : n_threads);
+    if (nt <= 1) { work(); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace sswav

@@ -15,7 +15,8 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_rir_spectra_f32", "ss_fftconv_binaural_spec_f32", "ss_audio_obs_spec_f32", "ss_ctx_observe_sims",
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
            "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
-           "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features")
+           "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features",
+           "ss_wav_read_rirs_f32")
 
 
 class SsRirBucket(ctypes.Structure):
@@ -35,7 +36,8 @@ class SsRequestTables(ctypes.Structure):
     """struct ss_request_tables of include/ss_hip.h."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("sound_keys", "sound_ids", "table_keys", "table_ids", "pair_keys", "pair_slots",
                                               "stale")] + \
-               [(n, ctypes.c_int) for n in ("n_sounds", "n_tables", "n_pairs", "n_slots")]
+               [(n, ctypes.c_int) for n in ("n_sounds", "n_tables", "n_pairs", "n_slots")] + \
+               [("last_used", ctypes.c_void_p), ("tick", ctypes.c_longlong)]
 
 
 class SsFeatures(ctypes.Structure):
@@ -105,6 +107,7 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe_features.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, ctypes.POINTER(SsFeatures), vp]
     lib.ss_ctx_observe_requests.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp]
     lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
+    lib.ss_wav_read_rirs_f32.argtypes = [vp, c_int, vp, c_ll, c_int, c_int, c_int, vp, vp, vp, c_int]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib
@@ -115,3 +118,24 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         kind = "invalid argument" if rc == -1 else f"hipError_t {-rc}"
         raise SsHipError(f"{what} failed: {kind}")
+
+
+WAV_OK, WAV_UNSUPPORTED, WAV_EMPTY, WAV_MISSING, WAV_TOO_LONG = 0, 1, 2, 3, 4
+
+
+def wav_read_rirs(paths, dst, cap: int, keep: int = -1, planar: bool = False, threads: int = 0):
+    """ss_wav_read_rirs_f32: the float32 stereo wav files `paths` -> rows of the HOST float32 numpy array `dst`
+    ([n, cap, 2] wav-interleaved, or [n, 2, cap] with planar=True; C-contiguous, typically the numpy view of a pinned
+    torch tensor).  -> (kept, frames, status) int32 arrays (include/ss_hip.h).  Host-only: works without a GPU."""
+    import numpy as np
+    n = len(paths)
+    assert dst.dtype == np.float32 and dst.flags.c_contiguous and dst.shape[0] >= n and dst[0].size == 2 * cap
+    kept, frames, status = (np.zeros((n,), np.int32) for _ in range(3))
+    if n == 0:
+        return kept, frames, status
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    if threads <= 0:
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    check(load().ss_wav_read_rirs_f32(ctypes.cast(arr, ctypes.c_void_p), n, dst.ctypes.data, 2 * cap, cap, keep, int(planar),
+                                      kept.ctypes.data, frames.ctypes.data, status.ctypes.data, threads), "ss_wav_read_rirs_f32")
+    return kept, frames, status

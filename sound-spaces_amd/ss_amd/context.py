@@ -298,7 +298,7 @@ class AudioContext:
 
     # ---- request records of a multi-process vector env (ss_amd/deferred.py) ------------------------------------------
     @staticmethod
-    def request_tables(sound_keys, sound_ids, table_keys, table_ids, pair_keys, pair_slots, stale=None):
+    def request_tables(sound_keys, sound_ids, table_keys, table_ids, pair_keys, pair_slots, stale=None, last_used=None):
         """The sorted lookup tables of ``ss_ctx_observe_requests`` as its C struct (int64 numpy arrays, borrowed: the
         returned dict keeps them alive; rebuild it whenever one of them is replaced)."""
         arrs = [np.ascontiguousarray(a, np.int64) for a in (sound_keys, sound_ids, table_keys, table_ids, pair_keys, pair_slots)]
@@ -309,7 +309,11 @@ class AudioContext:
         if stale is not None:
             assert stale.dtype in (np.bool_, np.uint8) and stale.flags.c_contiguous
             t.stale, t.n_slots = stale.ctypes.data, int(stale.shape[0])
-        return dict(t=t, ref=ctypes.byref(t), keep=(arrs, stale))
+        if last_used is not None:                             # the store's LRU clock: last_used[slot] = t.tick per used slot
+            assert last_used.dtype == np.int64 and last_used.flags.c_contiguous
+            assert stale is None or stale.shape[0] == last_used.shape[0]
+            t.last_used, t.n_slots = last_used.ctypes.data, int(last_used.shape[0])
+        return dict(t=t, ref=ctypes.byref(t), keep=(arrs, stale, last_used))
 
     def observe_requests(self, recs: bytes, n: int, tables, spectrogram_ptr, audiogoal_ptr, stream: int, miss) -> int:
         """One step from the concatenated request records (n x SS_REQ_WORDS int64, as bytes): lookups, planning and the

@@ -374,21 +374,34 @@ class DeferredResolver:
                 self._tables = None
 
     def _load_pairs(self, pair_keys: np.ndarray, which: np.ndarray, reload: bool = False) -> None:
-        """RIR files of the composite keys at positions `which` -> store slots -> the resident-pair arrays (the slow,
-        first-visit side of the column path: one wav read + one H2D copy per new pose, simulator.py:615-618)"""
+        """RIR files of the composite keys at positions `which` -> store slots -> the resident-pair arrays (the
+        first-visit side of the column path, simulator.py:615-618).  With the stock wav reader all new poses of the step are
+        read by the library's native reader in one call (``RirStore.load_files``: plain threads, one pinned block, one H2D
+        copy) and enter the sorted arrays with ONE merge; a custom reader keeps the file-by-file walk."""
         store = self.engine.store
-        for i in which:
-            k = int(pair_keys[i])
-            t, r, s_ = k >> 40, (k >> 20) & 0xFFFFF, k & 0xFFFFF
-            path = os.path.join(self._table_dirs[t], "{}_{}.wav".format(r, s_))
-            slot = store.slot(("ix", k), lambda path=path: self.rir_reader(path))     # (reloads rows that were clipped)
-            pos = int(np.searchsorted(self._pair_keys, k))
-            if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == k:
-                self._pair_slots[pos] = slot
-            else:
-                self._pair_keys = np.insert(self._pair_keys, pos, k)
-                self._pair_slots = np.insert(self._pair_slots, pos, slot)
-            self._tables = None
+        ks = np.unique(np.asarray(pair_keys)[which].astype(np.int64))
+        if ks.shape[0] == 0:
+            return
+        paths = [os.path.join(self._table_dirs[int(k) >> 40], "{}_{}.wav".format((int(k) >> 20) & 0xFFFFF, int(k) & 0xFFFFF))
+                 for k in ks]
+        from .renderer import _native_wav
+        if _native_wav(self.rir_reader) and hasattr(store, "load_files") and store.group == 1:
+            import functools
+            lenient = isinstance(self.rir_reader, functools.partial) and bool(self.rir_reader.keywords.get("lenient"))
+            slots = store.load_files([("ix", int(k)) for k in ks], paths, reader=self.rir_reader, missing_ok=lenient,
+                                     new_batch=False)
+        else:
+            slots = [store.slot(("ix", int(k)), lambda path=path: self.rir_reader(path)) for k, path in zip(ks, paths)]
+        slots = np.asarray(slots, np.int64)
+        # loading may have evicted resident pairs (the hook removed them from the arrays): merge against what is there NOW
+        pos = np.searchsorted(self._pair_keys, ks)
+        have = (pos < self._pair_keys.shape[0]) & (self._pair_keys[np.minimum(pos, max(self._pair_keys.shape[0] - 1, 0))] == ks) \
+            if self._pair_keys.shape[0] else np.zeros(ks.shape, bool)
+        self._pair_slots[pos[have]] = slots[have]
+        if (~have).any():
+            self._pair_keys = np.insert(self._pair_keys, pos[~have], ks[~have])
+            self._pair_slots = np.insert(self._pair_slots, pos[~have], slots[~have])
+        self._tables = None
 
     @staticmethod
     def _records(requests: Sequence[AudioRequest]) -> Optional[bytes]:
@@ -404,7 +417,8 @@ class DeferredResolver:
             ctx = self.engine.context()
             self._tables = ctx.request_tables(self._sound_keys, self._sound_ids, self._table_keys, self._table_ids,
                                               self._pair_keys, self._pair_slots,
-                                              stale=store._clipped if store.truncate_to is None else None)
+                                              stale=store._clipped if store.truncate_to is None else None,
+                                              last_used=getattr(store, "_batch_of", None))
         return self._tables
 
     def _columns(self, requests: Sequence[AudioRequest], buf: Optional[bytes] = None):
@@ -552,7 +566,11 @@ class DeferredResolver:
         sg, ag = (spectrogram_out if want_spectrogram else None), (audiogoal_out if want_audiogoal else None)
         done = False
         if hasattr(self.engine, "observe_requests"):       # lookups + planner + launch in one C call
-            done = self.engine.observe_requests(buf, n, self._request_tables(), spectrogram_out=sg, audiogoal_out=ag) == 0
+            tables = self._request_tables()
+            if tables["t"].last_used:                      # the store's LRU clock: the C lookups stamp the rows they use
+                self.engine.store.begin_batch()
+                tables["t"].tick = self.engine.store._batch
+            done = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag) == 0
             self.native_steps += done
         if not done:                                        # something to register / load (or an engine without the C path)
             self.engine.observe_columns(self._columns(requests, buf), spectrogram_out=sg, audiogoal_out=ag)

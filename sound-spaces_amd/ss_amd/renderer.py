@@ -674,19 +674,22 @@ class RirStore:
     def _take_slot(self) -> int:
         if self._free:
             return self._free.pop()
-        victim = next(iter(self._slot_of))
-        slot = self._slot_of[victim]
-        if self._batch and self._batch_of[slot] == self._batch:     # (callers that never open a batch: no guard)
-            # the oldest entry is in use by this launch.  Entries marked through touch_slots() (the column paths never
-            # pass through slot(), so the dict order does not know they were used) are skipped: take the oldest entry
-            # that this batch has not handed out
-            for victim, slot in self._slot_of.items():
-                if self._batch_of[slot] != self._batch:
-                    break
-            else:
-                raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
-                                   "(an entry handed out for this launch would be overwritten); raise rir_slots")
+        # Victim = the entry whose slot was handed out / touched longest ago.  Recency lives in `_batch_of` (the batch of
+        # the last use: slot() and the column paths' touch_slots() both write it), NOT only in the dict order - the
+        # native record path (ss_ctx_observe_requests) looks slots up without ever passing through slot(), so with the
+        # dict order alone the store degraded to FIFO for exactly the modes that keep the most poses resident (ADVICE
+        # r4).  Ties (callers that never open a batch, or entries of one batch) fall back to the dict order: oldest first.
+        keys = list(self._slot_of)
+        slots_arr = np.fromiter(self._slot_of.values(), np.int64, len(keys))
+        last = self._batch_of[slots_arr]
+        j = int(np.argmin(last))
+        if self._batch and last[j] == self._batch:                   # (callers that never open a batch: no guard)
+            raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
+                               "(an entry handed out for this launch would be overwritten); raise rir_slots")
+        slot, victim = int(slots_arr[j]), keys[j]
         del self._slot_of[victim]
+        for g in range(self.group):                                  # a row still queued for the victim must not land later
+            self._pending.pop(slot + g, None)
         if self.on_evict is not None or self._evict_hooks:
             self._notify_evict(victim, slot)
         return slot
@@ -786,6 +789,115 @@ class RirStore:
                 torch.cuda.current_stream(self.device).synchronize()   # the pinned block dies with this scope
         for i in todo:
             out[i] = self._slot_of[keys[i]]
+        return out
+
+    # ---- float32 wav files, read natively (ss_wav_read_rirs_f32) ----------------------------------------------------------
+    _FILE_CHUNK = 256                                            # rows per staging block (two blocks: read k+1 under copy k)
+
+    def _file_stage(self, k: int):
+        """pinned [_FILE_CHUNK, cap, 2] staging block k & 1 (wav layout), free to be overwritten"""
+        if getattr(self, "_fstage", None) is None or self._fstage[0].shape[1] != self.cap:
+            pin = self.device.type == "cuda"
+            self._fstage = [torch.zeros((self._FILE_CHUNK, self.cap, 2), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
+            self._fstage_ev = [None, None]
+        if self._fstage_ev[k & 1] is not None:
+            self._fstage_ev[k & 1].synchronize()                 # the H2D copy that last read this block has run
+            self._fstage_ev[k & 1] = None
+        return self._fstage[k & 1]
+
+    def load_files(self, keys: Sequence, paths: Sequence, reader=None, missing_ok: bool = False, threads: int = 0,
+                   new_batch: bool = True) -> List[int]:
+        """Slots of many keys whose RIRs are wav FILES: `paths[i]` is the file of `keys[i]` (group == 1) or the list of its
+        `group` files (None = no such file: a zero row).  The misses are read by the library's own reader
+        (ss_wav_read_rirs_f32: RIFF header parsed in C++, the first `truncate_to` frames read() straight into a pinned
+        staging block in the file's own interleaved layout, plain threads - no scipy, no per-file arrays, no host
+        transpose, no GIL), cross PCIe as one copy per block of 256 rows and are transposed into the planar bank rows by the
+        scatter on the device.  Reference semantics (simulator.py:615-624) are kept file by file: whatever is not a plain
+        float32 stereo wav goes through `reader(path)` (default ``sim_audio.wav_rir_reader``: scipy, ValueError -> zero
+        RIR), an empty file is the zero RIR, a file that cannot be opened raises FileNotFoundError unless `missing_ok`.
+        Same LRU semantics as ``slot_many``; nothing of the store changes when a file raises.  `new_batch=False`: the loads
+        belong to the batch the caller has open (a step's pose misses: the rows that step already looked up stay protected)."""
+        from . import _lib
+        G = self.group
+        if reader is None:
+            from .sim_audio import wav_rir_reader as reader
+        out: List[int] = [-1] * len(keys)
+        first = {}
+        if new_batch:
+            self.begin_batch()
+        for i, key in enumerate(keys):
+            if key in self._slot_of:
+                plist = [paths[i]] if G == 1 else list(paths[i])
+                out[i] = self.slot(key, (lambda pl=plist: (reader(pl[0]) if G == 1 else [reader(p) if p else None for p in pl])))
+            else:
+                first.setdefault(key, i)
+        uniq = list(first.values())
+        if len(set(keys)) > self.slots // G:
+            raise ValueError(f"load_files: {len(set(keys))} distinct keys do not fit a store of {self.slots // G} entries")
+        keep = -1 if self.truncate_to is None else int(self.truncate_to)
+        per = max(1, self._FILE_CHUNK // G)
+        for c, lo in enumerate(range(0, len(uniq), per)):
+            part = uniq[lo:lo + per]
+            flat = []                                             # (row in the block, path) of the files that exist
+            for j, i in enumerate(part):
+                for g, pth in enumerate([paths[i]] if G == 1 else list(paths[i])):
+                    if pth:
+                        flat.append((j * G + g, pth))
+            n_rows = len(part) * G
+            while True:                                           # (again after the rows have grown)
+                stage = self._file_stage(c)
+                snp = stage.numpy()
+                dense = len(flat) == n_rows
+                tgt = snp if dense else np.zeros((max(len(flat), 1), self.cap, 2), np.float32)
+                kept, frames, status = _lib.wav_read_rirs([p for _, p in flat], tgt, self.cap, keep=keep, threads=threads)
+                too_long = status == _lib.WAV_TOO_LONG
+                if too_long.any():
+                    self._ensure_cap(int(self._kept_len(int(frames[too_long].max()))))
+                    continue
+                break
+            lens = np.zeros((n_rows,), np.int32)
+            full = np.zeros((n_rows,), np.int32)
+            if not dense:
+                snp[:n_rows] = 0.0
+            for f, (row, pth) in enumerate(flat):
+                st = int(status[f])
+                if st == _lib.WAV_MISSING and not missing_ok:
+                    raise FileNotFoundError(pth)
+                if st == _lib.WAV_UNSUPPORTED:                    # scipy's semantics for everything unusual
+                    r = _planar(reader(pth))
+                    n = self._kept_len(r.shape[1])
+                    if n > self.cap:
+                        raise ValueError(f"load_files: {pth}: {n} frames after an unusual header; use slot()")
+                    snp[row, :n, :] = r[:, :n].T
+                    snp[row, n:, :] = 0.0
+                    lens[row], full[row] = n, r.shape[1]
+                    continue
+                if not dense:
+                    snp[row] = tgt[f]
+                lens[row], full[row] = kept[f], frames[f]
+            slots = []
+            for j, i in enumerate(part):
+                self.misses += 1
+                sl = self._take_slot()
+                self._slot_of[keys[i]] = sl
+                self._batch_of[sl] = self._batch
+                slots += [sl + g for g in range(G)]
+            sl_np = np.asarray(slots)
+            idx = torch.as_tensor(slots, dtype=torch.long, device=self.device)
+            dev_blk = stage[:n_rows].to(self.device, non_blocking=True).permute(0, 2, 1)     # [k, cap, 2] -> [k, 2, cap]
+            self.bank.data.index_copy_(0, idx, dev_blk)
+            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                self._fstage_ev[c & 1] = ev
+            self._dev_len[sl_np] = lens
+            self.host_len[sl_np] = lens
+            self._stale[sl_np] = True
+            self._clipped[sl_np] = lens < full
+        for i, key in enumerate(keys):
+            if out[i] < 0:
+                out[i] = self._slot_of[key]
         return out
 
 
@@ -947,10 +1059,22 @@ def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 
     if limit is not None:
         paths = paths[:limit]
     batch = max(1, min(batch, store.slots))
+    native = _native_wav(reader) and hasattr(store, "load_files")
     for lo in range(0, len(paths), batch):                      # threaded reads, one H2D copy per batch
         part = paths[lo:lo + batch]
-        store.slot_many(part, [(lambda path=path: reader(path)) for path in part], workers=workers)
+        if native:                                              # the library's own reader (ss_wav_read_rirs_f32): no scipy
+            store.load_files(part, part, reader=reader, threads=workers)
+        else:
+            store.slot_many(part, [(lambda path=path: reader(path)) for path in part], workers=workers)
     return len(paths)
+
+
+def _native_wav(reader) -> bool:
+    """`reader` is the stock wav reader (sim_audio.wav_rir_reader, possibly through functools.partial(lenient=...)): its
+    files can go through the library's native reader, which falls back to it for anything unusual"""
+    import functools
+    from .sim_audio import wav_rir_reader
+    return reader is wav_rir_reader or (isinstance(reader, functools.partial) and reader.func is wav_rir_reader)
 
 
 class AudioEngine:

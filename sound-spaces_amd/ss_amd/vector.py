@@ -241,9 +241,18 @@ def load_scene_pairs(store, index: RirIndex, scene: str, scene_rir_dir: str, rea
             return out
         return load
     chunk = max(1, store.slots // store.group // 2)
+    from .renderer import _native_wav
+    native = _native_wav(reader) and hasattr(store, "load_files")
     for lo in range(0, len(pairs), chunk):
         part = pairs[lo:lo + chunk]
-        bases = store.slot_many([(scene, p) for p in part], [group_loader(p) for p in part], workers=workers)
+        if native:                                              # the library's own reader: no scipy, no host transposes
+            files = []
+            for pair in part:
+                fl = [os.path.join(scene_rir_dir, str(az), "{}_{}.wav".format(*pair)) for az in azimuths]
+                files.append([f if os.path.exists(f) else None for f in fl] if store.group > 1 else fl[0])
+            bases = store.load_files([(scene, p) for p in part], files, reader=reader, threads=workers)
+        else:
+            bases = store.slot_many([(scene, p) for p in part], [group_loader(p) for p in part], workers=workers)
         r, s = np.array([p[0] for p in part]), np.array([p[1] for p in part])
         index.set(sid, r, s, np.asarray(bases, np.int32))
     return len(pairs)

@@ -1,0 +1,131 @@
+"""The library's native RIR-file reader (ss_wav_read_rirs_f32, csrc/ss_wavio.hpp) and ``RirStore.load_files`` against
+scipy.io.wavfile.read, the reader the reference uses on every cache miss (soundspaces/simulator.py:615-624): same samples
+for float32 stereo files, the reference's zero-RIR fallbacks for unreadable / empty files, everything unusual handed to
+the Python reader.  Host-only code: runs without a GPU (CPU store)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from ss_amd import _lib
+from ss_amd.renderer import RirStore, load_scene_rirs
+from ss_amd.sim_audio import wav_rir_reader
+
+
+@pytest.fixture(scope="module")
+def wavs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("rirs")
+    rng = np.random.default_rng(0)
+    files = {}
+    for name, L in [("a", 16000), ("ragged", 12345), ("one", 1), ("empty", 0), ("long", 40000)]:
+        p = str(d / f"{name}.wav")
+        wavfile.write(p, 16000, rng.standard_normal((L, 2)).astype(np.float32))
+        files[name] = p
+    files["i16"] = str(d / "i16.wav")
+    wavfile.write(files["i16"], 16000, (rng.standard_normal((100, 2)) * 1000).astype(np.int16))
+    files["mono"] = str(d / "mono.wav")
+    wavfile.write(files["mono"], 16000, rng.standard_normal((100,)).astype(np.float32))
+    files["junk"] = str(d / "junk.wav")
+    open(files["junk"], "wb").write(b"hello world, this is not a wav file at all")
+    files["trunc"] = str(d / "trunc.wav")
+    open(files["trunc"], "wb").write(open(files["a"], "rb").read()[:5000])
+    # a LIST chunk between fmt and data (ffmpeg writes one), odd-sized: must be skipped with its pad byte
+    raw = open(files["ragged"], "rb").read()
+    i = raw.index(b"data")
+    extra = b"LIST" + (5).to_bytes(4, "little") + b"INFOx" + b"\0"
+    body = raw[:i] + extra + raw[i:]
+    body = body[:4] + (len(body) - 8).to_bytes(4, "little") + body[8:]
+    files["list"] = str(d / "list.wav")
+    open(files["list"], "wb").write(body)
+    files["missing"] = str(d / "missing.wav")
+    return files
+
+
+def test_native_reader_equals_scipy_and_reports_what_it_does_not_read(wavs):
+    names = list(wavs)
+    paths = [wavs[n] for n in names]
+    cap = 16384
+    for planar in (False, True):
+        dst = np.full((len(paths), 2, cap) if planar else (len(paths), cap, 2), 7.0, np.float32)
+        kept, frames, status = _lib.wav_read_rirs(paths, dst, cap, keep=16000, planar=planar, threads=3)
+        st = dict(zip(names, status))
+        assert [st[n] for n in ("a", "ragged", "one", "list")] == [_lib.WAV_OK] * 4
+        assert st["empty"] == _lib.WAV_EMPTY and st["missing"] == _lib.WAV_MISSING
+        assert st["i16"] == st["mono"] == st["junk"] == st["trunc"] == _lib.WAV_UNSUPPORTED
+        assert st["long"] == _lib.WAV_OK and dict(zip(names, kept))["long"] == 16000 and dict(zip(names, frames))["long"] == 40000
+        for i, n in enumerate(names):
+            row = dst[i].T if planar else dst[i]
+            if status[i] == _lib.WAV_OK:
+                _, ref = wavfile.read(paths[i])
+                assert np.array_equal(row[:kept[i]], ref[:kept[i]]) and not row[kept[i]:].any()
+            else:
+                assert not row.any() and kept[i] == 0
+    # a row too short for what is to be kept: reported, nothing read
+    dst = np.zeros((1, 1000, 2), np.float32)
+    kept, frames, status = _lib.wav_read_rirs([wavs["a"]], dst, 1000, keep=-1)
+    assert status[0] == _lib.WAV_TOO_LONG and frames[0] == 16000 and not dst.any()
+
+
+@pytest.mark.parametrize("truncate_to", [16000, None])
+def test_store_load_files_equals_the_python_reader_path(wavs, truncate_to):
+    names = ["a", "ragged", "one", "empty", "long", "i16", "junk", "list", "a"]
+    paths = [wavs[n] for n in names]
+    s1 = RirStore(16, 16000, "cpu", truncate_to=truncate_to)
+    s2 = RirStore(16, 16000, "cpu", truncate_to=truncate_to)
+    got = s1.load_files(paths, paths)
+    ref = s2.slot_many(paths, [(lambda p=p: wav_rir_reader(p)) for p in paths], workers=1)
+    assert got[0] == got[-1] and len(set(got)) == len(names) - 1
+    assert s1.cap == s2.cap and (truncate_to is not None or s1.cap >= 40000)
+    for a, b in zip(got, ref):
+        assert np.array_equal(s1.bank.data[a].numpy(), s2.bank.data[b].numpy())
+        assert s1.host_len[a] == s2.host_len[b] and int(s1.bank.lengths[a]) == int(s2.bank.lengths[b])
+        assert s1._clipped[a] == s2._clipped[b]
+    # integer PCM keeps scipy's values (the reference would convolve them as they are), junk is the zero RIR
+    i16 = got[names.index("i16")]
+    assert s1.host_len[i16] == 100 and abs(s1.bank.data[i16]).max() > 10
+    assert s1.host_len[got[names.index("junk")]] == 0 and s1.host_len[got[names.index("empty")]] == 0
+    # hits the second time
+    h = s1.hits
+    assert s1.load_files(paths, paths) == got and s1.hits == h + len(paths)
+    with pytest.raises(FileNotFoundError):
+        s1.load_files([wavs["missing"]], [wavs["missing"]])
+    assert wavs["missing"] not in s1._slot_of
+    sl = s1.load_files([wavs["missing"]], [wavs["missing"]], missing_ok=True)[0]
+    assert s1.host_len[sl] == 0 and not s1.bank.data[sl].any()
+
+
+def test_store_load_files_azimuth_groups_and_eviction(wavs):
+    s1 = RirStore(8, 16000, "cpu", truncate_to=16000, group=4)
+    files = [[wavs["a"], None, wavs["ragged"], wavs["one"]], [wavs["ragged"], wavs["a"], wavs["a"], wavs["empty"]]]
+    base = s1.load_files(["p0", "p1"], files)
+    for b, fl in zip(base, files):
+        for g, f in enumerate(fl):
+            ref = wav_rir_reader(f) if f else None
+            n = 0 if ref is None else min(16000, ref.shape[0])
+            assert s1.host_len[b + g] == n
+            if n:
+                assert np.array_equal(s1.bank.data[b + g].numpy()[:, :n], ref[:n].T)
+            assert not s1.bank.data[b + g].numpy()[:, n:].any()
+    evicted = []
+    s1.on_evict = lambda key, slot: evicted.append(key)
+    b2 = s1.load_files(["p2"], [[wavs["a"]] * 4])[0]
+    assert evicted == ["p0"] and b2 == base[0]                  # LRU: p0 is the oldest entry
+    with pytest.raises(ValueError):
+        s1.load_files(["x", "y", "z"], [[wavs["a"]] * 4] * 3)
+
+
+def test_load_scene_rirs_takes_the_native_reader_for_the_stock_reader(wavs, tmp_path):
+    rng = np.random.default_rng(1)
+    for az in (0, 90):
+        os.makedirs(tmp_path / str(az))
+        for r in range(3):
+            wavfile.write(str(tmp_path / str(az) / f"{r}_0.wav"), 16000, rng.standard_normal((500 + r, 2)).astype(np.float32))
+    s1 = RirStore(8, 16000, "cpu", truncate_to=16000)
+    n = load_scene_rirs(s1, str(tmp_path), wav_rir_reader, azimuths=(0, 90))
+    assert n == 6 and s1.misses == 6
+    for az in (0, 90):
+        for r in range(3):
+            p = os.path.join(str(tmp_path), str(az), f"{r}_0.wav")
+            sl = s1.slot(p, lambda: pytest.fail("resident"))
+            assert np.array_equal(s1.bank.data[sl].numpy()[:, :500 + r], wav_rir_reader(p).T)
