@@ -367,6 +367,12 @@ int ss_ctx_stats(ss_ctx* ctx, long long* out8);
  * status are zero-filled.  Returns 0 / SS_EINVAL. */
 int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep, int planar,
                          int* kept_out, int* frames_out, int* status_out, int n_threads);
+/* n HOST arrays -> n rows of a (pinned) staging block: row i = src[i][0 .. n_floats[i]) followed by zeros up to row_floats,
+ * rows row_stride floats apart, on up to n_threads plain threads.  The live RIRs of a SoundSpaces 2.0 step (one new RIR per
+ * env and step from the ray tracer, soundspaces/continuous_simulator.py:419) travel to the bank this way: one block, one
+ * H2D copy.  Returns 0 / SS_EINVAL. */
+int ss_rows_gather_f32(const float* const* src, const int* n_floats, int n, float* dst, long long row_stride, int row_floats,
+                       int n_threads);
 
 #ifdef __cplusplus
 }

@@ -1466,3 +1466,11 @@ extern "C" int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst,
     sswav::read_many(paths, n, dst, row_stride, cap, keep, planar != 0, kept_out, frames_out, status_out, n_threads);
     return 0;
 }
+
+extern "C" int ss_rows_gather_f32(const float* const* src, const int* n_floats, int n, float* dst, long long row_stride,
+                                  int row_floats, int n_threads) {
+    if (n == 0) return 0;
+    if (!src || !n_floats || !dst || n < 0 || row_floats < 0 || row_stride < row_floats) return SS_EINVAL;
+    sswav::gather_rows(src, n_floats, n, dst, row_stride, row_floats, n_threads);
+    return 0;
+}

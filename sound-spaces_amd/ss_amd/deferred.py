@@ -32,6 +32,20 @@ import numpy as np
 from .renderer import UnitRequest
 
 
+import functools
+import operator
+
+_LIVE_GET = operator.attrgetter("live_rir", "last_rir")
+
+
+def _n_none(items) -> int:
+    """how many entries ARE None (identity: the entries may be arrays, whose == is element-wise)"""
+    return sum(map(_IS_NONE, items))
+
+
+_IS_NONE = functools.partial(operator.is_, None)
+
+
 @dataclass
 class AudioRequest:
     """Picklable stand-in for an audio observation (travels through habitat.VectorEnv's pipe)."""
@@ -59,6 +73,9 @@ class AudioRequest:
     # N requests of a vector step into unit COLUMNS with a dozen numpy operations instead of a Python walk (see
     # DeferredResolver._columns).  Names travel as CRC-32 keys; the strings above stay for first-use registration.
     rec: Optional[bytes] = None
+    # numbered live RIRs (SS2.0 workers): the scalar facts of the request as LREC_N packed int64 words, so that the trainer
+    # reads a step's N requests with one bytes.join + frombuffer and touches the request objects only for their arrays
+    lrec: Optional[bytes] = None
     # pose_cache mode (attach_deferred(..., pose_cache=True)): the reference's per-pose memo (simulator.py:678-701) kept by
     # the worker's own simulator dicts; a hit asks the trainer for the row it stored when this pose was first rendered
     cache_key: Optional[tuple] = None             # (source, receiver, azimuth)
@@ -72,6 +89,11 @@ REC_N = 10                                    # = SS_REQ_WORDS of include/ss_hip
 _SILENT_REC = np.zeros((REC_N,), np.int64)
 _SILENT_REC[REC_SILENT] = 1
 _SILENT_REC[REC_DIS_SOUND] = -1
+
+
+# layout of AudioRequest.lrec (int64 words); LREC_LAST_WRAP = -1: no previous RIR (first step of an episode, CROSSFADE off)
+LREC_SILENT, LREC_SOUND, LREC_T0, LREC_ENV, LREC_SEQ, LREC_LAST_SEQ, LREC_WRAP, LREC_LAST_WRAP = range(8)
+LREC_N = 8
 
 
 def _silent_rec(env: int) -> bytes:
@@ -146,7 +168,12 @@ class DeferredSimAudio:
         if sim._episode_step_count > sim._duration:                                  # simulator.py:610 / cont. :415
             rec = _SILENT_REC.copy()
             rec[REC_ENV] = self.env
-            return AudioRequest(env=self.env, kind=kind, silent=True, rec=rec.tobytes())
+            lrec = None
+            if self.continuous:
+                lrec = np.zeros((LREC_N,), np.int64)
+                lrec[LREC_SILENT], lrec[LREC_ENV], lrec[LREC_LAST_WRAP] = 1, self.env, -1
+                lrec = lrec.tobytes()
+            return AudioRequest(env=self.env, kind=kind, silent=True, rec=rec.tobytes(), lrec=lrec)
         name, clip = sim._current_sound, sim.current_source_sound
         req = AudioRequest(env=self.env, kind=kind, sound=name, clip=self._clip_once(name, clip))
         if self.continuous:
@@ -166,6 +193,11 @@ class DeferredSimAudio:
                 if prev is not None and same_rir(prev, last):                        # the array of the previous request: the
                     req.last_seq = self._live_seq - 1                                # trainer holds it under that number
             self._live_prev = req.live_rir
+            lrec = np.zeros((LREC_N,), np.int64)
+            lrec[LREC_SOUND], lrec[LREC_T0], lrec[LREC_ENV] = self._key(name), req.t0, self.env
+            lrec[LREC_SEQ], lrec[LREC_LAST_SEQ], lrec[LREC_WRAP] = req.live_seq, req.last_seq, bool(req.wrap)
+            lrec[LREC_LAST_WRAP] = -1 if req.last_rir is None else int(bool(req.last_wrap))
+            req.lrec = lrec.tobytes()
             return req
         if clip.shape[0] != sr:                                                      # simulator.py:634-635
             req.t0 = sim._audio_index * sr
@@ -225,7 +257,12 @@ class DeferredResolver:
         self.rir_reader = rir_reader or wav_rir_reader
         self._clips: Dict[str, np.ndarray] = {}
         self._live: Dict[int, list] = {}          # env -> [held arrays, slots, turn] (see HipContinuousSimAudio)
-        self._live_seq: Dict[int, list] = {}      # env -> [held sequence numbers, slots, turn] (numbered live RIRs)
+        # numbered live RIRs (SS2.0 workers): env e keeps two bank rows, RIR number q lives in row (q & 1) - the current RIR
+        # and the previous step's one (CROSSFADE) never share a row, and a step of N envs is N row writes at known places
+        self._lv_slots = np.full((0, 2), -1, np.int64)     # [env, parity] -> store slot (-1: not allocated)
+        self._lv_seqs = np.zeros((0, 2), np.int64)         # [env, parity] -> number of the RIR the row holds (0: none)
+        self._sid: Dict[str, int] = {}                      # sound name -> source id (live path)
+        self.live_steps = 0
         # column path (engines that own a C++ context: ss_amd.renderer.AudioEngine on a GPU).  CRC keys -> ids through
         # sorted arrays (np.searchsorted), RIR slots through dense (table, receiver, source) tables
         store = getattr(engine, "store", None)
@@ -263,27 +300,27 @@ class DeferredResolver:
             raise KeyError(f"deferred audio: the clip of sound {name!r} never arrived (worker restarted?)")
         return self.engine.source_id(name, self._clips[name])
 
-    def _live_slot_seq(self, env: int, seq: int, rir: Optional[np.ndarray], avoid: int = -1) -> int:
-        """Bank slot of env's live RIR number `seq` (workers that number their RIRs): no content compares.  rir = None: the
-        row must still be held (it was this env's `live_rir` one request ago)."""
-        st = self._live_seq.setdefault(env, [[0, 0], [-1, -1], [0]])
-        seqs, slots, turn = st
+    def _lv_rows(self, env_max: int) -> None:
+        if env_max >= self._lv_slots.shape[0]:
+            grow = max(env_max + 1, 2 * self._lv_slots.shape[0], 64)
+            sl, sq = np.full((grow, 2), -1, np.int64), np.zeros((grow, 2), np.int64)
+            sl[:self._lv_slots.shape[0]], sq[:self._lv_seqs.shape[0]] = self._lv_slots, self._lv_seqs
+            self._lv_slots, self._lv_seqs = sl, sq
 
+    def _live_slot_seq(self, env: int, seq: int, rir: Optional[np.ndarray], par: Optional[int] = None) -> int:
+        """Bank slot of env's live RIR number `seq` (workers that number their RIRs): row (seq & 1) of the env's two, no
+        content compares.  rir = None: the row must still be held (it was this env's `live_rir` one request ago).  `par`:
+        the row to use for an un-numbered companion (a `last_rir` sent in full: the row the current RIR does not use)."""
+        self._lv_rows(env)
+        k = (seq & 1) if par is None else par
+        held = self._lv_seqs[env, k] == seq and self._lv_slots[env, k] >= 0
+        if not held and rir is None:
+            raise KeyError(f"deferred audio: env {env}'s live RIR {seq} is no longer in the store (rir_slots < 2 per env?)")
         def gone():
             raise KeyError(f"deferred audio: env {env}'s live RIR {seq} is no longer in the store (rir_slots < 2 per env?)")
-        for k in (0, 1):
-            if seqs[k] == seq:
-                slots[k] = self.engine.rir_slot(("live", env, k), (lambda: rir) if rir is not None else gone, refresh=False)
-                return slots[k]
-        if rir is None:
-            gone()
-        k = turn[0]
-        if slots[k] == avoid and avoid >= 0:
-            k ^= 1
-        turn[0] = k ^ 1
-        seqs[k] = seq
-        slots[k] = self.engine.rir_slot(("live", env, k), lambda: rir, refresh=True)
-        return slots[k]
+        slot = self.engine.rir_slot(("live", env, k), (lambda: rir) if rir is not None else gone, refresh=not held)
+        self._lv_slots[env, k], self._lv_seqs[env, k] = slot, seq
+        return slot
 
     def _live_slot(self, env: int, rir: np.ndarray, avoid: int = -1) -> int:
         from .sim_audio import same_rir
@@ -315,9 +352,9 @@ class DeferredResolver:
             if q.live_rir is not None and q.live_seq > 0:                 # numbered live RIRs (SS2.0 workers of this version)
                 u.rir = self._live_slot_seq(q.env, q.live_seq, q.live_rir)
                 if q.last_seq > 0:
-                    u.last_rir = self._live_slot_seq(q.env, q.last_seq, q.last_rir, avoid=u.rir)
+                    u.last_rir = self._live_slot_seq(q.env, q.last_seq, q.last_rir)
                 elif q.last_rir is not None:                                  # not the previous request's array: sent in full
-                    u.last_rir = self._live_slot_seq(q.env, -q.live_seq, q.last_rir, avoid=u.rir)
+                    u.last_rir = self._live_slot_seq(q.env, -q.live_seq, q.last_rir, par=(q.live_seq & 1) ^ 1)
             elif q.live_rir is not None:
                 u.rir = self._live_slot(q.env, q.live_rir)
                 if q.last_rir is not None:
@@ -366,6 +403,10 @@ class DeferredResolver:
         return (table << 40) | (recv << 20) | src
 
     def _evicted(self, key, slot) -> None:
+        if isinstance(key, tuple) and len(key) == 3 and key[0] == "live":          # a live row lost its slot
+            if key[1] < self._lv_slots.shape[0]:
+                self._lv_slots[key[1], key[2]], self._lv_seqs[key[1], key[2]] = -1, 0
+            return
         if isinstance(key, tuple) and len(key) == 2 and key[0] == "ix":
             pos = int(np.searchsorted(self._pair_keys, key[1]))
             if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == key[1]:
@@ -402,6 +443,84 @@ class DeferredResolver:
             self._pair_keys = np.insert(self._pair_keys, pos[~have], ks[~have])
             self._pair_slots = np.insert(self._pair_slots, pos[~have], slots[~have])
         self._tables = None
+
+    def _live_columns(self, requests: Sequence[AudioRequest]):
+        """A step whose requests carry NUMBERED live RIRs (SoundSpaces 2.0 workers: every env a new RIR every step,
+        continuous_simulator.py:370-392, 413-426) -> unit columns
+        for ``engine.observe_columns``, or None when the step needs the per-request walk (RIR files among the requests, a
+        distractor, un-numbered RIRs).  Per request only one ``attrgetter`` call; row (seq & 1) of env e holds RIR number
+        seq, so the N new RIRs of the step go to N known rows through ONE gathered upload (``RirStore.upload_rows``) and the
+        previous step's RIR (CROSSFADE, :422-424) is found in the env's other row without comparing contents."""
+        n = len(requests)
+        try:
+            buf = b"".join([q.lrec for q in requests])
+        except TypeError:                                    # a request without the record (RIR files, un-numbered RIRs)
+            return None
+        recs = np.frombuffer(buf, np.int64).reshape(n, LREC_N)
+        live = recs[:, LREC_SILENT] == 0
+        n_silent = n - int(np.count_nonzero(live))
+        if n_silent == n:
+            return None
+        seq, lseq, env, t0 = recs[:, LREC_SEQ], recs[:, LREC_LAST_SEQ], recs[:, LREC_ENV], recs[:, LREC_T0]
+        rir, last = zip(*map(_LIVE_GET, requests))           # the only per-request attribute reads: the arrays themselves
+        store = self.engine.store
+        # sounds by CRC key (a clip travels with the first request that names it)
+        sids = self._lookup(self._sound_keys, self._sound_ids, recs[:, LREC_SOUND])
+        if (sids[live] < 0).any():
+            for i in np.flatnonzero(live & (sids < 0)):
+                q = requests[i]
+                if name_key(q.sound) not in self._key_names:
+                    self._learn_sound(q.sound, q.clip)
+            sids = self._lookup(self._sound_keys, self._sound_ids, recs[:, LREC_SOUND])
+            if (sids[live] < 0).any():
+                raise KeyError("deferred audio: a live request names a sound that could not be registered")
+        store.begin_batch()
+        self._lv_rows(int(env.max()))
+        par = seq & 1
+        li = np.flatnonzero(live) if n_silent else np.arange(n)
+        el, pl = env[li], par[li]
+        unalloc = (self._lv_slots[el, 0] < 0) | (self._lv_slots[el, 1] < 0)
+        if unalloc.any():
+            for e in np.unique(el[unalloc]):                     # an env's first step: its two rows
+                for k in (0, 1):
+                    if self._lv_slots[e, k] < 0:
+                        self._lv_slots[e, k] = store.slot(("live", int(e), k), lambda: None, refresh=True)
+                        self._lv_seqs[e, k] = 0
+        cur = self._lv_slots[el, pl]
+        new_cur = np.flatnonzero(self._lv_seqs[el, pl] != seq[li])
+        up_slots = cur[new_cur].tolist()
+        up_rows = [rir[j] for j in li[new_cur].tolist()]
+        self._lv_seqs[el, pl] = seq[li]
+        # the previous step's RIR: by number in the env's other row; an array that is NOT the previous request's (the worker
+        # says so with last_seq = 0) is uploaded there under a number nothing else uses
+        has_last = live & (recs[:, LREC_LAST_WRAP] >= 0)
+        last_slot = None
+        if has_last.any():
+            hi = np.flatnonzero(has_last)
+            eh, ph = env[hi], par[hi] ^ 1
+            want = np.where(lseq[hi] > 0, lseq[hi], -seq[hi])
+            stale = np.flatnonzero(self._lv_seqs[eh, ph] != want)
+            last_slot = np.full((n,), -1, np.int64)
+            last_slot[hi] = self._lv_slots[eh, ph]
+            for j in hi[stale].tolist():
+                up_slots.append(int(last_slot[j]))
+                up_rows.append(np.ascontiguousarray(last[j], dtype=np.float32))
+            self._lv_seqs[eh, ph] = want
+            store.touch_slots(np.concatenate([cur, last_slot[hi]]))
+        else:
+            store.touch_slots(cur)
+        if up_slots:
+            store.upload_rows(up_slots, up_rows)
+        if n_silent:
+            rir_col = np.full((n,), -1, np.int64)
+            rir_col[li] = cur
+        else:
+            rir_col = cur
+        cols = dict(sound=np.where(live, sids, 0), t0=np.where(live, t0, 0), rir=rir_col, wrap=recs[:, LREC_WRAP].astype(np.uint8))
+        if last_slot is not None:
+            cols["last_rir"] = last_slot
+            cols["last_wrap"] = np.maximum(recs[:, LREC_LAST_WRAP], 0).astype(np.uint8)
+        return cols
 
     @staticmethod
     def _records(requests: Sequence[AudioRequest]) -> Optional[bytes]:
@@ -546,10 +665,32 @@ class DeferredResolver:
         if buf is not None:
             return self.resolve_records(buf, len(requests), requests, want_audiogoal, want_spectrogram, spectrogram_out,
                                         audiogoal_out)
+        if self.columns_ok:                                  # numbered live RIRs (SoundSpaces 2.0 workers): columns, no walk
+            cols = self._live_columns(requests)
+            if cols is not None:
+                return self._observe_columns(cols, len(requests), want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
         self.walk_steps += 1
         return self.engine.observe(self.units(requests), want_audiogoal=want_audiogoal or audiogoal_out is not None,
                                    want_spectrogram=want_spectrogram, spectrogram_out=spectrogram_out,
                                    audiogoal_out=audiogoal_out)
+
+    def _observe_columns(self, cols, n, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out):
+        import torch
+        r = self.engine.renderer
+        want_audiogoal = want_audiogoal or audiogoal_out is not None
+        if want_spectrogram and spectrogram_out is None:
+            spectrogram_out = torch.empty((n,) + tuple(r.spectrogram_shape), dtype=torch.float32, device=r.device)
+        if want_audiogoal and audiogoal_out is None:
+            audiogoal_out = torch.empty((n, 2, r.out_len), dtype=torch.float32, device=r.device)
+        self.engine.observe_columns(cols, spectrogram_out=spectrogram_out if want_spectrogram else None,
+                                    audiogoal_out=audiogoal_out if want_audiogoal else None)
+        self.live_steps += 1
+        out = {}
+        if want_spectrogram:
+            out["spectrogram"] = spectrogram_out
+        if want_audiogoal:
+            out["audiogoal"] = audiogoal_out
+        return out
 
     def resolve_records(self, buf: bytes, n: int, requests: Optional[Sequence[AudioRequest]] = None,
                         want_audiogoal: bool = False, want_spectrogram: bool = True, spectrogram_out=None, audiogoal_out=None):

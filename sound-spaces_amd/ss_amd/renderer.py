@@ -653,6 +653,57 @@ class RirStore:
             self._flush_ev.record()
         return len(slots)
 
+    def upload_rows(self, slots: Sequence[int], rows: Sequence[np.ndarray], threads: int = 4) -> None:
+        """rows[i] (float32, wav layout [L, 2], C-contiguous: what the ray tracer's output transposes to) -> bank row
+        slots[i], NOW: the rows are gathered into one pinned block by the library (ss_rows_gather_f32: plain threads, no
+        per-row numpy call), cross PCIe as one copy and are transposed into the planar rows by the scatter on the device.
+        The vectorised form of ``slot(key, loader, refresh=True)`` + ``flush_uploads()`` for callers that own their slots (the
+        live RIRs of a SoundSpaces 2.0 step: ``DeferredResolver``); rows in any other layout take ``_upload``."""
+        from . import _lib
+        import ctypes
+        k = len(slots)
+        if k == 0:
+            return
+        ok = all(r.ndim == 2 and r.shape[1] == 2 and r.dtype == np.float32 and r.flags.c_contiguous for r in rows)
+        if not ok:
+            for sl, r in zip(slots, rows):
+                self._upload(int(sl), r)
+            return
+        full = np.fromiter((r.shape[0] for r in rows), np.int64, k)
+        lens = full if self.truncate_to is None else np.minimum(full, self.truncate_to)
+        self._ensure_cap(int(lens.max()))
+        if self._pending:
+            for sl in slots:
+                self._pending.pop(int(sl), None)
+        pin = self.device.type == "cuda"
+        if pin and self._flush_ev is not None:
+            self._flush_ev.synchronize()                       # the copy that last read the staging block has run
+        blk = self._flush_stage_wav
+        if blk is None or blk.shape[0] < k or tuple(blk.shape[1:]) != (self.cap, 2):
+            blk = self._flush_stage_wav = torch.zeros((max(k, 64), self.cap, 2), dtype=torch.float32, pin_memory=pin)
+        ptrs = (ctypes.c_void_p * k)(*[r.__array_interface__["data"][0] for r in rows])
+        nfl = (2 * lens).astype(np.int32)
+        _lib.check(_lib.load().ss_rows_gather_f32(ctypes.cast(ptrs, ctypes.c_void_p), nfl.ctypes.data, k, blk.data_ptr(),
+                                                  2 * self.cap, 2 * self.cap, threads), "ss_rows_gather_f32")
+        key = tuple(int(s_) for s_ in slots)
+        idx = self._idx_cache.get(key)
+        if idx is None:
+            if len(self._idx_cache) > 16:
+                self._idx_cache.clear()
+            idx = self._idx_cache[key] = torch.as_tensor(key, dtype=torch.long, device=self.device)
+        self.bank.data.index_copy_(0, idx, blk[:k].to(self.device, non_blocking=True).permute(0, 2, 1))
+        sl_np = np.asarray(key)
+        lens32 = lens.astype(np.int32)
+        if not np.array_equal(self._dev_len[sl_np], lens32):
+            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens32).to(self.device))
+            self._dev_len[sl_np] = lens32
+        if pin:
+            self._flush_ev = torch.cuda.Event()
+            self._flush_ev.record()
+        self.host_len[sl_np] = lens32
+        self._clipped[sl_np] = lens < full
+        self._stale[sl_np] = True
+
     def sync_spectra(self) -> int:
         """spectral stores: transform the rows loaded since the last call (contiguous runs, one ss_rir_spectra_f32 each;
         synchronous - this is bank-load work, steady-state steps find nothing to do).  Returns the rows transformed."""

@@ -220,11 +220,12 @@ class OracleColumnEngine(OracleEngine):
     ``observe_columns``), so that DeferredResolver's column path - CRC keys, resident-pair arrays, eviction hook, clipped-row
     reloads - runs without a GPU; the arithmetic is the oracle's."""
 
-    def __init__(self, sr, slots=64):
-        super().__init__(sr)
+    def __init__(self, sr, slots=64, **kw):
+        super().__init__(sr, **kw)
         from ss_amd.renderer import RirStore, UnitRequest
         self._unit = UnitRequest
-        self.store = RirStore(slots, sr, "cpu", truncate_to=sr, max_cap=1 << 17)
+        self.store = RirStore(slots, sr, "cpu", truncate_to=None if self.wrap else sr, max_cap=1 << 17)
+        self.store.defer_uploads = True                    # as AudioEngine: single rows queue up until the launch
         self.renderer = NS(spectrogram_shape=O.spectrogram_shape(sr), device=torch.device("cpu"), out_len=sr, sr=sr)
         self.column_calls = 0
 
@@ -239,6 +240,7 @@ class OracleColumnEngine(OracleEngine):
 
     def observe_columns(self, cols, spectrogram_out=None, audiogoal_out=None):
         self.column_calls += 1
+        self.store.flush_uploads()                         # (AudioEngine: _sync_context_bank -> sync_spectra -> flush)
         n = len(cols["sound"])
         units = []
         self.rirs = {}
@@ -251,6 +253,11 @@ class OracleColumnEngine(OracleEngine):
             if "dis_rir" in cols and cols["dis_rir"][i] >= 0:
                 u.dis_sound, u.dis_rir = int(cols["dis_sound"][i]), int(cols["dis_rir"][i])
                 self.rirs[u.dis_rir] = self._row(u.dis_rir)
+            if "wrap" in cols:
+                u.wrap = bool(cols["wrap"][i])
+            if "last_rir" in cols and cols["last_rir"][i] >= 0:
+                u.last_rir, u.last_wrap = int(cols["last_rir"][i]), bool(cols["last_wrap"][i])
+                self.rirs[u.last_rir] = self._row(u.last_rir)
             units.append(u)
         self.observe(units, want_audiogoal=audiogoal_out is not None, want_spectrogram=spectrogram_out is not None,
                      spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)

@@ -229,3 +229,44 @@ def test_two_resolvers_over_one_store_both_hear_evictions():
     for res in (r1, r2):
         for key, slot in zip(res._pair_keys.tolist(), res._pair_slots.tolist()):
             assert eng.store._slot_of[("ix", key)] == slot
+
+
+@pytest.mark.parametrize("crossfade", [False, True])
+def test_live_rir_steps_take_the_column_path(crossfade):
+    """SoundSpaces 2.0 in deferred mode (continuous_simulator.py:370-392, 413-426; the reference's current DD-PPO launch passes
+    CONTINUOUS True, ss_baselines/av_nav/single_node.sh:14): every env sends a NEW numbered RIR every step.  The resolver
+    turns such a step into unit columns without a per-request walk - row (seq & 1) of the env's two bank rows, ONE gathered
+    upload (RirStore.upload_rows -> ss_rows_gather_f32), the previous step's RIR found by number - and the result equals
+    the reference's _compute_audiogoal (through the oracle) step for step, incl. silence, a multi-second clip and an episode
+    reset (a `_last_rir` that is NOT the previous request's array); the store holds exactly two rows per env."""
+    from fakes import FakeContinuousSim
+    rng = np.random.default_rng(4)
+    sounds = {"telephone": O.synth_sources(rng, SR, k=1)[0], "horn": O.synth_sources(rng, SR, k=1, seconds=3)[0]}
+    bank = [np.ascontiguousarray(h) for h in O.synth_rir(rng, SR, length=9000, n=8)]
+    sims = [FakeContinuousSim(SR, sounds, lambda k, o=o: bank[(k + o) % 8].astype(np.float64).tolist(), start_index=500 * o,
+                              crossfade=crossfade) for o in range(4)]
+    sims[1]._current_sound = "horn"
+    for i, s in enumerate(sims):
+        attach_deferred(s, env_rank=i, continuous=True)
+    eng = OracleColumnEngine(SR, slots=8, step_time=0.25)
+    res = DeferredResolver(eng)
+    assert res.columns_ok
+    for step in range(9):
+        if step == 5:                                          # episode reset of env 2: its _last_rir is foreign to the worker's numbering
+            sims[2]._last_rir = np.ascontiguousarray(np.transpose(bank[7])) if crossfade else None
+            sims[2]._current_sample_index = 123
+        if step == 7:
+            sims[3]._episode_step_count = sims[3]._duration + 1   # silent from here on
+        reqs = [pickle.loads(pickle.dumps(s.get_current_spectrogram_observation(None))) for s in sims]
+        out = res.resolve(reqs, want_audiogoal=True)
+        for i, s in enumerate(sims):
+            ref = s.reference_audiogoal()
+            if not np.any(ref):
+                assert not out["audiogoal"][i].numpy().any()
+            else:
+                assert O.relerr(out["audiogoal"][i].numpy(), ref) < 1e-5, (step, i)
+        for s in sims:
+            s.step()
+    assert res.live_steps == 9 and res.walk_steps == 0
+    # one upload per env and step (+ the foreign _last_rir of the reset): the previous RIR is found by its number
+    assert eng.store.misses == 8                                # two rows per env, allocated once
