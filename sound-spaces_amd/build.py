@@ -37,7 +37,9 @@ def kernel_hash():
 
 def up_to_date():
     """By content, not mtime: the snapshot that carries the prebuilt library to the GPU box does not keep timestamps."""
-    if not (os.path.exists(SO) and os.path.exists(TORCH_SO) and os.path.exists(STAMP)):
+    if not (os.path.exists(SO) and os.path.exists(STAMP)):
+        return False
+    if not os.path.exists(TORCH_SO) and not os.path.exists(TORCH_SO + ".skipped"):
         return False
     return open(STAMP).read().strip() == _source_hash()
 
@@ -56,7 +58,15 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd[:-1] + [tmp_so], cwd=CSRC)
     guard_isa(hipcc, verbose)
     os.replace(tmp_so, SO)
-    build_torch_ops(verbose)
+    try:
+        build_torch_ops(verbose)
+    except Exception as e:                                      #  a torch with another ABI / no ROCm build must not
+        # take libss_hip.so down with it: ss_amd/ops.py keeps its Python registrations of the same ops when the extension is absent
+        print(f"[ss_amd] WARNING: libss_torch_ops.so not built ({type(e).__name__}: {e}); torch.ops.ss_hip.* stay Python-registered",
+              file=sys.stderr, flush=True)
+        if os.path.exists(TORCH_SO):
+            os.remove(TORCH_SO)                                 # never pair a stale extension with a new library
+        open(TORCH_SO + ".skipped", "w").write(str(e) + "\n")   # (up_to_date(): do not retry on every import)
     with open(STAMP, "w") as f:
         f.write(_source_hash() + "\n")
     with open(KERNEL_STAMP, "w") as f:
@@ -68,11 +78,13 @@ def build_torch_ops(verbose=True):
     """libss_torch_ops.so: the TORCH_LIBRARY extension (csrc/ss_torch_ops.cpp; host C++ only, calls libss_hip.so through the
     C ABI).  Compiled with g++ against the headers / libraries of the torch that is installed HERE (the GPU box runs the
     same image); finds libss_hip.so next to itself ($ORIGIN)."""
+    import torch
     from torch.utils import cpp_extension as ce
     inc = sum((["-I", p] for p in ce.include_paths()), []) + ["-I", "/opt/rocm/include"]
     libdir = ce.library_paths()[0]
+    abi = int(bool(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True)))       # the ABI the installed torch was built with
     cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "ss_torch_ops.cpp", "-o", TORCH_SO + ".tmp",
-            "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-D_GLIBCXX_USE_CXX11_ABI=1"] + inc +
+            "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={abi}"] + inc +
            ["-L", libdir, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-L", CSRC, "-lss_hip",
             "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + libdir])
     if verbose:

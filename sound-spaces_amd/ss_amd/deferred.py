@@ -115,7 +115,9 @@ class DeferredSimAudio:
         # reference-exact mode for multi-second sounds (see FastVectorAudioObserver(pose_cache=)): SoundSpaces 1.0 without
         # a distractor only - the reference bypasses its caches otherwise (:679-681), SS2.0 has none (cont. :458-462)
         self.pose_cache = bool(pose_cache) and not continuous
-        self._epoch, self._cache_obj = 0, None
+        # cache_epoch = a number no earlier incarnation of this worker can have used (a restarted worker that
+        # started from 0 again would be served the rows its predecessor stored under the same epoch)
+        self._epoch, self._cache_obj = int.from_bytes(os.urandom(4), "little") << 20, None
         self._sent = set()                        # sounds whose clip the trainer already has
         self._keys: Dict[str, int] = {}           # name -> CRC-32 (sounds, "<rir dir>/<azimuth>" tables)
 
@@ -613,6 +615,12 @@ class DeferredResolver:
             return self._resolve_with_pose_cache(requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
         return self._resolve(requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
 
+    def pose_pool_bytes(self) -> int:
+        """HBM held by the pose pool (pose_cache workers): 13.5 KB per cached pose at 16 kHz, 141.5 KB when the audiogoal is
+        cached too; rows are freed when an env's simulator drops its caches (scene / sound change, simulator.py:395-397) and
+        the pool itself only grows - size it by (poses visited per episode) x (envs)."""
+        return int(sum(t.numel() * t.element_size() for t in self._pose_pool.values()))
+
     def _resolve_with_pose_cache(self, requests, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out):
         """pose_cache workers: misses are rendered and their rows kept in a device-side pool under (env, pose); hits are
         row copies out of it (the reference returns the array it cached at that pose, simulator.py:683-686)."""
@@ -633,6 +641,11 @@ class DeferredResolver:
                 m[0], m[1] = q.cache_epoch, {}
             if not q.cache_hit:
                 miss_rows.append(i)
+        if self._pose_pool and set(out) != set(self._pose_pool):
+            # the pool holds one row per cached pose and OUTPUT; a step that asks for another set (an AudioGoalSensor that
+            # appears after the first step) can neither be stored nor served from it
+            raise KeyError(f"pose_cache: this step's outputs {sorted(out)} differ from those the pose pool was created with "
+                           f"{sorted(self._pose_pool)}: configure the same audio sensors for every step")
         if miss_rows:
             while len(self._pose_free) < len(miss_rows):
                 new_cap = max(256, 2 * self._pose_cap)

@@ -133,6 +133,7 @@ class HipSimAudio:
         self.lazy_audiogoal = bool(lazy_audiogoal)
         self._ag_wanted = False                      # an audiogoal read has been seen: fetch both outputs per launch
         self._pending = {}                           # pose -> (spectrogram it belongs to, request) awaiting an audiogoal read
+        self._refs = []
         self._env_id = next(HipSimAudio._ids)        # stable key of this env's live RIR row (USE_RENDERED_OBSERVATIONS False)
         for name in ("_audiogoal_cache", "_spectrogram_cache"):
             if not isinstance(getattr(sim, name, None), dict):
@@ -148,16 +149,32 @@ class HipSimAudio:
         if from_file or sim.config.USE_RENDERED_OBSERVATIONS:
             path = os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle),
                                 "{}_{}.wav".format(sim._receiver_position_index, source_index))      # :615-616, :650-651
+            self._refs.append(path)
             return self.engine.rir_slot(path, lambda: self.rir_reader(path))
         # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded.  The key is a
         # counter drawn at attach time: id(sim) can be handed to another simulator once this one is collected
         rir = np.transpose(np.array(sim._sim.get_sensor_observations()["audio_sensor"]))
+        self._refs.append(rir)
         return self.engine.rir_slot(("live", self._env_id), lambda: rir, refresh=True)
+
+    def _reslot(self, req: UnitRequest, refs) -> None:
+        """A request kept for later (lazy_audiogoal) names RAW store slots: by the time it is rendered again the store may have
+        given them to other keys (LRU), or - live RIRs - this env's one row holds a later step's RIR.  Resolve its
+        RIRs again from what they WERE: the file paths / the live RIR array of the step the request was made in."""
+        def slot(ref):
+            if isinstance(ref, str):
+                return self.engine.rir_slot(ref, lambda: self.rir_reader(ref))
+            return self.engine.rir_slot(("live", self._env_id), lambda: ref, refresh=True)
+        if refs:
+            req.rir = slot(refs[0])
+        if len(refs) > 1 and req.dis_rir is not None and req.dis_rir >= 0:
+            req.dis_rir = slot(refs[1])
 
     def unit_request(self) -> UnitRequest:
         """The request _compute_audiogoal would serve right now.  Advances ``_audio_index`` exactly where the
         reference does (:634-635: multi-second sounds only, not when silent)."""
         sim, sr = self.sim, self.sr
+        self._refs = []                                  # what the request's RIR slots were resolved from (see _reslot)
         if sim._episode_step_count > sim._duration:                                                  # :610
             return UnitRequest(silent=True)
         clip = sim.current_source_sound
@@ -206,6 +223,7 @@ class HipSimAudio:
                 # (the simulator has not dropped its caches since: the spectrogram is still the cached one)
                 if hasattr(self.engine, "begin_batch"):
                     self.engine.begin_batch()
+                self._reslot(pend[1], pend[2])
                 sim._audiogoal_cache[key] = _render_to_host(self, pend[1], False)[0]
             else:
                 sim._audiogoal_cache[key] = self._compute(False)[0]
@@ -239,7 +257,7 @@ class HipSimAudio:
                 else:
                     if len(self._pending) > 4096:    # (the simulator clears its caches per episode; this map follows lazily)
                         self._pending.clear()
-                    self._pending[key] = (sg, keep[0])
+                    self._pending[key] = (sg, keep[0], list(self._refs))
             else:                                    # one fused launch fills both caches
                 ag, sg = self._compute(True)
                 sim._audiogoal_cache[key] = ag

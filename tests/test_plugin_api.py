@@ -438,3 +438,32 @@ def test_rir_store_deferred_uploads_travel_as_one_block():
     st.slot("c", lambda: rirs["d"], refresh=True)
     st.clear()
     assert st.flush_uploads() == 0                                                   # a cleared store forgets what was queued
+
+
+def test_lazy_audiogoal_re_resolves_its_rirs_when_the_waveform_is_asked_for():
+    """a request kept for a deferred audiogoal read names raw store slots.  With live RIRs
+    (USE_RENDERED_OBSERVATIONS False, simulator.py:625-626) the env's ONE live row has been overwritten by the next step's
+    RIR by then; the reference (simulator.py:683-686) returns the waveform of the step the pose was first rendered in."""
+    sim, eng, _, sounds, rirs = make()
+    back = sim_audio.attach(sim, eng, rir_reader=sim.reader, lazy_audiogoal=True)
+    rng = np.random.default_rng(11)
+    live = [np.ascontiguousarray(h) for h in O.synth_rir(rng, SR, n=3)]          # [2, L] per call, like the ray tracer
+    sim.use_live_rirs(lambda k: live[k].tolist())
+    s0 = back.get_current_spectrogram_observation()                              # pose (270, 3): rendered with live[0]
+    sim._rotation_angle = 180
+    s1 = back.get_current_spectrogram_observation()                              # pose (180, 3): live[1] overwrites the env's row
+    assert len(back._pending) == 2 and not sim._audiogoal_cache
+    sim._rotation_angle = 270                                                    # back at the first pose: its waveform
+    a0 = back.get_current_audiogoal_observation()
+    ref0 = O.compute_audiogoal(sounds["telephone.wav"], live[0].T, SR)
+    assert O.relerr(a0, ref0) < 1e-5 and O.relerr(s0, O.compute_spectrogram(ref0)) < 1e-5
+    assert sim.live_calls == 2                                                   # no third trace: the request's own RIR was kept
+    # file RIRs: the row of the pending request is evicted (another key takes its slot) before the waveform is asked for
+    sim2, eng2, _, sounds2, rirs2 = make()
+    back2 = sim_audio.attach(sim2, eng2, rir_reader=sim2.reader, lazy_audiogoal=True)
+    back2.get_current_spectrogram_observation()
+    slot = eng2.keys["rirs/replica/apartment_0/90/3_7.wav"]
+    eng2.rirs[slot] = np.zeros((SR, 2), np.float32)                              # the store gave the slot to something else ...
+    del eng2.keys["rirs/replica/apartment_0/90/3_7.wav"]                         # ... and forgot the key
+    a = back2.get_current_audiogoal_observation()
+    assert O.relerr(a, O.compute_audiogoal(sounds2["telephone.wav"], rirs2["rirs/replica/apartment_0/90/3_7.wav"], SR)) < 1e-5
