@@ -26,6 +26,14 @@ namespace ssk {
 constexpr int kFeatMaxMels = 64, kFeatMaxLen = 60;          // more bands / wider filters take the stand-alone k_logmel
 constexpr int kFeatMelTable = 3072;                         // floats: n_mels * max_len (64 x 36, 40 x 52, 32 x 64 ... fit); 12 KiB
 static_assert(kGccMaxLag <= 32, "k_features extracts lags from output slots 0, 1 and 15 only");
+constexpr int kGccResStride = kSegFrames + 1;
+// PHAT cross-spectrum V[k], k < 256, of one frame in LDS: written by lane (f, q) at k = 4 (q + 16 i) + e and its mirror
+// 256 - k (ds_write_b64: 16 contiguous lanes per group over 32 banks -> consecutive q must be consecutive slots), read
+// back at k = q + 16 j for the inverse FFT (ds_read_b64: 32 lanes = two frames over 64 banks).  The natural order with
+// posN padding was 2.1-way conflicted on the stores and 2-way on the reads; posV is free of both (tests/test_lds_banks.py).
+__host__ __device__ constexpr int posV(int k) { return (k & 3) * 68 + (k >> 2); }
+constexpr int kVStride = 272;                               // complex per frame: >= 4 * 68, = 16 mod 32
+static_assert(4 * kVStride <= kWaveScratch && posV(255) < kVStride, "the four V frames live in the wave's scratch");
 constexpr int kFeatSegComplex = kSegLen / 2;                // one ear's staged segment as c32 (2912 floats = 11 648 B)
 
 struct FeatParams {
@@ -208,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
     // frames (32 VGPRs) wait in registers while the other ear is transformed.  79.7 KiB of LDS in all: two workgroups per CU
     alignas(16) __shared__ c32 sc[kFeatSegComplex + 4 * kWaveScratch];
     __shared__ float res_mel[kFeatMaxMels * 33];            // [n_mels][16 frames][2 ears], rows padded to 33 floats (banks)
-    __shared__ float res_gcc[(2 * kGccMaxLag + 1) * kSegFrames];
+    // [lag][16 frames], rows 17 floats apart: lane (f, q) stores lag 2 q + u of frame f - at a 16-float pitch all sixteen q of a
+    // frame met in ONE bank (32 LDS cycles per store instead of 2: the largest single source of the kernel's conflict cycles)
+    __shared__ float res_gcc[(2 * kGccMaxLag + 1) * kGccResStride];
     __shared__ float res_sg[kBins4 * 8];                    // [65][4 blocks][2 ears]
     __shared__ float s_win[kNfft];
     alignas(16) __shared__ c32 s_tw512[kTw512Lds];
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
             ear_spectrum(wsc, lane, wq, s_tw512, xl, R);
             if (want_gcc) {
                 // G[k] = X_l[k] conj(X_r[k]), PHAT-weighted; V = Hermitian merge; g = 256-point inverse FFT of V (k_gccphat)
-                c32* vn = wsc + (lane >> 4) * kNatStride;
+                c32* vn = wsc + (lane >> 4) * kVStride;
                 f32x4 w01[2], w23[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -350,18 +360,18 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
                         const c32 gpc = phat(cmulc(L.Y[4 * i + e], R.Y[4 * i + e]), eps4);     // conj(G[256-k])
                         c32 gp = mk2(gpc.x, -gpc.y);
                         herm_inv(gk, gp, ww[e]);                                              // -> 2 V[k], 2 V[256-k]
-                        vn[posN(4 * b + e)] = gk;
-                        if (4 * b + e != 0) vn[posN(256 - 4 * b - e)] = gp;                   // V[256] does not exist
+                        vn[posV(4 * b + e)] = gk;
+                        if (4 * b + e != 0) vn[posV(256 - 4 * b - e)] = gp;                   // V[256] does not exist
                     }
                 }
                 if (q == 0) {                               // k = 128 pairs with itself: X[128] = conj(Z[128])
                     const c32 g128 = phat(cmulc(mk2(L.z128.x, -L.z128.y), mk2(R.z128.x, -R.z128.y)), p.gcc_eps);
-                    vn[posN(128)] = mk2(2.f * g128.x, -2.f * g128.y);                         // 2 V[128] = 2 conj(G[128])
+                    vn[posV(128)] = mk2(2.f * g128.x, -2.f * g128.y);                         // 2 V[128] = 2 conj(G[128])
                 }
                 wave_sync();
                 c32 x[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) x[j] = lds_ld(vn + q + posN(16 * j));
+                for (int j = 0; j < 16; ++j) x[j] = lds_ld(vn + posV(q) + 4 * j);            // posV(q + 16 j)
                 fft16<true>(x);
                 c32 wqi = wq;
                 SSK_OPAQUE2(wqi);
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
                     for (int u = 0; u < 2; ++u) {
                         const int tau = 2 * (q + 16 * s2) + u;                    // lag 0..511; >= 256 means tau - 512
                         const int i = tau <= p.max_lag ? tau + p.max_lag : tau >= kNfft - p.max_lag ? tau - kNfft + p.max_lag : -1;
-                        if (i >= 0) res_gcc[i * kSegFrames + fl] = inv * (u ? x[s2].y : x[s2].x);
+                        if (i >= 0) res_gcc[i * kGccResStride + fl] = inv * (u ? x[s2].y : x[s2].x);
                     }
                 }
             }
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_features(FeatParams p) {     // two 
             float* o = p.gcc + (size_t)unit * n_lags * p.n_frames + kSegFrames * g;
             for (int e = t; e < n_lags * kSegFrames; e += 256) {
                 const int i = e >> 4, c = e & 15;
-                if (c < nf) o[(size_t)i * p.n_frames + c] = res_gcc[e];
+                if (c < nf) o[(size_t)i * p.n_frames + c] = res_gcc[i * kGccResStride + c];
             }
         }
         if (want_sg) {                                      // 65 rows x 4 (block, ear-pair) float2 = 32-byte runs

@@ -79,6 +79,9 @@ inline int t4_of(int len) { return (n_frames_of(len) + ssk::kPool - 1) / ssk::kP
 // launch call it leaves them here, and loop-free launches of <= kTabUnits units then carry {index, slot} per unit in the
 // kernel arguments (ConvParams::tab).  Callers of the stateless entry points hand over device pointers only: nullptr.
 thread_local const int* g_host_desc = nullptr;
+// ... and, in its overlap mode, the number of launches it keeps in flight (its lanes): a launch that spreads its rows over
+// idle CUs (parts_log2_for) then leaves the other lanes' launches their share of the chip.  1 for everybody else.
+thread_local int g_launch_share = 1;
 
 inline bool fill_unit_tab(ssk::UnitTab<true>& ut, const int* host_desc, int n_units) {
     if (!host_desc || n_units > ssk::kTabUnits) return false;
@@ -108,8 +111,9 @@ inline bool wide_one_block_ok(int out_len, int n_valid, int flags, bool spectral
 inline int parts_log2_for(int n_rows, int n_cus) {
     static const int forced = ab_int("SS_HIP_PARTS_LOG2", -1);        // (A/B builds only: -DSS_AB)
     if (forced >= 0) return forced < 3 ? forced : 3;
+    const int cus = n_cus / (g_launch_share > 1 ? g_launch_share : 1);       // overlap mode: the lanes share the chip
     int k = 0;
-    while (k < 3 && (n_rows << (k + 1)) <= n_cus) ++k;
+    while (k < 3 && (n_rows << (k + 1)) <= cus) ++k;
     return k;
 }
 
@@ -1058,6 +1062,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     }
     static const bool no_tab = ab_flag("SS_HIP_NO_UNIT_TAB");
     g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
+    g_launch_share = c.n_lanes;
     if (!c.buckets.empty()) {
         const int nb = static_cast<int>(c.buckets.size());
         rc = spectrogram ? ss_audio_obs_buckets_f32(c.pool, c.buckets.data(), nb, c.rir_len, dd, audiogoal, spectrogram, n,
@@ -1077,6 +1082,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         rc = ss_fftconv_binaural_f32(c.pool, c.rir, c.rir_len, dd, audiogoal, n, c.rir_us, c.rir_cs, c.rir_es, c.rir_cap,
                                      c.n_valid, c.out_len, res.flags, stream);
     g_host_desc = nullptr;
+    g_launch_share = 1;
     if (rc) return fail(rc);
     // (overlap mode: a group's ticks alternate between the lanes; each lane records its half after ITS last tick)
     return close_slot();

@@ -1110,8 +1110,14 @@ __device__ __forceinline__ void fused_stft_phase(c32* lds, const ConvParams& p, 
     const int len = p.out_len;
     lds_barrier();   // all pass-1' reads of layout A are done
     c32* yl2 = reinterpret_cast<c32*>(yl) + t;            // the row as packed pairs: one ds_write_b64 per pair
+    // split rows (parts_log2 > 0): only the 2048-sample chunks this workgroup's pooled blocks read - block b reads samples
+    // [640 b - 256, 640 b + 736) - plus the chunk the centre padding mirrors (first / last part); wave-uniform tests
+    const int per_w = WIDE ? 26 : part_blocks(p.t4, p.parts_log2);
+    const int s_lo = WIDE ? 0 : kHop * kPool * (part * per_w) - kNfft / 2;
+    const int s_hi = WIDE || p.parts_log2 == 0 ? 2 * kB : kHop * kPool * (part * per_w + per_w - 1) + kHop * (kPool - 1) + kNfft / 2;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
+        if (2048 * (a + 1) <= s_lo || 2048 * a >= s_hi) continue;
         const int n = 2 * (t + 1024 * a);
         yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);   // zeros beyond n_valid
     }

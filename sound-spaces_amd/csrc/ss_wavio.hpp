@@ -15,6 +15,9 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cerrno>
 #include <cstdint>
 #include <cstring>
@@ -29,6 +32,69 @@ enum Status : int {
     kEmpty = 2,         // readable, zero frames            -> zero RIR (simulator.py:622-624)
     kMissing = 3,       // open() failed                    -> the caller raises / maps to the zero RIR (lenient)
     kTooLong = 4,       // more frames to keep than the row holds: nothing read, the caller grows its rows and retries
+};
+
+// A small persistent pool: the per-step pose misses are a handful of files, and starting threads for every call costs more
+// than reading them (tens of microseconds per thread; far more under a sandboxed kernel).  Workers are created on first
+// use and park on a condition variable; run(n, fn) calls fn(i) for i in [0, n) on up to `threads` of them plus the caller
+// and returns when all are done.  One job at a time (callers are serialised by a mutex).
+class Pool {
+public:
+    static Pool& get() { static Pool p; return p; }
+    void run(int n, int threads, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        int helpers = (threads < 1 ? 1 : threads) - 1;
+        if (helpers > n - 1) helpers = n - 1;
+        if (helpers > kMax) helpers = kMax;
+        if (helpers <= 0) { for (int i = 0; i < n; ++i) fn(i); return; }
+        std::lock_guard<std::mutex> job_lock(job_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while (static_cast<int>(workers_.size()) < helpers) workers_.emplace_back([this] { loop(); });
+            fn_ = &fn; n_ = n; next_.store(0); pending_ = helpers; wanted_ = helpers; ++epoch_;
+        }
+        cv_.notify_all();
+        for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; fn(i); }
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    static constexpr int kMax = 15;
+    Pool() = default;
+    ~Pool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && wanted_ > 0); });
+                if (stop_) return;
+                seen = epoch_;
+                --wanted_;                                   // this worker joins the job (at most `helpers` do)
+                fn = fn_; n = n_;
+            }
+            for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*fn)(i); }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_one();
+            }
+        }
+    }
+    std::mutex job_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, pending_ = 0, wanted_ = 0;
+    unsigned long long epoch_ = 0;
+    bool stop_ = false;
 };
 
 inline bool read_exact(int fd, void* buf, size_t n) {
@@ -102,24 +168,12 @@ inline int read_one(const char* path, float* dst, int cap, int keep, bool planar
 // Rows whose file did not load (status != kOk) are zero-filled, kept = 0.
 inline void read_many(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep, bool planar,
                       int* kept, int* frames, int* status, int n_threads) {
-    std::atomic<int> next{0};
-    auto work = [&] {
-        std::vector<float> scratch;
-        for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n) return;
-            float* row = dst + static_cast<size_t>(i) * static_cast<size_t>(row_stride);
-            status[i] = read_one(paths[i], row, cap, keep, planar, &kept[i], &frames[i], scratch);
-            if (status[i] != kOk) std::memset(row, 0, static_cast<size_t>(cap) * 8);
-        }
-    };
-    const int nt = n_threads < 1 ? 1 : (n_threads > n ? n : n_threads);
-    if (nt <= 1) { work(); return; }
-    std::vector<std::thread> pool;
-    pool.reserve(nt - 1);
-    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    Pool::get().run(n, n_threads, [&](int i) {
+        thread_local std::vector<float> scratch;
+        float* row = dst + static_cast<size_t>(i) * static_cast<size_t>(row_stride);
+        status[i] = read_one(paths[i], row, cap, keep, planar, &kept[i], &frames[i], scratch);
+        if (status[i] != kOk) std::memset(row, 0, static_cast<size_t>(cap) * 8);
+    });
 }
 
 // n host arrays -> n rows of a staging block: row i = src[i][0 .. n_floats[i]) followed by zeros up to row_floats.
@@ -127,24 +181,12 @@ inline void read_many(const char* const* paths, int n, float* dst, long long row
 // RIRs into ONE pinned block - these copies, off the interpreter lock and on several threads, were a fifth of that step.)
 inline void gather_rows(const float* const* src, const int* n_floats, int n, float* dst, long long row_stride, int row_floats,
                         int n_threads) {
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (;;) {
-            const int i = next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n) return;
-            float* row = dst + static_cast<size_t>(i) * static_cast<size_t>(row_stride);
-            const int k = n_floats[i] < row_floats ? n_floats[i] : row_floats;
-            if (k > 0) std::memcpy(row, src[i], static_cast<size_t>(k) * 4);
-            std::memset(row + (k > 0 ? k : 0), 0, static_cast<size_t>(row_floats - (k > 0 ? k : 0)) * 4);
-        }
-    };
-    const int nt = n_threads < 1 ? 1 : (n_threads > n ? n : n_threads);
-    if (nt <= 1) { work(); return; }
-    std::vector<std::thread> pool;
-    pool.reserve(nt - 1);
-    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    Pool::get().run(n, n_threads, [&](int i) {
+        float* row = dst + static_cast<size_t>(i) * static_cast<size_t>(row_stride);
+        const int k = n_floats[i] < row_floats ? (n_floats[i] > 0 ? n_floats[i] : 0) : row_floats;
+        if (k > 0) std::memcpy(row, src[i], static_cast<size_t>(k) * 4);
+        std::memset(row + k, 0, static_cast<size_t>(row_floats - k) * 4);
+    });
 }
 
 }  // namespace sswav

@@ -288,7 +288,7 @@ class DeferredResolver:
         self._pose_pool: Dict[str, object] = {}
         self._pose_free: List[int] = []
         self._pose_cap = 0
-        self.native_steps = 0
+        self.native_steps = self.miss_steps = 0
         if self.columns_ok:                       # every resolver over this store hears about evictions (their pair tables
             if hasattr(store, "add_evict_hook"):  # name store slots); held weakly: a dropped resolver drops out
                 store.add_evict_hook(self._evicted)
@@ -524,6 +524,50 @@ class DeferredResolver:
             cols["last_wrap"] = np.maximum(recs[:, LREC_LAST_WRAP], 0).astype(np.uint8)
         return cols
 
+    def _serve_misses(self, buf: bytes, n: int, requests, miss_idx: np.ndarray) -> bool:
+        """The requests `miss_idx` of a step could not be resolved by ``ss_ctx_observe_requests``: register what is new among
+        THEM (first use of a sound / RIR directory: needs the request objects) and load the RIR files of their poses that are
+        not resident (or are clipped rows that are now needed whole).  Returns False when nothing could be done about them
+        (the caller then takes the numpy path, which raises the precise error)."""
+        recs = np.frombuffer(buf, np.int64).reshape(n, REC_N)[miss_idx]
+        changed = False
+        sound = self._lookup(self._sound_keys, self._sound_ids, recs[:, REC_SOUND])
+        table = self._lookup(self._table_keys, self._table_ids, recs[:, REC_TABLE])
+        has_dis = recs[:, REC_DIS_SOUND] >= 0
+        dsound = self._lookup(self._sound_keys, self._sound_ids, recs[:, REC_DIS_SOUND]) if has_dis.any() else None
+        new = (sound < 0) | (table < 0)
+        if dsound is not None:
+            new |= has_dis & (dsound < 0)
+        if new.any():
+            if requests is None:
+                return False
+            for j in np.flatnonzero(new):
+                q = requests[int(miss_idx[j])]
+                if sound[j] < 0 and name_key(q.sound) not in self._key_names:
+                    self._learn_sound(q.sound, q.clip)
+                    changed = True
+                if table[j] < 0 and name_key(os.path.dirname(q.rir_key)) not in self._key_names:
+                    self._learn_table(q.rir_key)
+                    changed = True
+                if dsound is not None and has_dis[j] and dsound[j] < 0 and name_key(q.dis_sound) not in self._key_names:
+                    self._learn_sound(q.dis_sound, q.dis_clip)
+                    changed = True
+            table = self._lookup(self._table_keys, self._table_ids, recs[:, REC_TABLE])
+            if (table < 0).any():
+                return False
+        store = self.engine.store
+        pk = self._pair_key(table, recs[:, REC_RECV], recs[:, REC_SRC])
+        if dsound is not None:
+            pk = np.concatenate([pk, self._pair_key(table[has_dis], recs[has_dis, REC_RECV], recs[has_dis, REC_DIS_SRC])])
+        slot = self._lookup(self._pair_keys, self._pair_slots, pk)
+        need = slot < 0
+        if store.truncate_to is None:
+            need |= (slot >= 0) & store._clipped[np.maximum(slot, 0)]
+        if need.any():
+            self._load_pairs(pk, np.flatnonzero(need))
+            changed = True
+        return changed
+
     @staticmethod
     def _records(requests: Sequence[AudioRequest]) -> Optional[bytes]:
         """the packed records of a step, concatenated (None: some request has none - live RIRs - the step takes the walk)"""
@@ -720,12 +764,24 @@ class DeferredResolver:
         sg, ag = (spectrogram_out if want_spectrogram else None), (audiogoal_out if want_audiogoal else None)
         done = False
         if hasattr(self.engine, "observe_requests"):       # lookups + planner + launch in one C call
-            tables = self._request_tables()
-            if tables["t"].last_used:                      # the store's LRU clock: the C lookups stamp the rows they use
-                self.engine.store.begin_batch()
-                tables["t"].tick = self.engine.store._batch
-            done = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag) == 0
+            store = self.engine.store
+            ticking = hasattr(store, "_batch_of")
+            if ticking:                                    # the store's LRU clock: the C lookups stamp the rows they use
+                store.begin_batch()
+            for attempt in range(3):
+                tables = self._request_tables()
+                if ticking:
+                    tables["t"].tick = store._batch
+                n_miss = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag)
+                if n_miss == 0:
+                    done = True
+                    break
+                # a step with something new (a pose whose RIR file is not resident, a first sound / RIR directory): only the
+                # reported requests are looked at - files read by the library's reader in one call - and the C call runs again
+                if attempt == 2 or not self._serve_misses(buf, n, requests, self.engine._req_miss["buf"][:n_miss]):
+                    break
             self.native_steps += done
+            self.miss_steps += bool(done and attempt)
         if not done:                                        # something to register / load (or an engine without the C path)
             self.engine.observe_columns(self._columns(requests, buf), spectrogram_out=sg, audiogoal_out=ag)
         self.column_steps += 1

@@ -653,7 +653,7 @@ class RirStore:
             self._flush_ev.record()
         return len(slots)
 
-    def upload_rows(self, slots: Sequence[int], rows: Sequence[np.ndarray], threads: int = 4) -> None:
+    def upload_rows(self, slots: Sequence[int], rows: Sequence[np.ndarray], threads: int = 8) -> None:
         """rows[i] (float32, wav layout [L, 2], C-contiguous: what the ray tracer's output transposes to) -> bank row
         slots[i], NOW: the rows are gathered into one pinned block by the library (ss_rows_gather_f32: plain threads, no
         per-row numpy call), cross PCIe as one copy and are transposed into the planar rows by the scatter on the device.
@@ -850,6 +850,10 @@ class RirStore:
         if getattr(self, "_fstage", None) is None or self._fstage[0].shape[1] != self.cap:
             pin = self.device.type == "cuda"
             self._fstage = [torch.zeros((self._FILE_CHUNK, self.cap, 2), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
+            # the rows' bank slots and lengths travel the same way (a list -> device tensor conversion is a SYNCHRONOUS pageable
+            # copy: two of them were a third of a step that loads one new pose)
+            self._fstage_idx = [torch.zeros((self._FILE_CHUNK,), dtype=torch.long, pin_memory=pin) for _ in range(2)]
+            self._fstage_len = [torch.zeros((self._FILE_CHUNK,), dtype=torch.int32, pin_memory=pin) for _ in range(2)]
             self._fstage_ev = [None, None]
         if self._fstage_ev[k & 1] is not None:
             self._fstage_ev[k & 1].synchronize()                 # the H2D copy that last read this block has run
@@ -934,10 +938,13 @@ class RirStore:
                 self._batch_of[sl] = self._batch
                 slots += [sl + g for g in range(G)]
             sl_np = np.asarray(slots)
-            idx = torch.as_tensor(slots, dtype=torch.long, device=self.device)
+            pidx, plen = self._fstage_idx[c & 1], self._fstage_len[c & 1]
+            pidx.numpy()[:n_rows] = sl_np
+            plen.numpy()[:n_rows] = lens
+            idx = pidx[:n_rows].to(self.device, non_blocking=True)
             dev_blk = stage[:n_rows].to(self.device, non_blocking=True).permute(0, 2, 1)     # [k, cap, 2] -> [k, 2, cap]
             self.bank.data.index_copy_(0, idx, dev_blk)
-            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
+            self.bank.lengths.index_copy_(0, idx, plen[:n_rows].to(self.device, non_blocking=True))
             if self.device.type == "cuda":
                 ev = torch.cuda.Event()
                 ev.record()

@@ -234,6 +234,35 @@ class OracleColumnEngine(OracleEngine):
             self.store.truncate_to = None                  # as AudioEngine.source_id: whole RIRs from now on
         return super().source_id(name, clip)
 
+    # ---- the C record path (AudioEngine.observe_requests) with the launch replaced by the oracle: the lookups run in the real
+    # library (ss_ctx_requests_units: host only), so DeferredResolver's miss handling - report, load, call again - runs on CPU
+    def enable_native_requests(self):
+        from ss_amd.context import AudioContext
+        self._ctx = AudioContext(self.sr)
+        self._req_miss = dict(buf=np.zeros((0,), np.int32))
+        self.request_calls = 0
+        self.observe_requests = self._observe_requests
+        self.context = lambda: self._ctx
+        return self
+
+    def source_id_ctx(self, name, clip):
+        sid = self.source_id(name, clip)
+        if getattr(self, "_ctx", None) is not None:
+            assert self._ctx.add_source_len(name, len(clip)) == sid
+        return sid
+
+    def _observe_requests(self, recs, n, tables, spectrogram_out=None, audiogoal_out=None):
+        self.request_calls += 1
+        for name, sid in sorted(self.names.items(), key=lambda kv: kv[1]):      # sounds registered since the last call
+            self._ctx.add_source_len(name, len(self.sources[sid]))
+        cols, miss = self._ctx.requests_units(recs, n, tables)
+        self._req_miss["buf"] = miss
+        if miss.shape[0]:
+            return int(miss.shape[0])
+        cols = {k: v for k, v in cols.items() if not (k.startswith("dis_") and not (cols["dis_rir"] >= 0).any())}
+        self.observe_columns(cols, spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out)
+        return 0
+
     def _row(self, slot):
         n = int(self.store.host_len[slot])
         return np.ascontiguousarray(self.store.bank.data[slot, :, :n].numpy().T)

@@ -16,7 +16,7 @@ from ss_amd.deferred import DeferredResolver, attach_deferred
 from test_deferred import SR, apply, make_world, trajectory
 
 
-def drive(n_env, steps, has_distractor, slots, sounds=None, files=None, mutate=None):
+def drive(n_env, steps, has_distractor, slots, sounds=None, files=None, mutate=None, native=False):
     sounds0, files0 = make_world()
     sounds, files = sounds or sounds0, files or files0
     sims = [FakeSim(SR, sounds, files, has_distractor) for _ in range(n_env)]
@@ -24,6 +24,8 @@ def drive(n_env, steps, has_distractor, slots, sounds=None, files=None, mutate=N
         s._current_distractor_sound = "dist.wav"
         attach_deferred(s, env_rank=i)
     fast_eng, slow_eng = OracleColumnEngine(SR, slots=slots), OracleEngine(SR)
+    if native:
+        fast_eng.enable_native_requests()
     fast = DeferredResolver(fast_eng, rir_reader=files.get)
     slow = DeferredResolver(slow_eng, rir_reader=files.get, fast=False)
     assert fast.columns_ok and not slow.columns_ok
@@ -40,6 +42,7 @@ def drive(n_env, steps, has_distractor, slots, sounds=None, files=None, mutate=N
         assert torch.allclose(a["audiogoal"], b["audiogoal"], atol=1e-6), k
         assert torch.allclose(a["spectrogram"], b["spectrogram"], atol=1e-6), k
     assert fast.column_steps == steps and fast.walk_steps == 0 and fast_eng.column_calls == steps
+    assert not native or fast.native_steps == steps           # every step ends in the C call, also the ones that had to load
     return fast, fast_eng
 
 
@@ -270,3 +273,18 @@ def test_live_rir_steps_take_the_column_path(crossfade):
     assert res.live_steps == 9 and res.walk_steps == 0
     # one upload per env and step (+ the foreign _last_rir of the reset): the previous RIR is found by its number
     assert eng.store.misses == 8                                # two rows per env, allocated once
+
+
+@pytest.mark.parametrize("has_distractor,slots", [(False, 64), (True, 64), (False, 6)])
+def test_native_record_path_serves_its_misses_and_calls_again(has_distractor, slots):
+    """The C record path (ss_ctx_observe_requests; here its host half ss_ctx_requests_units + the oracle) reports the requests
+    it cannot resolve; the resolver looks at THOSE only (first sounds / RIR directories, poses whose file is not resident -
+    read in one call - , rows evicted meanwhile), rebuilds the tables and calls again: same results as the request walk, no
+    numpy column pass, also with a store so small that every step evicts (the rows the step already looked up are stamped by
+    the C lookups and cannot be taken)."""
+    fast, eng = drive(3, 12 if slots == 6 else 9, has_distractor, slots=slots, native=True)
+    assert fast.miss_steps >= 3 and eng.request_calls > fast.native_steps
+    if slots == 6:
+        assert eng.store.misses > 6
+        for k, slot in zip(fast._pair_keys.tolist(), fast._pair_slots.tolist()):
+            assert eng.store._slot_of[("ix", k)] == slot

@@ -131,3 +131,37 @@ def test_stft_stage_accesses_are_conflict_free():
     bad = [2 * (f * 272 + 4 * q) for f, q in lanes]
     assert rd128_cost(bad) > 4
     assert max(pos_n(255) + 1, 15 * 17 + 16) <= NAT_STRIDE and pos_n(255) < 270
+
+
+# ---- k_features (ss_features.hpp): the PHAT cross-spectrum V and the lag rows ------------------------------------------
+def pos_v(k):
+    return (k & 3) * 68 + (k >> 2)
+
+
+def wr32_cost(dw):                   # ds_write_b32: two groups of 32 lanes over 32 banks (2 = conflict free)
+    tot = 0
+    for h in range(2):
+        banks = {}
+        for x in dw[32 * h:32 * h + 32]:
+            banks.setdefault(x % 32, set()).add(x)
+        tot += max(len(v) for v in banks.values())
+    return tot
+
+
+def test_features_cross_spectrum_layout_and_lag_rows_are_conflict_free():
+    V_STRIDE, RES_STRIDE = 272, 17
+    lanes = [(l >> 4, l & 15) for l in range(64)]
+    assert sorted(pos_v(k) for k in range(256)) == sorted(set(pos_v(k) for k in range(256))) and pos_v(255) < V_STRIDE
+    for i in range(2):
+        for e in range(4):
+            assert wr_cost([f * V_STRIDE + pos_v(4 * (q + 16 * i) + e) for f, q in lanes]) == 4
+            mirror = [f * V_STRIDE + pos_v((256 - 4 * (q + 16 * i) - e) % 256) for f, q in lanes]     # (k = 0 is not stored)
+            assert wr_cost(mirror) == 4
+    for j in range(16):
+        assert rd_cost([f * V_STRIDE + pos_v(q + 16 * j) for f, q in lanes]) == 2
+    # the layout this replaced (natural order + posN padding, frames 288 apart)
+    assert wr_cost([f * NAT_STRIDE + pos_n(4 * q) for f, q in lanes]) > 4
+    # lag rows: lane (f, q) stores lag 2 q + u of frame f; at a 16-float pitch the sixteen q of a frame shared one bank
+    for u in range(2):
+        assert wr32_cost([(2 * q + u + 32) * RES_STRIDE + f for f, q in lanes]) <= 4       # (2-way costs a b32 store nothing)
+        assert wr32_cost([(2 * q + u + 32) * 16 + f for f, q in lanes]) == 32
