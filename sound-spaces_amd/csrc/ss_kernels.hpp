@@ -857,6 +857,10 @@ __global__ __launch_bounds__(256) void k_gccphat(GccParams p) {
 // (96 VGPRs) that a 1024-thread workgroup does not have.
 constexpr int kMaxBuckets = 4;
 constexpr int kTabUnits = 256;
+// words per unit of the kernel-argument table: {bank index | -1, window-spectrum slot, OUTPUT unit}.  The host deals the
+// units out sorted by window spectrum (one group of sounds per XCD: row_slot), so the rows that read one 128-KiB spectrum sit
+// on one XCD and find it in that L2; word 2 says where the row's results go (the caller's unit order is untouched)
+constexpr int kTabWords = 3;
 struct BankBucket {
     const float* rir;            // planar [n, 2, cap] rows, zero beyond each entry's length
     const f32x4* hspec;          // spectral form [n][2][h_blocks][8192] f32x4, or nullptr
@@ -922,7 +926,7 @@ struct ConvParams {
 template <bool TAB>
 struct UnitTab { };
 template <>
-struct UnitTab<true> { int tab[2 * kTabUnits]; };
+struct UnitTab<true> { int tab[kTabWords * kTabUnits]; };
 static_assert(sizeof(ConvParams) <= 512, "ConvParams is passed by value to every conv kernel: keep it small");
 static_assert(sizeof(ConvParams) + sizeof(UnitTab<true>) + 64 <= 4096, "kernel arguments of the TAB instantiations");
 
@@ -1227,7 +1231,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
     bool any = false;
     if (SIMPLE) {
         int ridx;
-        if constexpr (TAB) ridx = ut.tab[2 * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
+        if constexpr (TAB) ridx = ut.tab[kTabWords * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
         bool active = false;
         if (ridx >= 0) {
             const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
@@ -1246,7 +1250,7 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
             int slot0 = 0;
             bool ok = true;
             if constexpr (TAB) {
-                slot0 = ut.tab[2 * unit + 1];
+                slot0 = ut.tab[kTabWords * unit + 1];
             } else {
                 const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
                 const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
@@ -1354,11 +1358,13 @@ __global__ __launch_bounds__(1024) void k_conv(ConvParams p, UnitTab<TAB> ut = U
             }
         }
     }
-    if (part == 0) store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    int ounit = unit;                                       // where the row's results go (unit table: units are dealt out sorted)
+    if constexpr (TAB) ounit = ut.tab[kTabWords * unit + 2];
+    if (part == 0) store_row_block(p, t, (size_t)ounit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;                    // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase<WIDE>(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res, part);
+        fused_stft_phase<WIDE>(lds, p, t, ounit, ch, y, s_win, s_tw512, wq, s_res, part);
     }
 }
 
@@ -1452,7 +1458,7 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p, UnitTab<TAB> u
     const size_t row_f4 = (size_t)p.h_blocks * (kSpecComplex / 2);     // f32x4 per (entry, ear)
     if (SIMPLE) {
         i32x4 dw;
-        if constexpr (TAB) dw = i32x4{ut.tab[2 * unit], ut.tab[2 * unit + 1], 0, 1};            // {index | -1, slot of window 0, m_min, count}
+        if constexpr (TAB) dw = i32x4{ut.tab[kTabWords * unit], ut.tab[kTabWords * unit + 1], 0, 1};            // {index | -1, slot of window 0, m_min, count}
         else dw = uniform_load4(d);
         const int ridx = dw.x;
         if (ridx >= 0) {
@@ -1520,11 +1526,13 @@ __global__ __launch_bounds__(1024) void k_conv_spec(ConvParams p, UnitTab<TAB> u
         return;
     }
 #endif
-    if (part == 0) store_row_block(p, t, (size_t)unit * 2 + ch, j, y);
+    int ounit = unit;
+    if constexpr (TAB) ounit = ut.tab[kTabWords * unit + 2];
+    if (part == 0) store_row_block(p, t, (size_t)ounit * 2 + ch, j, y);
     if (FUSE) {
         if (t < kNfft) s_win[t] = win_v;
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res, part);
+        fused_stft_phase(lds, p, t, ounit, ch, y, s_win, s_tw512, wq, s_res, part);
     }
 }
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p, UnitTab<TAB> ut = 
     }
     c32 y[16];
     int ridx;
-    if constexpr (TAB) ridx = ut.tab[2 * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
+    if constexpr (TAB) ridx = ut.tab[kTabWords * unit]; else ridx = __builtin_amdgcn_readfirstlane(d[0]);
     bool active = false;
     if (ridx >= 0) {
         const float* h = p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p, UnitTab<TAB> ut = 
         int slot0 = 0;
         bool ok = true;
         if constexpr (TAB) {
-            slot0 = ut.tab[2 * unit + 1];
+            slot0 = ut.tab[kTabWords * unit + 1];
         } else {
             const int L = __builtin_amdgcn_readfirstlane(p.rir_len[ridx]);
             const int spec0 = __builtin_amdgcn_readfirstlane(d[1]);
@@ -181,8 +181,10 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p, UnitTab<TAB> ut = 
 #pragma unroll
         for (int a = 0; a < 16; ++a) y[a] = mk2(0.f, 0.f);
     }
+    int ounit = unit;                                       // (unit table: units are dealt out sorted; see kTabWords)
+    if constexpr (TAB) ounit = ut.tab[kTabWords * unit + 2];
     if (p.out) {                                            // one output block: samples [0, n_valid), zeros up to out_len
-        const size_t row = (size_t)unit * 2 + ch;
+        const size_t row = (size_t)ounit * 2 + ch;
         float* orow = p.out + row * p.out_len;
         const int nv = p.n_valid;
         if (!(nv & 1) && !(reinterpret_cast<size_t>(orow) & 7)) {
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(512) void k_conv32(ConvParams p, UnitTab<TAB> ut = 
     if (FUSE) {
         s_win[t] = win_v;                                   // visible to the STFT phase after its first barrier
         if (t < 256) s_tw512[posN(t)] = tw512_v;
-        fused_stft_phase32(lds, p, t, unit, ch, y, s_win, s_tw512, wq, s_res);
+        fused_stft_phase32(lds, p, t, ounit, ch, y, s_win, s_tw512, wq, s_res);
     }
 }
 

@@ -230,11 +230,13 @@ int hs_conv32(int fuse, const float* spec, const float* rir, const int* rir_len,
     ssk::UnitTab<true> ut;
     if (use_tab) {
         if (n_units > ssk::kTabUnits) return -2;
-        for (int i = 0; i < n_units; ++i) {
+        for (int k = 0; k < n_units; ++k) {                 // launch slot k renders unit n - 1 - k (the library deals the units
+            const int i = n_units - 1 - k;                  // out sorted by window spectrum: word 2 = where the results go)
             const int* d = desc + 8 * i;
             const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;
-            ut.tab[2 * i] = ok ? d[0] : -1;
-            ut.tab[2 * i + 1] = ok ? d[1] - d[2] : 0;
+            ut.tab[ssk::kTabWords * k] = ok ? d[0] : -1;
+            ut.tab[ssk::kTabWords * k + 1] = ok ? d[1] - d[2] : 0;
+            ut.tab[ssk::kTabWords * k + 2] = i;
         }
     }
     gridDim = dim3{(unsigned)(2 * n_units), 1, 1};
