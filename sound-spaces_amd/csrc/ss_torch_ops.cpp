@@ -13,7 +13,10 @@
 //                              both outputs into pinned memory + stream synchronise - an eager observation is ONE dispatch
 //   ss_hip::ctx_register / ctx_unregister   the raw ss_ctx* behind an AudioContext.handle
 //
-// Schemas are those ss_amd/ops.py registered before (it now only adds the ops not defined here).  Built in-tree by
+//   round 5: source_windows, fftconv_binaural, rir_spectra, fftconv_binaural_spec, audio_obs_spec, audio_features, intensity
+//
+// Schemas are those ss_amd/ops.py registered before (it now only adds the ops not defined here: the two stand-alone feature
+// kernels and the Meta shape functions).  Built in-tree by
 // sound-spaces_amd/build.py (g++ against the torch headers; links libss_hip.so by $ORIGIN).
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // PyTorch-ROCm: HIP devices carry the device type "cuda"
@@ -86,6 +89,98 @@ std::tuple<at::Tensor, at::Tensor> audio_obs(const at::Tensor& spec, const at::T
                               static_cast<int>(n_valid), static_cast<int>(out_len), static_cast<int>(pad_mode),
                               static_cast<int>(flags), stream_of(spec)), "ss_audio_obs_f32");
     return {ag, sg};
+}
+
+// ---- round 5: the rest of the op layer ("no hot op crosses ctypes") ---------------------------------
+constexpr int64_t kSpecFloats = 2 * 16384, kKB = 16384;
+
+at::Tensor source_windows(const at::Tensor& src, const at::Tensor& win_desc) {
+    TORCH_CHECK(win_desc.dim() == 2 && win_desc.size(1) == 4, "win_desc must be [W, 4]");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(src.device());
+    at::Tensor out = at::empty({win_desc.size(0), kSpecFloats}, src.options());
+    check_rc(ss_source_windows_f32(fptr(src, "src"), iptr(win_desc, "win_desc"), out.data_ptr<float>(),
+                                   static_cast<int>(win_desc.size(0)), stream_of(src)), "ss_source_windows_f32");
+    return out;
+}
+
+at::Tensor fftconv_binaural(const at::Tensor& spec, const at::Tensor& rir_bank, const at::Tensor& rir_len,
+                            const at::Tensor& unit_desc, int64_t n_valid, int64_t out_len, bool interleaved, int64_t flags) {
+    TORCH_CHECK(rir_bank.dim() == 3, "rir_bank must be [R,2,L] (planar) or [R,L,2] (wav-interleaved)");
+    TORCH_CHECK(unit_desc.dim() == 2 && unit_desc.size(1) == 8, "unit_desc must be [N, 8]");
+    const int64_t cap = interleaved ? rir_bank.size(1) : rir_bank.size(2), N = unit_desc.size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(spec.device());
+    at::Tensor out = at::empty({N, 2, out_len}, spec.options());
+    check_rc(ss_fftconv_binaural_f32(fptr(spec, "spec"), fptr(rir_bank, "rir_bank"), iptr(rir_len, "rir_len"),
+                                     iptr(unit_desc, "unit_desc"), out.data_ptr<float>(), static_cast<int>(N), 2 * cap,
+                                     interleaved ? 1 : static_cast<int>(cap), interleaved ? 2 : 1, static_cast<int>(cap),
+                                     static_cast<int>(n_valid), static_cast<int>(out_len), static_cast<int>(flags),
+                                     stream_of(spec)), "ss_fftconv_binaural_f32");
+    return out;
+}
+
+at::Tensor rir_spectra(const at::Tensor& rir_bank) {
+    TORCH_CHECK(rir_bank.dim() == 3 && rir_bank.size(1) == 2, "rir_bank must be planar [R, 2, cap]");
+    const int64_t R = rir_bank.size(0), cap = rir_bank.size(2), hb = (cap + kKB - 1) / kKB;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(rir_bank.device());
+    at::Tensor out = at::empty({R, 2, hb, kSpecFloats}, rir_bank.options());
+    check_rc(ss_rir_spectra_f32(fptr(rir_bank, "rir_bank"), out.data_ptr<float>(), static_cast<int>(R), 2 * cap,
+                                static_cast<int>(cap), static_cast<int>(cap), stream_of(rir_bank)), "ss_rir_spectra_f32");
+    return out;
+}
+
+at::Tensor fftconv_binaural_spec(const at::Tensor& spec, const at::Tensor& hspec, const at::Tensor& rir_len,
+                                 const at::Tensor& unit_desc, int64_t n_valid, int64_t out_len, int64_t flags) {
+    TORCH_CHECK(hspec.dim() == 4 && unit_desc.dim() == 2 && unit_desc.size(1) == 8, "hspec [R,2,hb,F], unit_desc [N,8]");
+    const int64_t N = unit_desc.size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(spec.device());
+    at::Tensor out = at::empty({N, 2, out_len}, spec.options());
+    check_rc(ss_fftconv_binaural_spec_f32(fptr(spec, "spec"), fptr(hspec, "hspec"), iptr(rir_len, "rir_len"),
+                                          iptr(unit_desc, "unit_desc"), out.data_ptr<float>(), static_cast<int>(N),
+                                          static_cast<int>(hspec.size(2)), static_cast<int>(n_valid), static_cast<int>(out_len),
+                                          static_cast<int>(flags), stream_of(spec)), "ss_fftconv_binaural_spec_f32");
+    return out;
+}
+
+std::tuple<at::Tensor, at::Tensor> audio_obs_spec(const at::Tensor& spec, const at::Tensor& hspec, const at::Tensor& rir_len,
+                                                  const at::Tensor& unit_desc, int64_t n_valid, int64_t out_len, int64_t pad_mode,
+                                                  int64_t flags) {
+    TORCH_CHECK(hspec.dim() == 4 && unit_desc.dim() == 2 && unit_desc.size(1) == 8, "hspec [R,2,hb,F], unit_desc [N,8]");
+    const int64_t N = unit_desc.size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(spec.device());
+    at::Tensor ag = at::empty({N, 2, out_len}, spec.options());
+    at::Tensor sg = at::empty({N, 65, t4_of(out_len), 2}, spec.options());
+    check_rc(ss_audio_obs_spec_f32(fptr(spec, "spec"), fptr(hspec, "hspec"), iptr(rir_len, "rir_len"), iptr(unit_desc, "unit_desc"),
+                                   ag.data_ptr<float>(), sg.data_ptr<float>(), static_cast<int>(N), static_cast<int>(hspec.size(2)),
+                                   static_cast<int>(n_valid), static_cast<int>(out_len), static_cast<int>(pad_mode),
+                                   static_cast<int>(flags), stream_of(spec)), "ss_audio_obs_spec_f32");
+    return {ag, sg};
+}
+
+// log-mel + GCC-PHAT of x [N, 2, n] in ONE pass (k_features; BASELINE configs[4]'s fused sensor)
+std::tuple<at::Tensor, at::Tensor> audio_features(const at::Tensor& x, const at::Tensor& mel_start, const at::Tensor& mel_w,
+                                                  double mel_eps, int64_t max_lag, double gcc_eps, int64_t pad_mode) {
+    TORCH_CHECK(x.dim() == 3 && x.size(1) == 2, "x must be [N, 2, n]");
+    TORCH_CHECK(mel_w.dim() == 2 && mel_start.dim() == 1 && mel_start.size(0) == mel_w.size(0), "mel_start [n_mels], mel_w [n_mels, max_len]");
+    const int64_t N = x.size(0), n = x.size(2), T = 1 + n / 160;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    at::Tensor lm = at::empty({N, mel_w.size(0), T, 2}, x.options());
+    at::Tensor gc = at::empty({N, 2 * max_lag + 1, T}, x.options());
+    check_rc(ss_audio_features_f32(fptr(x, "x"), static_cast<int>(N), static_cast<int>(n), static_cast<int>(pad_mode), nullptr,
+                                   lm.data_ptr<float>(), iptr(mel_start, "mel_start"), fptr(mel_w, "mel_w"),
+                                   static_cast<int>(mel_w.size(0)), static_cast<int>(mel_w.size(1)), static_cast<float>(mel_eps),
+                                   gc.data_ptr<float>(), static_cast<int>(max_lag), static_cast<float>(gcc_eps), stream_of(x)),
+             "ss_audio_features_f32");
+    return {lm, gc};
+}
+
+at::Tensor intensity(const at::Tensor& audiogoal, int64_t num_frame) {
+    TORCH_CHECK(audiogoal.dim() == 3 && audiogoal.size(1) == 2, "audiogoal must be [N, 2, n]");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(audiogoal.device());
+    at::Tensor out = at::empty({audiogoal.size(0)}, audiogoal.options());
+    check_rc(ss_intensity_f32(fptr(audiogoal, "audiogoal"), out.data_ptr<float>(), static_cast<int>(audiogoal.size(0)),
+                              static_cast<int>(audiogoal.size(2)), static_cast<int>(num_frame), stream_of(audiogoal)),
+             "ss_intensity_f32");
+    return out;
 }
 
 void ctx_register(int64_t handle, int64_t ptr) {
@@ -167,12 +262,30 @@ TORCH_LIBRARY(ss_hip, m) {
     m.def("ctx_unregister(int handle) -> ()", &ctx_unregister);
     m.def("eager_obs(int ctx, int sound, int t0, int rir, int dis_sound, int dis_rir, int last_rir, int wrap, int last_wrap, "
           "Tensor(a!) dev, Tensor(b!) host, int sr, bool want_spectrogram, bool want_audiogoal=True) -> ()");
-    m.def("native_ops() -> int", []() -> int64_t { return 1; });
+    m.def("source_windows(Tensor src, Tensor win_desc) -> Tensor");
+    m.def("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+          "bool interleaved=False, int flags=0) -> Tensor");
+    m.def("rir_spectra(Tensor rir_bank) -> Tensor");
+    m.def("fftconv_binaural_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+          "int flags=0) -> Tensor");
+    m.def("audio_obs_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+          "int pad_mode=0, int flags=0) -> (Tensor, Tensor)");
+    m.def("audio_features(Tensor x, Tensor mel_start, Tensor mel_w, float mel_eps=1e-6, int max_lag=32, float gcc_eps=1e-8, "
+          "int pad_mode=0) -> (Tensor, Tensor)");
+    m.def("intensity(Tensor audiogoal, int num_frame=150) -> Tensor");
+    m.def("native_ops() -> int", []() -> int64_t { return 2; });   // 2: + the ops of round 5 (ss_amd/ops.py registers the rest)
 }
 
 TORCH_LIBRARY_IMPL(ss_hip, CUDA, m) {
     m.impl("spectrogram", &spectrogram);
     m.impl("audio_obs", &audio_obs);
+    m.impl("source_windows", &source_windows);
+    m.impl("fftconv_binaural", &fftconv_binaural);
+    m.impl("rir_spectra", &rir_spectra);
+    m.impl("fftconv_binaural_spec", &fftconv_binaural_spec);
+    m.impl("audio_obs_spec", &audio_obs_spec);
+    m.impl("audio_features", &audio_features);
+    m.impl("intensity", &intensity);
 }
 
 TORCH_LIBRARY_IMPL(ss_hip, CompositeExplicitAutograd, m) {

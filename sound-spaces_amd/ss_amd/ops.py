@@ -347,18 +347,23 @@ def _load_native_ops() -> bool:
 
 
 NATIVE_OPS = _load_native_ops()
+# 2: the extension also defines source_windows / fftconv_binaural / rir_spectra / *_spec / audio_features / intensity
+NATIVE_LEVEL = int(torch.ops.ss_hip.native_ops()) if NATIVE_OPS else 0
 
 
 def _register():
     lib = torch.library.Library("ss_hip", "FRAGMENT" if NATIVE_OPS else "DEF")
-    lib.define("source_windows(Tensor src, Tensor win_desc) -> Tensor")
-    lib.define("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, "
-               "int out_len, bool interleaved=False, int flags=0) -> Tensor")
+    py2 = NATIVE_LEVEL < 2                                  # these ops are NOT defined by the C++ extension: register them here
+    if py2:
+        lib.define("source_windows(Tensor src, Tensor win_desc) -> Tensor")
+        lib.define("fftconv_binaural(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, "
+                   "int out_len, bool interleaved=False, int flags=0) -> Tensor")
     if not NATIVE_OPS:
         lib.define("spectrogram(Tensor x, int pad_mode=0) -> Tensor")
         lib.define("audio_obs(Tensor spec, Tensor rir_bank, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
                    "int pad_mode=0, bool interleaved=False, int flags=0) -> (Tensor, Tensor)")
-    lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
+    if py2:
+        lib.define("intensity(Tensor audiogoal, int num_frame=150) -> Tensor")
     lib.define("gccphat(Tensor x, int max_lag=32, float eps=1e-8, int pad_mode=0) -> Tensor")
     lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0: gccphat(x, max_lag, eps, pad_mode), "CUDA")
     lib.impl("gccphat", lambda x, max_lag=32, eps=1e-8, pad_mode=0:
@@ -367,20 +372,23 @@ def _register():
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0: logmel(x, ms, mw, eps, pad_mode), "CUDA")
     lib.impl("logmel", lambda x, ms, mw, eps=1e-6, pad_mode=0:
              x.new_empty((x.shape[0], mw.shape[0], 1 + x.shape[2] // 160, 2)), "Meta")
-    lib.define("audio_features(Tensor x, Tensor mel_start, Tensor mel_w, float mel_eps=1e-6, int max_lag=32, float gcc_eps=1e-8, "
-               "int pad_mode=0) -> (Tensor, Tensor)")
+    if py2:
+        lib.define("audio_features(Tensor x, Tensor mel_start, Tensor mel_w, float mel_eps=1e-6, int max_lag=32, float gcc_eps=1e-8, "
+                   "int pad_mode=0) -> (Tensor, Tensor)")
 
     def _audio_features(x, ms, mw, mel_eps=1e-6, max_lag=32, gcc_eps=1e-8, pad_mode=0):
         o = audio_features(x, ("logmel", "gccphat"), ms, mw, mel_eps, max_lag, gcc_eps, pad_mode)
         return o["logmel"], o["gccphat"]
-    lib.impl("audio_features", _audio_features, "CUDA")
+    if py2:
+        lib.impl("audio_features", _audio_features, "CUDA")
     lib.impl("audio_features", lambda x, ms, mw, mel_eps=1e-6, max_lag=32, gcc_eps=1e-8, pad_mode=0:
              (x.new_empty((x.shape[0], mw.shape[0], 1 + x.shape[2] // 160, 2)),
               x.new_empty((x.shape[0], 2 * max_lag + 1, 1 + x.shape[2] // 160))), "Meta")
-    lib.impl("intensity", intensity, "CUDA")
+    if py2:
+        lib.impl("intensity", intensity, "CUDA")
+        lib.impl("source_windows", source_windows, "CUDA")
+        lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
     lib.impl("intensity", lambda a, num_frame=150: a.new_empty((a.shape[0],)), "Meta")
-    lib.impl("source_windows", source_windows, "CUDA")
-    lib.impl("fftconv_binaural", fftconv_binaural, "CUDA")
     def _audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode=0, interleaved=False, flags=0):
         ag, sg = audio_obs(spec, rir_bank, rir_len, unit_desc, n_valid, out_len, pad_mode, True, interleaved, flags)
         return ag, sg
@@ -389,21 +397,25 @@ def _register():
         lib.impl("audio_obs", _audio_obs, "CUDA")
 
     # spectral RIR bank: the bank builder + the two *_spec entry points
-    lib.define("rir_spectra(Tensor rir_bank) -> Tensor")
-    lib.impl("rir_spectra", rir_spectra, "CUDA")
+    if py2:
+        lib.define("rir_spectra(Tensor rir_bank) -> Tensor")
+        lib.impl("rir_spectra", rir_spectra, "CUDA")
     lib.impl("rir_spectra", lambda b: b.new_empty((b.shape[0], 2, ceil_div(b.shape[2], KB), SPEC_FLOATS)), "Meta")
-    lib.define("fftconv_binaural_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
-               "int flags=0) -> Tensor")
+    if py2:
+        lib.define("fftconv_binaural_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+                   "int flags=0) -> Tensor")
 
     def _conv_spec(spec, hspec, rir_len, unit_desc, n_valid, out_len, flags=0):
         out = torch.empty((unit_desc.shape[0], 2, out_len), dtype=torch.float32, device=spec.device)
         fftconv_binaural_spec_into(spec, hspec, rir_len, unit_desc, out, n_valid, flags)
         return out
-    lib.impl("fftconv_binaural_spec", _conv_spec, "CUDA")
+    if py2:
+        lib.impl("fftconv_binaural_spec", _conv_spec, "CUDA")
     lib.impl("fftconv_binaural_spec", lambda spec, h, l, d, n_valid, out_len, flags=0: spec.new_empty((d.shape[0], 2, out_len)),
              "Meta")
-    lib.define("audio_obs_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
-               "int pad_mode=0, int flags=0) -> (Tensor, Tensor)")
+    if py2:
+        lib.define("audio_obs_spec(Tensor spec, Tensor hspec, Tensor rir_len, Tensor unit_desc, int n_valid, int out_len, "
+                   "int pad_mode=0, int flags=0) -> (Tensor, Tensor)")
 
     def _obs_spec(spec, hspec, rir_len, unit_desc, n_valid, out_len, pad_mode=0, flags=0):
         N = unit_desc.shape[0]
@@ -411,7 +423,8 @@ def _register():
         sg = torch.empty((N,) + spectrogram_shape(out_len), dtype=torch.float32, device=spec.device)
         audio_obs_spec_into(spec, hspec, rir_len, unit_desc, ag, sg, n_valid, out_len, pad_mode, flags)
         return ag, sg
-    lib.impl("audio_obs_spec", _obs_spec, "CUDA")
+    if py2:
+        lib.impl("audio_obs_spec", _obs_spec, "CUDA")
     lib.impl("audio_obs_spec", lambda spec, h, l, d, n_valid, out_len, pad_mode=0, flags=0:
              (spec.new_empty((d.shape[0], 2, out_len)), spec.new_empty((d.shape[0],) + spectrogram_shape(out_len))), "Meta")
     # the observe-level op: one vector step through a context (planner + window cache + descriptor ring in the library).

@@ -1145,13 +1145,22 @@ class AudioEngine:
     use, longer RIRs grow the bank (RirStore)."""
 
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
-                 rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: bool = False,
-                 rir_buckets: Optional[Sequence[Tuple[int, int]]] = None, **renderer_kwargs):
-        """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec (no
-        forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change every step and stay
-        on the time-domain kernels."""
+                 rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: Optional[bool] = None,
+                 rir_buckets: Optional[Sequence[Tuple[int, int]]] = None, spectral_hbm_fraction: float = 0.5,
+                 **renderer_kwargs):
+        """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec /
+        k_obs_rows<SPECTRAL> (no forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change
+        every step and stay on the time-domain kernels.  None (default) = decided here: ON for file-backed stores at rates
+        whose rows span several partition blocks (44.1 / 48 kHz - the reference's Replica rate,
+        configs/audionav/av_nav/replica/audiogoal.yaml:18: every observation is three forward FFTs per ear and a stash round
+        trip there; cfg[2]: 271 vs 334 us per 512 units) when rows + spectra fit `spectral_hbm_fraction` of the device's free
+        memory; OFF at 16 kHz, where the forward FFT hides under the row's load (+-2 us per 128 envs) and the bytes double."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
+        if rir_spectral is None:
+            rir_spectral = self._auto_spectral(sampling_rate, rir_slots if not rir_buckets else sum(b[0] for b in rir_buckets),
+                                               rir_cap or sampling_rate, full, spectral_hbm_fraction)
+        self.rir_spectral = bool(rir_spectral) and not full
         if rir_buckets:
             # length-bucketed bank: [(slots, cap samples), ...] ascending, e.g. [(4096, 16000), (256, 49152), (64, 65536)]
             self.store = BucketedRirStore([b[0] for b in rir_buckets], [b[1] for b in rir_buckets], self.renderer.device,
@@ -1165,6 +1174,15 @@ class AudioEngine:
                               on_grow=self.renderer.set_rir_bank, group=rir_group, spectral=rir_spectral and not full)
         self.store.defer_uploads = True            # single-row uploads of a step travel as one block (flushed before every launch)
         self.renderer.set_rir_bank(self.store.bank)
+
+    def _auto_spectral(self, sr: int, slots: int, cap: int, full: bool, fraction: float) -> bool:
+        dev = self.renderer.device
+        if full or sr <= P.KB or dev.type != "cuda":
+            return False
+        blocks = P.ceil_div(cap + (cap & 1), P.KB)
+        need = slots * 2 * (cap * 4 + blocks * P.SPEC_FLOATS * 4)          # time-domain rows + their block spectra
+        free, _total = torch.cuda.mem_get_info(dev)
+        return need <= fraction * free
 
     def source_id(self, name: str, clip: np.ndarray) -> int:
         if self.store.truncate_to is not None and np.shape(clip)[0] != self.renderer.sr:

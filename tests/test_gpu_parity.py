@@ -1639,3 +1639,24 @@ def test_split_rows_small_steps_vs_reference_run_vectors(n_units, group):
             check(ag[n][:, ::stride], ref_a)
             check(sg[n], ref_s)
             check(sg_only[n], ref_s)
+
+
+def test_engine_keeps_the_spectral_form_by_default_at_the_replica_rate():
+    """AudioEngine(rir_spectral=None): file-backed stores at 44.1 kHz (configs/audionav/av_nav/replica/audiogoal.yaml:18) keep
+    the rows' block spectra when they fit the HBM budget (no forward FFT, no stash per observation); 16 kHz stores, SS2.0
+    engines (live RIRs) and stores that would not fit stay on the time-domain kernels.  Same observation either way."""
+    from ss_amd.renderer import AudioEngine, UnitRequest
+    assert AudioEngine(44100, device=DEV, rir_slots=16).rir_spectral
+    assert not AudioEngine(16000, device=DEV, rir_slots=16).rir_spectral
+    assert not AudioEngine(44100, device=DEV, rir_slots=16, step_time=0.25, wrap=True).rir_spectral
+    assert not AudioEngine(44100, device=DEV, rir_slots=16, spectral_hbm_fraction=1e-9).rir_spectral
+    d = case_inputs("clip1s_44k")
+    ref_a, ref_s, stride = case_outputs("clip1s_44k")
+    for spectral in (None, False):
+        eng = AudioEngine(44100, device=DEV, rir_slots=8, rir_spectral=spectral)
+        assert eng.store.spectral == (spectral is None)
+        sid = eng.source_id("s", d["source"])
+        slot = eng.rir_slot("a.wav", lambda: d["rir"])
+        out = eng.observe([UnitRequest(sid, 0, slot)], want_audiogoal=True)
+        check(out["audiogoal"][0].cpu().numpy()[:, ::stride], ref_a)
+        check(out["spectrogram"][0].cpu().numpy(), ref_s)
