@@ -231,7 +231,10 @@ inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags, bool s
 template <bool SPECTRAL>
 int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStream_t st) {
     const int n_rows = 2 * n_units;
-    const int grid = n_rows < n_cus ? n_rows : n_cus;
+    // small steps (the reference steps 5-10 envs per GPU at this rate): a row on 2 / 4 / 8 CUs, each rendering the row and
+    // its share of every phase's pooled STFT blocks - only while every (row, part) still gets a workgroup of its own
+    p.parts_log2 = parts_log2_for(n_rows, n_cus);
+    const int grid = (n_rows << p.parts_log2) < n_cus ? (n_rows << p.parts_log2) : n_cus;
     p.nb_y = p.n_valid == 0 ? 0 : (p.n_valid + ssk::kB - 1) / ssk::kB;
     p.stash = nullptr;
     p.stash_nbh = 0;

@@ -1851,7 +1851,7 @@ __device__ __forceinline__ void rows_product(const f32x4* hp, const f32x4* sp, i
 // (packed pairs t + 1024 a).  `last`: j is the row's last block (right centre padding, frames up to n_frames - 1).
 __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, int j, int b0, int b1,
                                                 bool last, const c32 (&y)[8], const float* s_win, const c32* s_tw512,
-                                                const c32* s_wq, float* s_res, float* s_tail) {
+                                                const c32* s_wq, float* s_res, float* s_tail, int part = 0) {
     float* buf = reinterpret_cast<float*>(lds);           // buf[k] = row sample 640 b0 - 256 + k
     const int base = kB * j;                              // first sample of this block
     const int ctx = j == 0 ? kNfft / 2 : base - (kHop * kPool * b0 - kNfft / 2);    // even, <= kTailFloats
@@ -1883,21 +1883,25 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     // frames relative to the buffer: pooled block b0 + k starts at buf + 640 k; both rounds are pulled into registers
     // before the wave scratches overlay the buffer (see fused_stft_phase)
     c32 x0[16], x1[16];
-    const bool one = wv < cnt, two = wv + 16 < cnt;
+    // split rows (ConvParams::parts_log2: small steps, one row on 2 / 4 / 8 CUs): every part has rendered the whole block;
+    // of the phase's pooled blocks it computes [k_lo, k_hi) only
+    const int per = (cnt + (1 << p.parts_log2) - 1) >> p.parts_log2, k_lo = part * per, k_hi = min(cnt, k_lo + per);
+    const int kw = k_lo + wv;
+    const bool one = kw < k_hi, two = kw + 16 < k_hi;
     const int live = p.n_frames - kPool * b0;             // frames of this phase that exist (relative index < live)
-    stft_load_padded(buf, 4 * wv + (lane >> 4), one ? live : 0, lane & 15, s_win, x0);      // (the window pairs in registers for
-    stft_load_padded(buf, 4 * (wv + 16) + (lane >> 4), two ? live : 0, lane & 15, s_win, x1);  // both rounds spill here: 8-16 VGPRs)
+    stft_load_padded(buf, 4 * kw + (lane >> 4), one ? live : 0, lane & 15, s_win, x0);      // (the window pairs in registers for
+    stft_load_padded(buf, 4 * (kw + 16) + (lane >> 4), two ? live : 0, lane & 15, s_win, x1);  // both rounds spill here: 8-16 VGPRs)
     lds_barrier();
-    if (one) stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * cnt + wv] = v; });
+    if (one) stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x0, [&](int b, float v) { s_res[b * cnt + kw] = v; });
     if (two) {
         wave_sync();
-        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * cnt + wv + 16] = v; });
+        stft_block(lds + wv * kWaveScratch, lane, wq, s_tw512, x1, [&](int b, float v) { s_res[b * cnt + kw + 16] = v; });
     }
     lds_barrier();
     float* o = p.sgram + ((size_t)unit * kBins4 * p.t4 + b0) * 2 + ch;
     for (int b = t / 32; b < kBins4; b += kT / 32) {      // 32 threads per pooled row (cnt <= 27): no division by cnt
         const int k = t & 31;
-        if (k < cnt) o[((size_t)b * p.t4 + k) * 2] = s_res[b * cnt + k];
+        if (k >= k_lo && k < k_hi) o[((size_t)b * p.t4 + k) * 2] = s_res[b * cnt + k];
     }
 }
 
@@ -1938,7 +1942,10 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
     const size_t blk_f4 = kSpecComplex / 2;               // f32x4 per block spectrum
     // the workgroup's stash: [term][RIR block] block spectra of the row being rendered (time-domain bank only)
     f32x4* stash = SPECTRAL ? nullptr : p.stash + (size_t)blockIdx.x * p.stash_terms * p.stash_nbh * blk_f4;
-    for (int row = row_slot(blockIdx.x, G, p.xcd_map); row < n_rows; row += G) {
+    // split rows (parts_log2 > 0; the launcher only asks for it when every (row, part) has a workgroup of its own): slot =
+    // (row, part); every part renders the row's blocks, the pooled STFT blocks of each phase are shared out (rows_stft_phase)
+    const int part = row_slot(blockIdx.x, G, p.xcd_map) & ((1 << p.parts_log2) - 1);
+    for (int row = row_slot(blockIdx.x, G, p.xcd_map) >> p.parts_log2; row < n_rows; row += G) {
         const int unit = row >> 1, ch = row & 1;
         i32x4 dws[2];
         uniform_load8(p.desc + 8 * unit, dws[0], dws[1]);
@@ -1955,6 +1962,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
             if (dws[1].x >= 0) nbh1 = min(nbh1, min(p.stash_nbh, (bank_row(p, dws[1].x, 0).cap + kB - 1) / kB));
         }
         if (dws[0].x < 0 && dws[1].x < 0) {               // silent unit (simulator.py:610-612): exact zeros, no transforms
+            if (part) continue;
             int tz = t;
             SSK_OPAQUE1(tz);                              // nothing of these loops is worth a register outside them
             if (p.out) {
@@ -2112,7 +2120,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
             }                                             // round
             int row_j = row;                              // (output addresses are rebuilt per block, in scalar registers:
             SSK_OPAQUE_S(row_j);                          //  hoisted out of the j loop they lived in VGPRs and spilled)
-            if (j < p.nb_y || j == 0) store_row_block(p, tl, (size_t)row_j, j, y);
+            if ((j < p.nb_y || j == 0) && part == 0) store_row_block(p, tl, (size_t)row_j, j, y);
             const bool last = j == nb_rows - 1;
             const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
             // Short steps (SS2.0: 0.25 s of a 1-s row): pooled blocks that are exactly zero (live_blocks) are written, not
@@ -2123,11 +2131,12 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                 if (y[0].x == 123.456f) p.sgram[0] = y[7].y;      // keeps the convolution alive
                 lds_barrier();
             } else if (b1c > b0) {
-                rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1c, last && b1c == b1, y, s_win, s_tw512, s_wq, s_res, s_tail);
+                rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1c, last && b1c == b1, y, s_win, s_tw512, s_wq, s_res, s_tail,
+                                part);
             } else {
                 lds_barrier();                            // (the phase's entry barrier: pass-1' reads of the buffer are over)
             }
-            if (b1c < b1) {
+            if (b1c < b1 && part == 0) {
                 float* o = p.sgram + ((size_t)(row_j >> 1) * kBins4 * p.t4) * 2 + (row_j & 1);
                 const int nz = b1 - b1c;
                 for (int e = tl; e < kBins4 * nz; e += kT) {

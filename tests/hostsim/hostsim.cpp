@@ -99,7 +99,7 @@ ssk::Tables host_tables() {
 
 // a second length bucket for the next hs_conv / hs_obs_rows call (cleared by it): entries >= first live in `rir` [n,2,cap]
 static int g_spec_n_valid = -1;
-static int g_parts_log2 = 0;          // the next fused one-block hs_conv / hs_conv_spec call: 2^k workgroups per row (cleared by it)
+static int g_parts_log2 = 0;          // the next fused hs_conv / hs_conv_spec / hs_obs_rows call: 2^k workgroups per row (cleared by it)
 static const float* g_b2_rir = nullptr;
 static int g_b2_first = 0, g_b2_cap = 0;
 static void apply_bucket2(ssk::ConvParams& p) {
@@ -343,7 +343,9 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     p.nb_y = n_valid == 0 ? 0 : (n_valid + ssk::kB - 1) / ssk::kB;
     p.n_terms = no_distractor ? 1 : 2;
     apply_bucket2(p);
-    const int n_rows = 2 * n_units, grid = wgs < n_rows ? wgs : n_rows;
+    p.parts_log2 = g_parts_log2;                        // split rows: one workgroup per (row, part), whatever `wgs` says
+    g_parts_log2 = 0;
+    const int n_rows = 2 * n_units, grid = p.parts_log2 ? (n_rows << p.parts_log2) : (wgs < n_rows ? wgs : n_rows);
     std::vector<float> stash;
     p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
     (void)use_stash;                                    // (the time-domain path always has its stash)

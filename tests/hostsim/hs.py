@@ -110,6 +110,9 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
             rc = L.hs_spectrogram(_p(out, ctypes.c_float), _p(sg, ctypes.c_float), N, out_len, pad_mode, 1)
             assert rc == 0, rc
         return (out if want_audiogoal else None), (sg if (fuse or want_spectrogram) else None)
+    if parts_log2:                                       # fused rows rendered by 2^k workgroups each (ConvParams::parts_log2)
+        assert (fuse or row_wgs) and not core32 and not persist
+        L.hs_set_parts_log2(int(parts_log2))
     if row_wgs:                                          # k_obs_rows: fused rows of 2-3 blocks, `row_wgs` persistent workgroups
         assert out_len > P.KB and not (crossfade and spectral)
         hb, hspec = 0, None
@@ -125,9 +128,6 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
                            int(out_len), int(pad_mode), int(row_wgs), int(no_dis and not crossfade), int(row_stash), int(crossfade))
         assert rc == 0, rc
         return (out if want_audiogoal else None), sg
-    if parts_log2:                                       # fused one-block rows rendered by 2^k workgroups each (ConvParams::parts_log2)
-        assert fuse and not row_wgs and not core32 and not persist
-        L.hs_set_parts_log2(int(parts_log2))
     if spectral:                                         # spectral RIR bank (ss_rir_spectra_f32 + k_conv_spec)
         assert not crossfade and not interleaved
         hb = P.ceil_div(cap, P.KB)

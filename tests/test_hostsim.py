@@ -767,3 +767,33 @@ def test_split_rows_equal_one_workgroup_per_row(parts_log2, variant):
         _, ref_s, _ = case_outputs("clip1s_ragged")
         check(s2[0], ref_s)
         assert not s2[1].any()
+
+
+@pytest.mark.parametrize("parts_log2", [1, 3])
+@pytest.mark.parametrize("variant", ["time", "spectral", "short_step", "crossfade"])
+def test_split_rows_of_the_44k_kernel_equal_one_workgroup_per_row(parts_log2, variant):
+    """k_obs_rows with a row on 2 / 8 workgroups (small steps at the reference's Replica rate - 5 envs per GPU at 44.1 kHz,
+    ss_baselines/av_nav/config/audionav/replica/train_telephone/audiogoal_depth_ddppo.yaml:3 +
+    configs/audionav/av_nav/replica/audiogoal.yaml:18): every part renders the row's three blocks, the pooled STFT blocks of
+    each phase are shared out.  Bit-identical to the one-workgroup row, incl. a silent unit, a distractor, a 0.25-s step
+    (zero columns) and a cross-faded row."""
+    d = case_inputs("clip1s_44k")
+    sr = d["sr"]
+    rng = np.random.default_rng(5)
+    bank = np.concatenate([planar(d["rir"]), planar(np.ascontiguousarray(O.synth_rir(rng, sr, length=d["rir"].shape[0], n=1)[0].T))])
+    lens = [d["rir"].shape[0]] * 2
+    units = [dict(sound=0, t0=0, rir=0), dict(sound=0, t0=0, rir=-1), dict(sound=0, t0=0, rir=1, dis_sound=0, dis_t0=0, dis_rir=0)]
+    kw = dict(fuse=True, row_wgs=64, spectral=variant == "spectral")
+    n_valid = 11025 if variant == "short_step" else sr
+    src = [O.tile_short_source(d["source"], sr)] if variant in ("short_step", "crossfade") else [d["source"]]
+    if variant == "crossfade":
+        units = [dict(sound=0, t0=9000, rir=0, last_rir=1), dict(sound=0, t0=9000, rir=1)]
+        kw.update(crossfade=True)
+    a1, s1 = hs.run(src, bank, lens, units, n_valid, sr, **kw)
+    a2, s2 = hs.run(src, bank, lens, units, n_valid, sr, parts_log2=parts_log2, **kw)
+    np.testing.assert_array_equal(a1, a2)
+    np.testing.assert_array_equal(s1, s2)
+    if variant == "time":
+        ref_a, ref_s, stride = case_outputs("clip1s_44k")
+        check(s2[0], ref_s)
+        assert not s2[1].any()
