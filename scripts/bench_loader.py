@@ -85,7 +85,7 @@ def scene_load(dev, root, sr, n, native, workers):
     return {"files": n, "seconds": round(dt, 4), "files_per_s": round(n / dt, 1), "GBps": round(n * sr * 8 / dt / 1e9, 3)}
 
 
-def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources):
+def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources, profile=False):
     """trainer half of a vector step with round(rate * n_envs) envs on a never-seen pose"""
     from ss_amd.deferred import DeferredResolver, attach_deferred
     from ss_amd.rollout import RolloutStorage
@@ -146,10 +146,14 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
     fresh = iter(poses[n_res:])
     sync()
     host = []
+    import cProfile
+    pr = cProfile.Profile() if profile else None
     for k in range(warm + steps):
         if k == warm:
             sync()
             t_start = time.perf_counter()
+            if pr:
+                pr.enable()
         movers = set(rng.choice(n_envs, m, replace=False).tolist())
         for i, sim in enumerate(sims):
             place(sim, next(fresh) if i in movers else resident[int(rng.integers(0, len(resident)))])
@@ -159,6 +163,12 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
             host.append(dt)
     sync()
     wall = time.perf_counter() - t_start
+    if pr:
+        import io, pstats
+        pr.disable()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(30)
+        print(st.getvalue()[:7000], flush=True)
     hm = float(np.median(host))
     return {"mode": mode, "reader": "native" if native else "scipy", "miss_rate": rate, "new_poses_per_step": m,
             "trainer_half_us_per_step_median": round(1e6 * hm, 1), "trainer_half_us_per_step_mean": round(1e6 * float(np.mean(host)), 1),
@@ -174,12 +184,22 @@ def main():
     ap.add_argument("--envs", type=int, default=128)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--out", default="")
+    ap.add_argument("--profile-miss", type=float, default=0.0, help="only: cProfile of deferred-mode steps at this miss rate")
     ap.add_argument("--device", default="cuda:0", help="cpu: the scene-load half only, into a host store (functional check)")
     a = ap.parse_args()
     dev = torch.device(a.device)
     tmp = "/dev/shm/ss_loader_bench" if os.path.isdir("/dev/shm") else "/tmp/ss_loader_bench"
     rng = np.random.default_rng(0)
     out = {"tmpfs": tmp, "cores": len(os.sched_getaffinity(0)), "box": box_rates(dev), "scene_load": [], "miss_steps": []}
+    if a.profile_miss > 0:
+        sr = 16000
+        root = os.path.join(tmp, f"scene{sr}")
+        need = 4 * a.envs + (a.steps + 12) * max(1, int(round(a.profile_miss * a.envs)))
+        n_nodes = make_scene(root, sr, min(a.files, 512), max(need + 64, 4096), rng)
+        r = miss_steps(dev, root, sr, n_nodes, a.envs, a.profile_miss, a.steps, True, "deferred", O.synth_sources(rng, sr, k=8), profile=True)
+        print(json.dumps(r), flush=True)
+        shutil.rmtree(tmp, ignore_errors=True)
+        return
     for sr, n in ((16000, 2 * a.files), (44100, a.files)):
         root = os.path.join(tmp, f"scene{sr}")
         make_scene(root, sr, a.files if sr == 16000 else a.files // 2, n, rng)

@@ -233,7 +233,11 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
     const int n_rows = 2 * n_units;
     // small steps (the reference steps 5-10 envs per GPU at this rate): a row on 2 / 4 / 8 CUs, each rendering the row and
     // its share of every phase's pooled STFT blocks - only while every (row, part) still gets a workgroup of its own
-    p.parts_log2 = parts_log2_for(n_rows, n_cus);
+    // Time-domain bank: every part also repeats the row's stash round trip (640 KiB per row), and the launch turns
+    // memory-bound long before the CUs run out - same box, alternating, us per launch at 1 / 5 / 10 / 16 units with up to 8
+    // parts per row: 58.7 / 62.2 / 69.5 / 75.4 against 70.8 / 71.1 / 72.1 / 72.6 with one (profiles/r5/kbench_parts_44k.txt) -
+    // so the split stops at 96 workgroups there.  The spectral bank has no stash: -20 % up to 32 units (256 workgroups).
+    p.parts_log2 = parts_log2_for(n_rows, SPECTRAL ? n_cus : std::min(n_cus, 96));
     const int grid = (n_rows << p.parts_log2) < n_cus ? (n_rows << p.parts_log2) : n_cus;
     p.nb_y = p.n_valid == 0 ? 0 : (p.n_valid + ssk::kB - 1) / ssk::kB;
     p.stash = nullptr;
