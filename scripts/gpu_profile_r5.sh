@@ -1,25 +1,29 @@
 #!/bin/bash
-# Round-4 profile pass (run through gpurun): for every tracked configuration
+# Round-5 profile pass (run through gpurun): for every tracked configuration
 #   1. the bench line as the driver runs it (default flags of that config; the headline also at --steps 20 --warmup 5)
 #   2. rocprofv3 --kernel-trace --stats of a SINGLE-STREAM run of the same config          -> stats_<cfg>.txt
 # for the headline, cfg2 and cfg4: one --pmc pass per counter group (separate runs, no tracing domains mixed in) -> pmc_<cfg>.txt
 # and the FETCH_SIZE / WRITE_SIZE calibration on known byte counts (scripts/calib_traffic.hip)     -> calibration in traffic.json
-# -> traffic.json (keyed by the hash of the kernel sources).  Copy gpurun_out/prof_r4/* to profiles/r4/.
+# -> traffic.json (keyed by the hash of the kernel sources).  Copy gpurun_out/prof_r5/* to profiles/r5/.
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r4"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r5"
 rm -rf "$OUT"; mkdir -p "$OUT"
 declare -A CFG
 CFG[headline]=""
 CFG[headline_driver_protocol]="--steps 20 --warmup 5"
 CFG[cfg1]="--config cfg1"
 CFG[cfg2]="--config cfg2 --steps 40 --warmup 5"
+CFG[cfg3]="--config cfg3"
 CFG[cfg4]="--config cfg4 --steps 100"
 CFG[cfg4_no_features]="--config cfg4 --steps 100 --features none"
 CFG[replica44k_128]="--sr 44100 --envs 128 --steps 60 --warmup 5"
-for NAME in headline headline_driver_protocol cfg1 cfg2 cfg4 cfg4_no_features replica44k_128; do
+CFG[replica44k_10]="--sr 44100 --envs 10 --steps 100 --warmup 10"
+# every line carries its cpu_baseline (the oracle at the CONFIG's own rate and shape on the box's cores, ~16 s per line)
+for NAME in headline headline_driver_protocol cfg1 cfg2 cfg3 cfg4 cfg4_no_features replica44k_128 replica44k_10; do
   ARGS=${CFG[$NAME]}
-  EXTRA="--no-cpu-baseline"; [ "$NAME" = headline ] && EXTRA=""; [ "$NAME" = headline_driver_protocol ] && EXTRA=""
+  EXTRA=""; [ "$NAME" = cfg4_no_features ] && EXTRA="--no-cpu-baseline"
+  [ "$NAME" = headline ] || [ "$NAME" = headline_driver_protocol ] || EXTRA="$EXTRA --no-plugin-path"
   timeout 900 python bench.py $ARGS $EXTRA > "$OUT/bench_$NAME.json" 2> "$OUT/bench_$NAME.err" || echo "bench $NAME failed"
   [ "$NAME" = headline_driver_protocol ] && continue
   [ "$NAME" = cfg4_no_features ] && continue
@@ -141,7 +145,7 @@ rm -rf "$OUT"/pmc_headline "$OUT"/pmc_cfg2 "$OUT"/pmc_cfg4 "$OUT"/pmc_calib
 for f in "$OUT"/stats_*.txt; do echo "== $f"; cat "$f"; done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/prof_r4/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/prof_r5/bench_*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         print(f.split('/')[-1], 'value',d['value'], 'ms',d['ms_per_step'], 'roofline',d['roofline']['frac'], d['roofline']['avg_launch_ms'], 'pipe',d['roofline'].get('pipeline_frac'), {k:v.get('value') for k,v in d.items() if isinstance(v,dict) and 'value' in v and k not in ('roofline','cpu_baseline')})

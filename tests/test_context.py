@@ -441,6 +441,31 @@ def test_observe_features_equals_observe_then_feature_kernels(overlap):
         assert torch.equal(ag, ag0) and torch.equal(sg, sg0)
         assert float((lm - lm0).abs().max()) <= 5e-5 and float((gc - gc0).abs().max()) <= 5e-6
         assert not ag[2].any() and torch.allclose(lm[2], torch.full_like(lm[2], float(np.log(1e-6))), rtol=1e-6)
+    # ... and the ORACLE on what this entry point wrote (the entry cfg[4]'s bench line times): per stage - the oracle's
+    # features of the waveform the kernels rendered - at the north star's 1e-4, and END TO END - oracle waveform
+    # (simulator.py:629-664 restated) -> oracle feature - with the bound recorded here: the convolution's 1e-6 through log / PHAT
+    ag, sg, lm, gc, _ = got[0]
+    ag_np, c = ag.cpu().numpy(), cols[0]
+    worst = {"logmel": 0.0, "gccphat": 0.0, "logmel_e2e": 0.0, "gccphat_e2e": 0.0, "spectrogram_e2e": 0.0}
+    for i in range(n):
+        if c["rir"][i] < 0:
+            continue
+        lm_i, gc_i = lm[i].cpu().numpy(), gc[i].cpu().numpy()
+        ref_lm, ref_gc = O.compute_logmel(ag_np[i], SR), O.compute_gcc_phat(ag_np[i])
+        worst["logmel"] = max(worst["logmel"], float(np.abs(lm_i - ref_lm).max() / np.abs(ref_lm).max()))
+        worst["gccphat"] = max(worst["gccphat"], float(np.abs(gc_i - ref_gc).max()))
+        s_i = int(c["sound"][i])
+        a = O.compute_audiogoal(src[s_i], rirs[int(c["rir"][i])], SR, audio_index=int(c["t0"][i]) // SR,
+                                distractor=src[int(c["dis_sound"][i])], distractor_rir=rirs[int(c["dis_rir"][i])]).astype(np.float32)
+        assert O.relerr(ag_np[i], a) <= 1e-4
+        e_lm, e_gc = O.compute_logmel(a, SR), O.compute_gcc_phat(a)
+        worst["logmel_e2e"] = max(worst["logmel_e2e"], float(np.abs(lm_i - e_lm).max() / np.abs(e_lm).max()))
+        worst["gccphat_e2e"] = max(worst["gccphat_e2e"], float(np.abs(gc_i - e_gc).max()))
+        worst["spectrogram_e2e"] = max(worst["spectrogram_e2e"], O.relerr(sg[i].cpu().numpy(), O.compute_spectrogram(a)))
+    print("ss_ctx_observe_features vs oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert worst["logmel"] <= 1e-4 and worst["gccphat"] <= 1e-4 and worst["spectrogram_e2e"] <= 1e-4
+    # end to end the log of near-empty mel bands and the phase transform of near-zero bins amplify the waveform's 1e-6:
+    assert worst["logmel_e2e"] <= 2e-3 and worst["gccphat_e2e"] <= 2e-2
     ctx.set_overlap(1)
     sg = torch.empty((n, 65, 26, 2), device=dev)
     ctx.observe(spectrogram_out=sg, **cols[0])

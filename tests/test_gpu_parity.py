@@ -1134,7 +1134,6 @@ def test_continuous_steps_at_44k_both_forms(name):
     check(sg1[0].cpu().numpy(), ref_s)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("step_time,len_prev,sample_index", [(0.25, 20000, 50000), (0.25, 40000, 9000), (1.0, 30000, 70000)])
 def test_crossfaded_rows_at_44k_both_forms(step_time, len_prev, sample_index):
     """SS2.0 CROSSFADE at the reference's Replica rate (continuous_simulator.py:47-53, 413-426) against the oracle: the
@@ -1186,7 +1185,6 @@ def test_crossfaded_rows_at_44k_both_forms(step_time, len_prev, sample_index):
     check(sg3[1].cpu().numpy(), plain_s)
 
 
-@pytest.mark.gpu
 def test_wide_one_block_route_every_step_length():
     """Rows of 44100 samples rendered up to n_valid <= 16384 (SS2.0 steps of any length up to one block): the fused loop
     kernel in one launch (k_conv<..., WIDE>) against the oracle - both pad modes, with and without
@@ -1221,7 +1219,6 @@ def test_wide_one_block_route_every_step_length():
         assert not sg[2].any() and not ag2[2].any()
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cont_crossfade_44k", "cont_crossfade_48k"])
 def test_crossfade_44k_reference_run_vector_both_forms(name):
     """cont_crossfade_44k / _48k (the reference's own _compute_audiogoal with CROSSFADE on, a 0.25-s step; 48 kHz: the longest
@@ -1244,7 +1241,6 @@ def test_crossfade_44k_reference_run_vector_both_forms(name):
     check(sg1[0].cpu().numpy(), ref_s)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("has_distractor", [False, True])
 def test_batched_observer_record_path_on_gpu(has_distractor):
     """In-process vector envs (ss_baselines/common/sync_vector_env.py): ``VectorAudioObserver`` packs the step's simulator
@@ -1293,7 +1289,6 @@ def test_batched_observer_record_path_on_gpu(has_distractor):
     assert obs_a._rec["res"].native_steps > 0
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("spectral", [False, True])
 def test_deferred_column_path_on_gpu(spectral):
     """DeferredResolver on the C++ context (ss_amd/deferred.py::_columns -> AudioEngine.observe_columns -> ss_ctx_observe): the
@@ -1336,7 +1331,6 @@ def test_deferred_column_path_on_gpu(spectral):
     assert fast.engine.store.misses > 8                      # evictions happened under the resident-pair arrays
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("has_distractor", [False, True])
 def test_live_rir_branch_on_gpu(has_distractor):
     """soundspaces/simulator.py:625-626 (USE_RENDERED_OBSERVATIONS False: the RIR of the pose comes from the habitat_sim
@@ -1386,7 +1380,6 @@ def test_live_rir_branch_on_gpu(has_distractor):
         check_episode(episode(make, has_distractor), tol=TOL)
 
 
-@pytest.mark.gpu
 def test_core32_kernels_vs_oracle_and_1024_thread_core():
     """The 512-thread / 32-values-per-thread FFT core (csrc/ss_fft_core32.hpp; ss_source_windows32_f32 + ss_audio_obs32_f32)
     on 96 units incl. silent units, empty and ragged RIRs, a 0.25-s step: audiogoal and spectrogram against the 1024-thread
@@ -1445,7 +1438,6 @@ SWEEP_SS1 = [(16000, 0, "plain"), (16000, 1, "plain"), (22050, 2, "plain"), (441
              (16000, 5, "spectral"), (44100, 6, "spectral"), (16000, 7, "big"), (16000, 8, "constant_pad"), (44100, 9, "constant_pad")]
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("sr,seed,variant", SWEEP_SS1)
 def test_randomized_sweep_soundspaces1_through_the_context(sr, seed, variant):
     """Random steps of SoundSpaces-1.0 semantics (simulator.py:608-666) through ``ss_ctx_observe`` against the oracle: clips of
@@ -1505,7 +1497,6 @@ def test_randomized_sweep_soundspaces1_through_the_context(sr, seed, variant):
         assert not np.isnan(ag).any() and not np.isnan(sg).any()
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("sr,step_time,seed", [(16000, 0.25, 0), (16000, 0.1, 1), (16000, 1.0, 2), (44100, 0.25, 3),
                                                (44100, 0.4, 4), (44100, 1.0, 5), (48000, 0.25, 6)])
 def test_randomized_sweep_soundspaces2_through_the_context(sr, step_time, seed):
@@ -1554,7 +1545,6 @@ def test_randomized_sweep_soundspaces2_through_the_context(sr, step_time, seed):
             check(sg[u], O.compute_spectrogram(ref))
 
 
-@pytest.mark.gpu
 def test_overlap_mode_soak_under_window_cache_churn():
     """scripts/soak_ctx.py: 1200 steps with eight in flight on two overlap lanes, 167 (sound, second) keys against a window cache
     that has to evict on most steps - every output bit-identical to a single-stream context's (the overlap mode's
@@ -1571,7 +1561,6 @@ def test_overlap_mode_soak_under_window_cache_churn():
     assert m and int(m.group(1)) > 100, r.stdout[-500:]
 
 
-@pytest.mark.gpu
 def test_no_device_memory_leaks_over_long_runs():
     """scripts/leak_check.py: free HBM before / after 30 000 overlapped steps, 60 create / observe at 44.1 kHz with overlap /
     destroy cycles of a context (the per-stream stash of k_obs_rows), 1 500 deferred SoundSpaces-2.0 steps."""
@@ -1583,7 +1572,6 @@ def test_no_device_memory_leaks_over_long_runs():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.gpu
 def test_reference_run_vector_at_48k():
     """sim48k_multi_i1 (the reference's _compute_audiogoal at 48 kHz, 3-s clip, second 1) through the renderer and the context."""
     from ss_amd.context import AudioContext
