@@ -177,6 +177,67 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
             "store_misses": eng.store.misses}
 
 
+def walk_steps(dev, root, sr, n_nodes, n_envs, steps, prefetch, sources):
+    """Agent-like motion through a scene that is NOT resident: every env starts an episode at a random (receiver, source)
+    and per step turns left / right (same node, next azimuth) or moves forward to a neighbouring receiver, one action in
+    three each (habitat's MOVE_FORWARD / TURN_LEFT / TURN_RIGHT); a new episode every 40 steps.  Deferred mode, trainer half;
+    with and without the sibling-azimuth prefetch of DeferredResolver."""
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.rollout import RolloutStorage
+    NS = types.SimpleNamespace
+    rng = np.random.default_rng(5)
+    sounds = {"sound%d" % i: c for i, c in enumerate(sources)}
+
+    class DSim(SyntheticSim):
+        config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, HAS_DISTRACTOR_SOUND=False), USE_RENDERED_OBSERVATIONS=True)
+        binaural_rir_dir = root
+        azimuth_angle = property(lambda self: -(self._rotation_angle + 0) % 360)
+        current_source_sound = property(lambda self: self._source_sound_dict[self._current_sound])
+        _audio_length = property(lambda self: self.current_source_sound.shape[0] // sr)
+
+    eng = AudioEngine(sr, device=dev, rir_slots=4 * n_nodes * n_nodes)
+    res = DeferredResolver(eng, rir_reader=wav_rir_reader, fast=True, prefetch_azimuths=prefetch)
+    sims = [DSim(sounds, n_nodes, rng) for _ in range(n_envs)]
+    for i, sim in enumerate(sims):
+        sim._duration = 10 ** 9
+        attach_deferred(sim, env_rank=i)
+    space = NS(spaces={"spectrogram": NS(shape=P.spectrogram_shape(sr))})
+
+    class ActionSpace:
+        pass
+    rollouts = RolloutStorage(16, n_envs, space, ActionSpace(), 8, device=dev)
+    host, warm = [], 5
+    for k in range(warm + steps):
+        if k == warm:
+            sync()
+            m0, ms0 = eng.store.misses, res.miss_steps
+        for sim in sims:
+            if k % 40 == 0:                                     # episode start
+                sim._receiver_position_index, sim._source_position_index = int(rng.integers(0, n_nodes)), int(rng.integers(0, n_nodes))
+                sim._rotation_angle = 90 * int(rng.integers(0, 4))
+            else:
+                a = int(rng.integers(0, 3))
+                if a == 0:
+                    sim._receiver_position_index = int(np.clip(sim._receiver_position_index + (1 if rng.integers(0, 2) else -1), 0, n_nodes - 1))
+                else:
+                    sim._rotation_angle = (sim._rotation_angle + (90 if a == 1 else 270)) % 360
+            sim._episode_step_count += 1
+        obs = [{"spectrogram": sim.get_current_spectrogram_observation(None)} for sim in sims]
+        t0 = time.perf_counter()
+        res.resolve_observations(obs, rollouts, replace=False)
+        dt = time.perf_counter() - t0
+        rollouts.step = (rollouts.step + 1) % 16
+        if k >= warm:
+            host.append(dt)
+    sync()
+    return {"mode": "deferred, agent-like walk through a scene that is not resident", "prefetch_azimuths": prefetch, "envs": n_envs,
+            "steps": steps, "trainer_half_us_per_step_mean": round(1e6 * float(np.mean(host)), 1),
+            "trainer_half_us_per_step_median": round(1e6 * float(np.median(host)), 1),
+            "env_steps_per_s_trainer_half": round(n_envs / float(np.mean(host)), 1),
+            "files_read": eng.store.misses - m0, "steps_with_misses": res.miss_steps - ms0,
+            "poses_missing_per_step": round((eng.store.misses - m0 - res.prefetched * (1 if prefetch else 0)) / steps, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--files", type=int, default=2048, help="distinct files per rate (hard-linked to the scene's names)")
@@ -224,6 +285,10 @@ def main():
                 r = miss_steps(dev, root, sr, n_nodes, a.envs, rate, a.steps, native, mode, sources)
                 out["miss_steps"].append(r)
                 print(json.dumps(r), flush=True)
+    for prefetch in (True, False, True, False):
+        r = walk_steps(dev, root, sr, n_nodes, a.envs, 160, prefetch, sources)
+        out.setdefault("walk", []).append(r)
+        print(json.dumps(r), flush=True)
     shutil.rmtree(tmp, ignore_errors=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)

@@ -251,11 +251,19 @@ class DeferredResolver:
     continuous simulators); ``rir_reader(path) -> [L, 2] array or None`` as in ``sim_audio.wav_rir_reader``."""
 
     def __init__(self, engine, rir_reader: Optional[Callable[[str], Optional[np.ndarray]]] = None,
-                 fast: Optional[bool] = None):
+                 fast: Optional[bool] = None, prefetch_azimuths: bool = True):
         """fast: None = use the column path when the engine has one and every request of the step carries `rec`;
-        False = always walk the requests (per-unit Python planner); True = require the column path."""
+        False = always walk the requests (per-unit Python planner); True = require the column path.
+        prefetch_azimuths (column path): a pose that is not resident is loaded together with the OTHER azimuths of its
+        (receiver, source) pair - `<binaural_rir_dir>/{0,90,180,270}/<recv>_<src>.wav`, simulator.py:615-616 - in the same
+        read + upload: two of the agent's three actions are turns (`TURN_LEFT` / `TURN_RIGHT` keep the node), so the step after
+        a miss is usually a rotation of the same pair, and a miss STEP costs far more than a file (fixed ~0.2 ms against
+        ~20 us per file: scripts/bench_loader.py).  Files that do not exist are simply not prefetched."""
         from .sim_audio import wav_rir_reader
         self.engine = engine
+        self.prefetch_azimuths = bool(prefetch_azimuths)
+        self._siblings: Dict[int, list] = {}      # table id -> ids of the other azimuth tables of its RIR directory
+        self.prefetched = 0
         self.rir_reader = rir_reader or wav_rir_reader
         self._clips: Dict[str, np.ndarray] = {}
         self._live: Dict[int, list] = {}          # env -> [held arrays, slots, turn] (see HipContinuousSimAudio)
@@ -425,6 +433,8 @@ class DeferredResolver:
         ks = np.unique(np.asarray(pair_keys)[which].astype(np.int64))
         if ks.shape[0] == 0:
             return
+        if self.prefetch_azimuths and not reload:
+            ks = self._with_sibling_azimuths(ks)
         paths = [os.path.join(self._table_dirs[int(k) >> 40], "{}_{}.wav".format((int(k) >> 20) & 0xFFFFF, int(k) & 0xFFFFF))
                  for k in ks]
         from .renderer import _native_wav
@@ -445,6 +455,46 @@ class DeferredResolver:
             self._pair_keys = np.insert(self._pair_keys, pos[~have], ks[~have])
             self._pair_slots = np.insert(self._pair_slots, pos[~have], slots[~have])
         self._tables = None
+
+    def _sibling_tables(self, t: int) -> list:
+        """ids of the other azimuth directories next to table t's (`<binaural_rir_dir>/<azimuth>`), registered on first need"""
+        sib = self._siblings.get(t)
+        if sib is None:
+            d = self._table_dirs[t]
+            parent, az = os.path.split(d)
+            sib = []
+            if az in ("0", "90", "180", "270"):
+                for other in ("0", "90", "180", "270"):
+                    od = os.path.join(parent, other)
+                    if other == az or not os.path.isdir(od):
+                        continue
+                    key = name_key(od)
+                    if key not in self._key_names:
+                        self._learn_table(os.path.join(od, "x.wav"))
+                    elif self._key_names[key] != od:
+                        continue
+                    sib.append(self._table_dirs.index(od))
+            self._siblings[t] = sib
+        return sib
+
+    def _with_sibling_azimuths(self, ks: np.ndarray) -> np.ndarray:
+        """ks + the same (receiver, source) under the other azimuth directories, where that file exists and is not resident"""
+        extra = []
+        for k in ks.tolist():
+            t, rest = k >> 40, k & ((1 << 40) - 1)
+            for o in self._sibling_tables(t):
+                k2 = (o << 40) | rest
+                pos = int(np.searchsorted(self._pair_keys, k2))
+                if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == k2:
+                    continue
+                if os.path.exists(os.path.join(self._table_dirs[o], "{}_{}.wav".format((rest >> 20) & 0xFFFFF, rest & 0xFFFFF))):
+                    extra.append(k2)
+        store = self.engine.store
+        room = len(getattr(store, "_free", ())) * getattr(store, "group", 1) - int(ks.shape[0])
+        if not extra or room < len(extra):                  # best effort: never evict resident poses for a guess
+            return ks
+        self.prefetched += len(extra)
+        return np.unique(np.concatenate([ks, np.asarray(extra, np.int64)]))
 
     def _live_columns(self, requests: Sequence[AudioRequest]):
         """A step whose requests carry NUMBERED live RIRs (SoundSpaces 2.0 workers: every env a new RIR every step,

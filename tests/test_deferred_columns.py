@@ -288,3 +288,48 @@ def test_native_record_path_serves_its_misses_and_calls_again(has_distractor, sl
         assert eng.store.misses > 6
         for k, slot in zip(fast._pair_keys.tolist(), fast._pair_slots.tolist()):
             assert eng.store._slot_of[("ix", k)] == slot
+
+
+def test_pose_miss_prefetches_the_other_azimuths_of_the_pair(tmp_path):
+    """A pose that is not resident is loaded together with the other azimuths of its (receiver, source) pair
+    (`<binaural_rir_dir>/{0,90,180,270}/<recv>_<src>.wav`, simulator.py:615-616): the rotation that usually follows is then a
+    plain hit of the C record path.  Real float32 wav files, the stock reader (-> the library's native reader); a missing
+    sibling file is simply not prefetched, and a full store prefetches nothing."""
+    from scipy.io import wavfile
+    from ss_amd.sim_audio import wav_rir_reader
+    rng = np.random.default_rng(8)
+    sounds, _ = make_world()
+    rirs = {}
+    for az in (0, 90, 180, 270):
+        (tmp_path / str(az)).mkdir()
+        for r in (3, 4):
+            if (az, r) == (270, 4):
+                continue                                        # one sibling file does not exist
+            h = np.ascontiguousarray(O.synth_rir(rng, SR, n=1)[0].T)
+            wavfile.write(str(tmp_path / str(az) / f"{r}_7.wav"), SR, h)
+            rirs[(az, r)] = h
+    sim = FakeSim(SR, sounds, {})
+    sim.binaural_rir_dir = str(tmp_path)
+    attach_deferred(sim, env_rank=0)
+    eng = OracleColumnEngine(SR, slots=16).enable_native_requests()
+    res = DeferredResolver(eng, rir_reader=wav_rir_reader)
+
+    def observe(rot, recv):
+        sim._rotation_angle, sim._receiver_position_index = rot, recv
+        sim._episode_step_count += 1
+        out = res.resolve([pickle.loads(pickle.dumps(sim.get_current_spectrogram_observation(None)))], want_audiogoal=True)
+        ref = O.compute_audiogoal(sounds[sim._current_sound], rirs[(sim.azimuth_angle, recv)], SR)
+        assert O.relerr(out["audiogoal"][0].numpy(), ref) < 1e-5
+    observe(270, 3)                                             # azimuth 90: a miss; 0 / 180 / 270 of (3, 7) come along
+    assert eng.store.misses == 4 and res.prefetched == 3 and res.miss_steps == 1
+    for rot in (0, 90, 180):                                    # the rotations: hits, no miss step
+        observe(rot, 3)
+    assert eng.store.misses == 4 and res.miss_steps == 1
+    observe(270, 4)                                             # (4, 7): its azimuth-270 file does not exist -> 3 files
+    assert eng.store.misses == 7 and res.prefetched == 5
+    small = DeferredResolver(OracleColumnEngine(SR, slots=2).enable_native_requests(), rir_reader=wav_rir_reader)
+    sim2 = FakeSim(SR, sounds, {})                              # (a fresh worker: it ships the clip with its first request)
+    sim2.binaural_rir_dir = str(tmp_path)
+    attach_deferred(sim2, env_rank=0)
+    small.resolve([sim2.get_current_spectrogram_observation(None)], want_audiogoal=True)
+    assert small.prefetched == 0 and small.engine.store.misses == 1
