@@ -112,44 +112,64 @@ inline uint16_t le16(const unsigned char* p) { return static_cast<uint16_t>(p[0]
 
 // One file -> one row.  dst: [cap][2] floats (interleaved) or, planar, dst[c * cap + n].  keep < 0: the whole file.
 // frames_out: frames the FILE holds (the caller learns whether the row was clipped); returns the Status, *kept = frames stored.
+// Four system calls per file - open, one read of the first 4 KiB (RIFF header, "fmt ", any LIST chunk and the start of the
+// samples), one read of the rest straight into the row, close: a step that loads a handful of new poses is bound by the
+// latency of these calls, not by the bytes (the first version parsed the header with one read per field: nine calls).
+constexpr int kHeadBytes = 4096;
 inline int read_one(const char* path, float* dst, int cap, int keep, bool planar, int* kept, int* frames_out,
                     std::vector<float>& scratch) {
     *kept = 0; *frames_out = 0;
     const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return kMissing;
     struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
-    unsigned char h[12];
-    if (!read_exact(fd, h, 12) || std::memcmp(h, "RIFF", 4) != 0 || std::memcmp(h + 8, "WAVE", 4) != 0) return kUnsupported;
+    alignas(8) unsigned char head[kHeadBytes];
+    size_t have = 0;
+    for (;;) {                                                  // (a short read is legal: keep reading until 4 KiB or EOF)
+        const ssize_t r = ::read(fd, head + have, kHeadBytes - have);
+        if (r < 0) { if (errno == EINTR) continue; return kUnsupported; }
+        if (r == 0) break;
+        have += static_cast<size_t>(r);
+        if (have == kHeadBytes) break;
+    }
+    if (have < 12 || std::memcmp(head, "RIFF", 4) != 0 || std::memcmp(head + 8, "WAVE", 4) != 0) return kUnsupported;
     bool have_fmt = false;
     int channels = 0, bits = 0, tag = 0, block_align = 0;
+    size_t pos = 12;
     for (;;) {
-        unsigned char ch[8];
-        if (!read_exact(fd, ch, 8)) return kUnsupported;          // no data chunk / truncated header: scipy's call
+        if (pos + 8 > have) return kUnsupported;               // no data chunk within the first 4 KiB / truncated header
+        const unsigned char* ch = head + pos;
         const uint32_t sz = le32(ch + 4);
+        pos += 8;
         if (std::memcmp(ch, "fmt ", 4) == 0) {
-            unsigned char f[40];
-            if (sz < 16 || sz > 40 || !read_exact(fd, f, sz)) return kUnsupported;
+            if (sz < 16 || sz > 40 || pos + sz > have) return kUnsupported;
+            const unsigned char* f = head + pos;
             tag = le16(f); channels = le16(f + 2); block_align = le16(f + 12); bits = le16(f + 14);
             if (tag == 0xFFFE && sz >= 26) tag = le16(f + 24);    // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
-            if (sz & 1) { unsigned char pad; if (!read_exact(fd, &pad, 1)) return kUnsupported; }
             have_fmt = true;
+            pos += sz + (sz & 1);
         } else if (std::memcmp(ch, "data", 4) == 0) {
             if (!have_fmt || tag != 3 || bits != 32 || channels != 2 || block_align != 8) return kUnsupported;
-            struct stat st;
-            if (::fstat(fd, &st) != 0) return kUnsupported;
-            const off_t pos = ::lseek(fd, 0, SEEK_CUR);
-            if (pos < 0 || static_cast<uint64_t>(st.st_size - pos) < sz) return kUnsupported;   // truncated data chunk
             const int frames = static_cast<int>(sz / 8);
             *frames_out = frames;
             if (frames == 0) return kEmpty;
             const int n = keep >= 0 && keep < frames ? keep : frames;
             if (n > cap) return kTooLong;
+            const size_t want = static_cast<size_t>(n) * 8;                          // bytes of samples to store
+            const size_t in_head = have - pos < want ? have - pos : want;            // ... of which the first read holds
+            float* tgt = dst;
+            if (planar) { scratch.resize(static_cast<size_t>(n) * 2); tgt = scratch.data(); }
+            std::memcpy(tgt, head + pos, in_head);
+            if (in_head < want) {
+                if (have < static_cast<size_t>(kHeadBytes)) return kUnsupported;      // EOF inside the data chunk: truncated
+                if (!read_exact(fd, reinterpret_cast<char*>(tgt) + in_head, want - in_head)) return kUnsupported;
+            }
+            if (n < frames) {                                     // a clipped read: the bytes asked for arrived, but a file cut
+                struct stat st;                                   // short BEHIND them is not what scipy would have accepted
+                if (::fstat(fd, &st) != 0 || static_cast<uint64_t>(st.st_size) < pos + sz) return kUnsupported;
+            }
             if (!planar) {
-                if (!read_exact(fd, dst, static_cast<size_t>(n) * 8)) return kUnsupported;
                 std::memset(dst + static_cast<size_t>(n) * 2, 0, static_cast<size_t>(cap - n) * 8);
             } else {
-                scratch.resize(static_cast<size_t>(n) * 2);
-                if (!read_exact(fd, scratch.data(), static_cast<size_t>(n) * 8)) return kUnsupported;
                 for (int c = 0; c < 2; ++c) {
                     float* row = dst + static_cast<size_t>(c) * cap;
                     for (int i = 0; i < n; ++i) row[i] = scratch[2 * static_cast<size_t>(i) + c];
@@ -159,7 +179,7 @@ inline int read_one(const char* path, float* dst, int cap, int keep, bool planar
             *kept = n;
             return kOk;
         } else {                                                   // LIST, fact, ...: skipped (word-aligned)
-            if (::lseek(fd, static_cast<off_t>(sz) + (sz & 1), SEEK_CUR) < 0) return kUnsupported;
+            pos += static_cast<size_t>(sz) + (sz & 1);
         }
     }
 }

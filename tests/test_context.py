@@ -464,8 +464,8 @@ def test_observe_features_equals_observe_then_feature_kernels(overlap):
         worst["spectrogram_e2e"] = max(worst["spectrogram_e2e"], O.relerr(sg[i].cpu().numpy(), O.compute_spectrogram(a)))
     print("ss_ctx_observe_features vs oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
     assert worst["logmel"] <= 1e-4 and worst["gccphat"] <= 1e-4 and worst["spectrogram_e2e"] <= 1e-4
-    # end to end the log of near-empty mel bands and the phase transform of near-zero bins amplify the waveform's 1e-6:
-    assert worst["logmel_e2e"] <= 2e-3 and worst["gccphat_e2e"] <= 2e-2
+    # end to end as well (measured on the MI355X: log-mel 1.5e-5, GCC-PHAT 5.7e-6, spectrogram 4.9e-7; per stage 1.1e-6 / 5.7e-6)
+    assert worst["logmel_e2e"] <= 1e-4 and worst["gccphat_e2e"] <= 1e-4
     ctx.set_overlap(1)
     sg = torch.empty((n, 65, 26, 2), device=dev)
     ctx.observe(spectrogram_out=sg, **cols[0])

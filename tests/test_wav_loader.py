@@ -38,6 +38,12 @@ def wavs(tmp_path_factory):
     body = body[:4] + (len(body) - 8).to_bytes(4, "little") + body[8:]
     files["list"] = str(d / "list.wav")
     open(files["list"], "wb").write(body)
+    # the data chunk cut short BEHIND the frames a clipped read keeps (keep = 16000 of 40000): still not a file scipy reads
+    files["long_trunc"] = str(d / "long_trunc.wav")
+    open(files["long_trunc"], "wb").write(open(files["long"], "rb").read()[:200000])
+    # a tiny file: header and samples inside the reader's first 4-KiB read
+    files["tiny"] = str(d / "tiny.wav")
+    wavfile.write(files["tiny"], 16000, rng.standard_normal((300, 2)).astype(np.float32))
     files["missing"] = str(d / "missing.wav")
     return files
 
@@ -50,7 +56,8 @@ def test_native_reader_equals_scipy_and_reports_what_it_does_not_read(wavs):
         dst = np.full((len(paths), 2, cap) if planar else (len(paths), cap, 2), 7.0, np.float32)
         kept, frames, status = _lib.wav_read_rirs(paths, dst, cap, keep=16000, planar=planar, threads=3)
         st = dict(zip(names, status))
-        assert [st[n] for n in ("a", "ragged", "one", "list")] == [_lib.WAV_OK] * 4
+        assert [st[n] for n in ("a", "ragged", "one", "list", "tiny")] == [_lib.WAV_OK] * 5
+        assert st["long_trunc"] == _lib.WAV_UNSUPPORTED
         assert st["empty"] == _lib.WAV_EMPTY and st["missing"] == _lib.WAV_MISSING
         assert st["i16"] == st["mono"] == st["junk"] == st["trunc"] == _lib.WAV_UNSUPPORTED
         assert st["long"] == _lib.WAV_OK and dict(zip(names, kept))["long"] == 16000 and dict(zip(names, frames))["long"] == 40000
