@@ -234,8 +234,7 @@ def walk_steps(dev, root, sr, n_nodes, n_envs, steps, prefetch, sources):
             "steps": steps, "trainer_half_us_per_step_mean": round(1e6 * float(np.mean(host)), 1),
             "trainer_half_us_per_step_median": round(1e6 * float(np.median(host)), 1),
             "env_steps_per_s_trainer_half": round(n_envs / float(np.mean(host)), 1),
-            "files_read": eng.store.misses - m0, "steps_with_misses": res.miss_steps - ms0,
-            "poses_missing_per_step": round((eng.store.misses - m0 - res.prefetched * (1 if prefetch else 0)) / steps, 2)}
+            "files_read": eng.store.misses - m0, "steps_with_misses": res.miss_steps - ms0, "files_prefetched_in_all": res.prefetched}
 
 
 def main():
@@ -285,10 +284,11 @@ def main():
                 r = miss_steps(dev, root, sr, n_nodes, a.envs, rate, a.steps, native, mode, sources)
                 out["miss_steps"].append(r)
                 print(json.dumps(r), flush=True)
-    for prefetch in (True, False, True, False):
-        r = walk_steps(dev, root, sr, n_nodes, a.envs, 160, prefetch, sources)
-        out.setdefault("walk", []).append(r)
-        print(json.dumps(r), flush=True)
+    for envs in (8, a.envs):                                    # the reference's per-GPU env count, and the headline's
+        for prefetch in (True, False, True, False):
+            r = walk_steps(dev, root, sr, n_nodes, envs, 320 if envs < 32 else 160, prefetch, sources)
+            out.setdefault("walk", []).append(r)
+            print(json.dumps(r), flush=True)
     shutil.rmtree(tmp, ignore_errors=True)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)

@@ -18,7 +18,13 @@ timeout 900 python bench.py > "$OUT/bench_headline.json" 2> "$OUT/bench_headline
 timeout 900 python bench.py --config cfg2 --steps 40 --warmup 5 --no-plugin-path > "$OUT/bench_cfg2.json" 2> "$OUT/bench_cfg2.err"
 timeout 900 python bench.py --config cfg4 --steps 100 --no-plugin-path > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
 timeout 600 python scripts/bench_loader.py --out "$OUT/loader.json" > "$OUT/loader.log" 2>&1; echo "loader rc=$?"
-timeout 300 python scripts/bench_deferred_continuous.py > "$OUT/bench_deferred_continuous.json" 2> /dev/null; cat "$OUT/bench_deferred_continuous.json"
+# SS2.0 deferred: the live-column path and, on the SAME box, round 4's per-request walk (alternating: host speed differs box to box)
+: > "$OUT/bench_deferred_continuous.jsonl"
+for i in 1 2 3; do
+  timeout 300 python scripts/bench_deferred_continuous.py >> "$OUT/bench_deferred_continuous.jsonl" 2> /dev/null
+  timeout 300 python scripts/bench_deferred_continuous.py --walk >> "$OUT/bench_deferred_continuous.jsonl" 2> /dev/null
+done
+cut -c1-330 "$OUT/bench_deferred_continuous.jsonl"
 timeout 600 python scripts/bench_boundary.py > "$OUT/bench_boundary.jsonl" 2> "$OUT/bench_boundary.err"; echo "boundary rc=$?"
 timeout 300 python scripts/prof_eager.py > "$OUT/prof_eager.txt" 2>&1; echo "eager rc=$?"; grep "^eager" "$OUT/prof_eager.txt"
 timeout 300 python scripts/kbench_features.py > "$OUT/kbench_features.json" 2>/dev/null; cat "$OUT/kbench_features.json"

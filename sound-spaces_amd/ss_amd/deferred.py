@@ -250,6 +250,8 @@ class DeferredResolver:
     """Trainer side: N requests -> one launch.  ``engine`` = ``ss_amd.renderer.AudioEngine`` (an SS2.0 one for
     continuous simulators); ``rir_reader(path) -> [L, 2] array or None`` as in ``sim_audio.wav_rir_reader``."""
 
+    PREFETCH_MAX_POSES = 4                      # new poses per step up to which their sibling azimuths are loaded along
+
     def __init__(self, engine, rir_reader: Optional[Callable[[str], Optional[np.ndarray]]] = None,
                  fast: Optional[bool] = None, prefetch_azimuths: bool = True):
         """fast: None = use the column path when the engine has one and every request of the step carries `rec`;
@@ -258,7 +260,10 @@ class DeferredResolver:
         (receiver, source) pair - `<binaural_rir_dir>/{0,90,180,270}/<recv>_<src>.wav`, simulator.py:615-616 - in the same
         read + upload: two of the agent's three actions are turns (`TURN_LEFT` / `TURN_RIGHT` keep the node), so the step after
         a miss is usually a rotation of the same pair, and a miss STEP costs far more than a file (fixed ~0.2 ms against
-        ~20 us per file: scripts/bench_loader.py).  Files that do not exist are simply not prefetched."""
+        ~20 us per file: scripts/bench_loader.py).  Only for steps with at most PREFETCH_MAX_POSES new poses - the reference's
+        5-10 envs per GPU, where the prefetch turns most steps into plain hits; a 128-env step has some env on a new pose
+        nearly every time, pays the fixed cost anyway and would only read the files earlier (measured: -7 %).  Files that do
+        not exist are simply not prefetched."""
         from .sim_audio import wav_rir_reader
         self.engine = engine
         self.prefetch_azimuths = bool(prefetch_azimuths)
@@ -433,7 +438,7 @@ class DeferredResolver:
         ks = np.unique(np.asarray(pair_keys)[which].astype(np.int64))
         if ks.shape[0] == 0:
             return
-        if self.prefetch_azimuths and not reload:
+        if self.prefetch_azimuths and not reload and ks.shape[0] <= self.PREFETCH_MAX_POSES:
             ks = self._with_sibling_azimuths(ks)
         paths = [os.path.join(self._table_dirs[int(k) >> 40], "{}_{}.wav".format((int(k) >> 20) & 0xFFFFF, int(k) & 0xFFFFF))
                  for k in ks]
