@@ -812,6 +812,19 @@ def main():
             if evs:
                 region_ev.append([evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if per_step_events
                                  else [evs[0].elapsed_time(evs[1]) / args.steps])
+        if use_ctx and cx is None and world == 1:
+            # host time of ONE product-path call (planner + window cache + descriptor ring + launch inside ss_ctx_observe, plus
+            # the bound Python call): each call timed on its own, launch queue kept shallow.  Small steps are bound by THIS,
+            # not by the kernel (a 32-env launch on two lanes is 10 us of GPU time per step: profiles/r5/kbench_lanes.txt)
+            hs = []
+            for k in range(256):
+                t_h = time.perf_counter()
+                step(k % len(descs))
+                hs.append(time.perf_counter() - t_h)
+                if k % 32 == 31:
+                    ctx.join()
+                    torch.cuda.synchronize()
+            state["host_us_per_call"] = round(1e6 * float(np.median(hs)), 2)
         if sustain_s > 0 and world == 1:
             # a run long enough for an outside observer (rocm-smi samples once a second): the same steps, cycled over every
             # prepared step of the run (500+ distinct steps over a 1-GiB bank), for ~sustain_s seconds between two fences
@@ -846,10 +859,12 @@ def main():
         last_regions[:] = region_s
         last_sustained.clear()
         last_sustained.update(state.get("sustained") or {})
+        last_host[:] = [state.get("host_us_per_call")]
         return elapsed, per_step, note
 
     last_regions = []
     last_sustained = {}
+    last_host = [None]
     spectra = None
     if args.spectral or not args.no_secondary:
         r.rirs.build_spectra()
@@ -864,6 +879,7 @@ def main():
     elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, lanes=LANES, regions=REGIONS, sustain_s=args.sustain)
     head_regions = list(last_regions)
     head_sustained = dict(last_sustained)
+    head_host_us = last_host[0]
     side = {}
     step_dist = None
     # ---- the kernel's own rate: pre-planned descriptors, ONE stream - per-launch durations are separable only without
@@ -952,6 +968,7 @@ def main():
                               **{k_: round(world * N * args.steps / float(np.quantile(head_regions, q_)), 1)
                                  for k_, q_ in (("min", 1.0), ("p10", 0.9), ("p90", 0.1), ("max", 0.0))}}),
             "sustained": head_sustained or None,
+            "host_us_per_call": head_host_us,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": n_env, "rotations": rot, "units_per_gpu": N,
