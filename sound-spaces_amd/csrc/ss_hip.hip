@@ -91,7 +91,9 @@ inline bool fill_unit_tab(ssk::UnitTab<true>& ut, const int* host_desc, int n_un
     // Word 2 of an entry = the unit the row's results belong to, so the caller's order of outputs is untouched.
     static const bool no_sort = ab_flag("SS_HIP_NO_SORT");            // (A/B builds only)
     unsigned key[ssk::kTabUnits];                                     // (slot << 8) | unit: 32-bit keys, ~1 us for 128 units
-    bool sortable = !no_sort && n_units > 8;
+    // (steps of >= 64 units only: with fewer, few rows share a spectrum and the ~2 us of host time per call - measured:
+    // 13.9 vs 11.7 us at 128 units - are the bottleneck of a small step, not its bytes)
+    bool sortable = !no_sort && n_units >= 64;
     for (int i = 0; i < n_units; ++i) {
         const int* d = host_desc + 8 * i;
         const bool ok = d[0] >= 0 && d[2] <= 0 && d[2] + d[3] > 0;          // window m = 0 of the unit's key is stored
