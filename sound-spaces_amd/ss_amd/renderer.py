@@ -749,6 +749,8 @@ class RirStore:
         """Column paths (``DeferredResolver``, tables of ``RirIndex``) look slots up without going through ``slot()``: this
         marks them as handed out for the current batch, so that a miss of the same step cannot evict them."""
         self._batch_of[slots] = self._batch
+        if self.group > 1:                                       # recency and the in-use guard live on a group's FIRST slot
+            self._batch_of[(np.asarray(slots) // self.group) * self.group] = self._batch
 
     def slot(self, key, loader, refresh: bool = False) -> int:
         """Bank slot of ``key`` (first slot of its group); ``loader()`` -> float array [L,2] / [2,L] or None (a list of
