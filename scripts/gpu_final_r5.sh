@@ -4,7 +4,7 @@
 # traffic.json in place under profiles/r5/ - the headline lines again so that roofline.traffic is filled in; the RIR miss path
 # (scripts/bench_loader.py), SS2.0 deferred mode, the boundary modes, the eager profile, the feature kernels.  Everything lands
 # in gpurun_out/prof_r5/ (copy to profiles/r5/).  The same-box A/B files of the round (kbench_parts_*.txt, kbench_lanes.txt,
-# ab_sort_*.json) come from scripts/gpu_r5_[a-c].sh with the -DSS_AB library.
+# ab_sort_*.json) come from scripts/gpu_r5_{a,b,c,f}.sh with the -DSS_AB library (prebuilt into gpurun_in/).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r5"
