@@ -1104,6 +1104,68 @@ class BucketedRirStore:
         return out
 
 
+    def load_files(self, keys: Sequence, paths: Sequence, reader=None, missing_ok: bool = False, threads: int = 0,
+                   new_batch: bool = True) -> List[int]:
+        """``RirStore.load_files`` over the length buckets: the files' frame counts are probed first (the library's reader with
+        a one-frame row: header only, nothing copied), every key goes to the smallest bucket that holds its (longest) RIR and
+        each bucket loads its files through its sub-store's native path."""
+        from . import _lib
+        G = self.group
+        out: List[int] = [-1] * len(keys)
+        todo = []
+        for i, key in enumerate(keys):
+            b = self._where.get(key)
+            if b is not None and key in self.stores[b]._slot_of:
+                st = self.stores[b]
+                sl = st._slot_of[key]
+                if st.truncate_to is None and st._clipped[sl:sl + G].any():
+                    plist = [paths[i]] if G == 1 else list(paths[i])
+                    rd = reader
+                    if rd is None:
+                        from .sim_audio import wav_rir_reader as rd
+                    out[i] = self.slot(key, (lambda pl=plist, rd=rd: rd(pl[0]) if G == 1 else [rd(p) if p else None for p in pl]))
+                else:
+                    out[i] = self.first[b] + st.slot(key, lambda: None)
+            else:
+                todo.append(i)
+        first = {}
+        for i in todo:
+            first.setdefault(keys[i], i)
+        uniq = list(first.values())
+        flat = [(i, p) for i in uniq for p in ([paths[i]] if G == 1 else list(paths[i])) if p]
+        probe = np.zeros((max(len(flat), 1), 1, 2), np.float32)
+        _kept, frames, status = _lib.wav_read_rirs([p for _, p in flat], probe, 1, keep=-1, threads=threads)
+        longest: Dict[int, int] = {i: 0 for i in uniq}
+        keep0 = self.stores[0]._kept_len
+        for (i, pth), fr, st_ in zip(flat, frames, status):
+            n = int(fr)
+            if st_ == _lib.WAV_UNSUPPORTED:                       # odd file: the Python reader decides (and gives its length)
+                rd = reader
+                if rd is None:
+                    from .sim_audio import wav_rir_reader as rd
+                n = _planar(rd(pth)).shape[1]
+            longest[i] = max(longest[i], keep0(n))
+        per_bucket: Dict[int, List[int]] = {}
+        for i in uniq:
+            b = len(self.stores) - 1
+            for bb, st in enumerate(self.stores[:-1]):
+                if longest[i] <= st.cap:
+                    b = bb
+                    break
+            per_bucket.setdefault(b, []).append(i)
+        for b, idx in per_bucket.items():
+            got = self.stores[b].load_files([keys[i] for i in idx], [paths[i] for i in idx], reader=reader, missing_ok=missing_ok,
+                                            threads=threads, new_batch=new_batch)
+            for i, sl in zip(idx, got):
+                self._where[keys[i]] = b
+                out[i] = self.first[b] + sl
+        for i in todo:
+            if out[i] < 0:
+                b = self._where[keys[i]]
+                out[i] = self.first[b] + self.stores[b]._slot_of[keys[i]]
+        return out
+
+
 def load_scene_rirs(store: "RirStore", scene_rir_dir: str, reader, azimuths=(0, 90, 180, 270), limit: Optional[int] = None,
                     batch: int = 256, workers: int = 8):
     """Bulk pre-load of one scene's binaural RIRs, `<scene_rir_dir>/<azimuth>/<receiver>_<source>.wav`

@@ -136,3 +136,23 @@ def test_load_scene_rirs_takes_the_native_reader_for_the_stock_reader(wavs, tmp_
             p = os.path.join(str(tmp_path), str(az), f"{r}_0.wav")
             sl = s1.slot(p, lambda: pytest.fail("resident"))
             assert np.array_equal(s1.bank.data[sl].numpy()[:, :500 + r], wav_rir_reader(p).T)
+
+
+def test_bucketed_store_load_files_routes_by_probed_length(wavs):
+    """BucketedRirStore.load_files: frame counts probed by the library's reader (header only), every file into the smallest
+    bucket that holds it, same rows / lengths as the Python-reader path (slot_many)."""
+    from ss_amd.renderer import BucketedRirStore
+    names = ["a", "ragged", "long", "empty", "i16", "junk", "tiny", "a"]
+    paths = [wavs[n] for n in names]
+    s1 = BucketedRirStore([8, 4], [16000, 65536], "cpu", truncate_to=None)
+    s2 = BucketedRirStore([8, 4], [16000, 65536], "cpu", truncate_to=None)
+    got = s1.load_files(paths, paths)
+    ref = s2.slot_many(paths, [(lambda p=p: wav_rir_reader(p)) for p in paths], workers=1)
+    assert got[0] == got[-1] and ref[0] == ref[-1]
+    assert s1.bank.bucket_of(got[names.index("long")]) == 1 and s1.bank.bucket_of(got[names.index("a")]) == 0
+    for g, r_ in zip(got, ref):                                 # (slot numbers may differ: the order of loading does)
+        b = s1.bank.bucket_of(g)
+        assert b == s2.bank.bucket_of(r_)
+        assert np.array_equal(s1.stores[b].bank.data[g - s1.first[b]].numpy(), s2.stores[b].bank.data[r_ - s2.first[b]].numpy())
+        assert s1.host_len[g] == s2.host_len[r_]
+    assert s1.load_files(paths, paths) == got                  # hits
