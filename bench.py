@@ -825,6 +825,20 @@ def main():
                     ctx.join()
                     torch.cuda.synchronize()
             state["host_us_per_call"] = round(1e6 * float(np.median(hs)), 2)
+            if os.environ.get("SS_AB_HOST_PROFILE") and hasattr(ctx.lib, "ss_ab_host_profile"):
+                # -DSS_AB libraries only (scripts/gpu_host_profile.sh): the call's host time by segment, queue kept shallow
+                import ctypes
+                ns, calls = (ctypes.c_double * 8)(), ctypes.c_longlong(0)
+                ctx.lib.ss_ab_host_profile(ns, ctypes.byref(calls))
+                for k in range(512):
+                    step(k % len(descs))
+                    if k % 32 == 31:
+                        ctx.join()
+                        torch.cuda.synchronize()
+                ctx.lib.ss_ab_host_profile(ns, ctypes.byref(calls))
+                names = ("input_fence", "lane_waits", "ring_slot", "planner", "windows", "launch", "group_event", "-")
+                print("host_profile_us " + json.dumps({"calls": calls.value, **{nm: round(v / max(calls.value, 1) / 1e3, 2)
+                                                                                for nm, v in zip(names, ns)}}), file=sys.stderr, flush=True)
         if sustain_s > 0 and world == 1:
             # a run long enough for an outside observer (rocm-smi samples once a second): the same steps, cycled over every
             # prepared step of the run (500+ distinct steps over a 1-GiB bank), for ~sustain_s seconds between two fences

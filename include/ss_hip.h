@@ -367,6 +367,15 @@ int ss_ctx_stats(ss_ctx* ctx, long long* out8);
  * status are zero-filled.  Returns 0 / SS_EINVAL. */
 int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst, long long row_stride, int cap, int keep, int planar,
                          int* kept_out, int* frames_out, int* status_out, int n_threads);
+/* The miss path's last hop: n staged rows in wav layout - row i = frames j < lens[i] as (L, R) pairs at
+ * staged[i*staged_row_stride + 2*j + c] - into the planar bank rows bank[slots[i]*unit_stride + c*chan_stride + j], zeros
+ * behind each row's length up to `cap`, and lens[i] into bank_len[slots[i]] (bank_len may be NULL).  `staged`, `slots`
+ * and `lens` may be PINNED HOST memory (the kernel pulls the samples over the host link: one launch, no staging copy) or
+ * device memory; bank / bank_len are device memory.  Asynchronous on `stream`: the caller keeps the staged block alive and
+ * unchanged until the launch has run.  Replaces the reference's per-file host path simulator.py:615-624 -> numpy -> (no
+ * device at all there) for what follows ss_wav_read_rirs_f32 / ss_rows_gather_f32.  Returns 0 / SS_EINVAL / -hipError_t. */
+int ss_bank_scatter_rows_f32(const float* staged, long long staged_row_stride, const int* slots, const int* lens, int n,
+                             float* bank, long long unit_stride, int chan_stride, int cap, int* bank_len, void* stream);
 /* n HOST arrays -> n rows of a (pinned) staging block: row i = src[i][0 .. n_floats[i]) followed by zeros up to row_floats,
  * rows row_stride floats apart, on up to n_threads plain threads.  The live RIRs of a SoundSpaces 2.0 step (one new RIR per
  * env and step from the ray tracer, soundspaces/continuous_simulator.py:419) travel to the bank this way: one block, one

@@ -17,6 +17,8 @@ ap.add_argument("--rir-len", type=int, default=9000)
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--profile", action="store_true", help="cProfile of the trainer half over the timed steps")
+ap.add_argument("--scatter-copy", action="store_true", help="A/B: H2D copy of the staged rows, then the scatter on the device copy "
+                "(default: the scatter kernel reads the pinned block itself)")
 ap.add_argument("--walk", action="store_true", help="force the per-request walk (round 4's path: fast=False) - same-box A/B")
 a = ap.parse_args()
 sr, N, L = 16000, a.envs, a.rir_len
@@ -51,6 +53,7 @@ sims = [Sim(o) for o in range(N)]
 for i, s in enumerate(sims):
     attach_deferred(s, env_rank=i, continuous=True)
 eng = AudioEngine(sr, device="cuda:0", rir_slots=2 * N + 8, rir_cap=L, step_time=0.25, wrap=True)
+eng.store.scatter_from_host = not a.scatter_copy
 res = DeferredResolver(eng, fast=False) if a.walk else DeferredResolver(eng)
 sg = torch.empty((N, 65, 26, 2), device="cuda:0")
 w_us, t_us = [], []
@@ -74,7 +77,7 @@ for k in range(a.warmup + a.steps):
         w_us.append(1e6 * (t1 - t0)); t_us.append(1e6 * (t2 - t1))
 torch.cuda.synchronize()
 dt = time.perf_counter() - t_start
-print(json.dumps({"mode": "deferred, SoundSpaces 2.0 live RIRs + CROSSFADE", "path": "request walk (r4)" if a.walk else "live columns (r5)",
+print(json.dumps({"mode": "deferred, SoundSpaces 2.0 live RIRs + CROSSFADE", "scatter": "copy + device scatter" if a.scatter_copy else "kernel reads the pinned block", "path": "request walk (r4)" if a.walk else "live columns (r5)",
                   "live_steps": res.live_steps, "walk_steps": res.walk_steps, "envs": N, "rir_len": L, "steps": a.steps,
                   "trainer_half_us_per_step": round(float(np.median(t_us)), 1),
                   "trainer_half_env_steps_per_s": round(N / (np.median(t_us) * 1e-6), 1),

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <iterator>
 #include <map>
@@ -39,6 +40,27 @@ inline int ab_int(const char* name, int dflt) { const char* v = std::getenv(name
 #else
 constexpr bool ab_flag(const char*) { return false; }
 constexpr int ab_int(const char*, int dflt) { return dflt; }
+#endif
+
+// Host time of one ss_ctx_observe call by segment (A/B builds only; ss_ab_host_profile reads and clears the sums)
+#if defined(SS_AB)
+double g_prof_ns[8] = {0};
+long long g_prof_calls = 0;
+struct ProfClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(int seg) {
+        const auto n = std::chrono::steady_clock::now();
+        g_prof_ns[seg] += std::chrono::duration<double, std::nano>(n - t).count();
+        t = n;
+    }
+};
+#define SS_PROF_BEGIN() ProfClock prof_clock
+#define SS_PROF_MARK(seg) prof_clock.mark(seg)
+#define SS_PROF_CALL() (++g_prof_calls)
+#else
+#define SS_PROF_BEGIN() ((void)0)
+#define SS_PROF_MARK(seg) ((void)0)
+#define SS_PROF_CALL() ((void)0)
 #endif
 
 int get_tables(ssk::Tables* out, int* n_cus = nullptr) {
@@ -967,6 +989,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     ssctx::Context& c = h->c;
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e;
+    SS_PROF_BEGIN();
     if (c.plan_only_keys) {                                    // ss_ctx_plan was used on this context: its keys claim
         // spectra that were never computed, and its ticks took no ring slot (the eviction guard of the overlap mode counts
         // ticks as ring slots) - start from an empty cache, and only once nothing in flight reads the pool (a
@@ -997,6 +1020,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         if (e == hipSuccess) e = hipStreamWaitEvent(st, c.ev_xstream, 0);
         if (e != hipSuccess) return hip_err(e);
     }
+    SS_PROF_MARK(1);                                           // cross-lane / cross-stream waits
     int rc = ctx_ensure_ring(c, n, 0, st);
     if (rc) return rc;
     // Ring slots are released in GROUPS: one completion event per kGroup consecutive steps (recorded after the group's
@@ -1027,8 +1051,10 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     int* hd = c.h_desc + static_cast<size_t>(k) * c.ring_cap * 8;
     int* dd = direct ? hd : c.d_desc + static_cast<size_t>(k) * c.ring_cap * 8;
     ssctx::PlanResult res;
+    SS_PROF_MARK(2);                                           // ring slot: group event synchronise
     rc = ssctx::plan_units(c, units, n, hd, &res);
     if (rc) return rc;                                         // (refused before the cache or the ring was touched)
+    SS_PROF_MARK(3);                                           // planner
     c.ring_k = (k + 1) % ssctx::kRing;                         // the slot is taken from here on, whatever happens next
     // The slot's group is released by an event recorded behind the group's last launch (overlap mode: behind each lane's
     // last launch of the group); a step that fails after this point must still record it, or the group's next round
@@ -1087,6 +1113,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         audiogoal = c.ag_scratch;
     }
     static const bool no_tab = ab_flag("SS_HIP_NO_UNIT_TAB");
+    SS_PROF_MARK(4);                                           // new windows (upload + k_source_windows), descriptor upload
     g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
     g_launch_share = c.n_lanes;
     if (!c.buckets.empty()) {
@@ -1109,9 +1136,12 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
                                      c.n_valid, c.out_len, res.flags, stream);
     g_host_desc = nullptr;
     g_launch_share = 1;
+    SS_PROF_MARK(5);                                           // the launch entry (unit table + hipLaunchKernel)
     if (rc) return fail(rc);
     // (overlap mode: a group's ticks alternate between the lanes; each lane records its half after ITS last tick)
-    return close_slot();
+    rc = close_slot();
+    SS_PROF_MARK(6);                                           // group event record
+    return rc;
 }
 
 // ---- overlap mode -------------------------------------------------------------------------------------------------
@@ -1191,13 +1221,32 @@ static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audio
     // ss_ctx_join.  Consecutive steps run on different streams: the head of step k+1 (descriptor + row loads, HBM latency,
     // nothing to compute) overlaps the tail of step k (STFT, no memory traffic).
     const int lane = c.ring_k % c.n_lanes;                     // tick parity: a refused call does not shift the lanes
-    hipError_t e = hipEventRecord(c.ev_in, static_cast<hipStream_t>(stream));
-    if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
+    SS_PROF_BEGIN();
+    // The fence costs an event record + a stream wait (measured: 4.6 us of the call's 10.8 us of host time at 16-32 envs, where
+    // the host IS the step's bound) and a barrier packet in front of the lane's launch.  A caller's stream that has nothing
+    // pending - a trainer that has just read its actions back, a vector env between two policy steps - needs none.
+    static const bool always_fence = ab_flag("SS_HIP_ALWAYS_FENCE");        // (A/B builds only)
+    hipError_t e = always_fence ? hipErrorNotReady : hipStreamQuery(static_cast<hipStream_t>(stream));
+    if (e == hipErrorNotReady) {
+        if (!always_fence) (void)hipGetLastError();            // (not an error: do not leave it for the launch's own check)
+        e = hipEventRecord(c.ev_in, static_cast<hipStream_t>(stream));
+        if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
+    }
     if (e != hipSuccess) return hip_err(e);
+    SS_PROF_MARK(0);                                           // input fence: caller's stream -> lane
+    SS_PROF_CALL();
     c.lane_dirty[lane] = true;
     const int rc = ctx_observe_on(h, units, n, audiogoal, sg_late ? nullptr : spectrogram, c.lane_stream[lane], lane);
     return rc ? rc : ctx_features_on(h, n, audiogoal, sg_late ? spectrogram : nullptr, f, c.lane_stream[lane]);
 }
+
+#if defined(SS_AB)
+int ss_ab_host_profile(double* ns_out8, long long* calls_out) {
+    for (int i = 0; i < 8; ++i) { ns_out8[i] = g_prof_ns[i]; g_prof_ns[i] = 0; }
+    *calls_out = g_prof_calls; g_prof_calls = 0;
+    return 0;
+}
+#endif
 
 int ss_ctx_observe(ss_ctx* h, const ss_units* units, int n, float* audiogoal, float* spectrogram, void* stream) {
     return ctx_observe_any(h, units, n, audiogoal, spectrogram, nullptr, stream);
@@ -1497,6 +1546,25 @@ extern "C" int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst,
     if (!paths || !dst || !kept_out || !frames_out || !status_out || n < 0 || cap < 1 || row_stride < 2LL * cap) return SS_EINVAL;
     sswav::read_many(paths, n, dst, row_stride, cap, keep, planar != 0, kept_out, frames_out, status_out, n_threads);
     return 0;
+}
+
+// Staged rows (wav layout, pinned host or device memory) -> planar bank rows + their lengths, one launch (k_scatter_rows)
+extern "C" int ss_bank_scatter_rows_f32(const float* staged, long long staged_row_stride, const int* slots, const int* lens,
+                                        int n, float* bank, long long unit_stride, int chan_stride, int cap, int* bank_len,
+                                        void* stream) {
+    if (n == 0) return 0;
+    if (!staged || !slots || !lens || !bank || n < 0 || cap <= 0 || unit_stride <= 0 || chan_stride <= 0 ||
+        staged_row_stride < 2LL * cap) return SS_EINVAL;
+    ssk::ScatterRowsParams p;
+    p.staged = staged; p.slots = slots; p.lens = lens; p.bank = bank; p.bank_len = bank_len;
+    p.staged_stride = staged_row_stride; p.unit_stride = unit_stride; p.chan_stride = chan_stride; p.cap = cap;
+    for (int lo = 0; lo < n; lo += 65535) {                    // (grid.y limit)
+        const int m = n - lo < 65535 ? n - lo : 65535;
+        ssk::ScatterRowsParams q = p;
+        q.staged += static_cast<size_t>(lo) * staged_row_stride; q.slots += lo; q.lens += lo;
+        hipLaunchKernelGGL(ssk::k_scatter_rows, dim3((cap + 511) / 512, m), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+    }
+    return hip_err(hipGetLastError());
 }
 
 extern "C" int ss_rows_gather_f32(const float* const* src, const int* n_floats, int n, float* dst, long long row_stride,

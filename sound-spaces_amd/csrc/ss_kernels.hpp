@@ -2217,4 +2217,46 @@ __global__ __launch_bounds__(256) void k_intensity(IntensityParams p) {
     if (t == 0) p.out[blockIdx.x] = n > 0 ? tot / (2.f * n) : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_scatter_rows: the RIR miss path's last hop.  n staged rows in wav layout ([frames][2], the layout the files and the ray
+// tracer's output have) -> the planar bank rows bank[slot][c][j], zero behind each row's own length up to `cap`; and the
+// rows' lengths into the bank's length table.  `staged`, `slots`, `lens` may be PINNED HOST memory (device-mapped under
+// ROCm): the kernel then pulls the samples over the host link itself - one launch instead of three copies, a transpose
+// and two index_copy dispatches (61 us of host time per miss step, profiles/r5/NOTES.md section 2).  Frames beyond a row's
+// length are not read at all.  Grid: (chunks of 512 frames, n); 256 threads x 2 frames: 16-byte loads, 8-byte stores.
+struct ScatterRowsParams {
+    const float* staged;       // [n][staged_stride] floats, row i = frames j < lens[i] as (L, R) pairs
+    const int* slots;          // [n] bank rows
+    const int* lens;           // [n] frames of row i (<= cap)
+    float* bank;               // bank[slot * unit_stride + c * chan_stride + j]
+    int* bank_len;             // [slots of the bank] (may be nullptr)
+    long long staged_stride, unit_stride;
+    int chan_stride, cap;
+};
+
+__global__ __launch_bounds__(256) void k_scatter_rows(ScatterRowsParams p) {
+    const int i = blockIdx.y;
+    const int slot = p.slots[i];
+    const int len = min(max(p.lens[i], 0), p.cap);
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.bank_len) p.bank_len[slot] = len;
+    if (j >= p.cap) return;
+    float* dl = p.bank + (size_t)slot * p.unit_stride;
+    float* dr = dl + p.chan_stride;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* src = p.staged + (size_t)i * p.staged_stride + 2 * (size_t)j;
+    const bool al16 = ((p.staged_stride & 3) | (reinterpret_cast<size_t>(p.staged) & 15)) == 0;
+    if (j + 1 < len) {
+        if (al16) v = *reinterpret_cast<const f32x4*>(src);
+        else { v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3]; }
+    } else if (j < len) { v.x = src[0]; v.y = src[1]; }
+    if (j + 1 < p.cap && ((p.chan_stride | p.unit_stride | (reinterpret_cast<size_t>(p.bank) >> 2)) & 1) == 0) {
+        *reinterpret_cast<c32*>(dl + j) = mk2(v.x, v.z);
+        *reinterpret_cast<c32*>(dr + j) = mk2(v.y, v.w);
+    } else {
+        dl[j] = v.x; dr[j] = v.y;
+        if (j + 1 < p.cap) { dl[j + 1] = v.z; dr[j + 1] = v.w; }
+    }
+}
+
 }  // namespace ssk

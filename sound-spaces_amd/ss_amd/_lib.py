@@ -16,7 +16,7 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
            "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
            "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features",
-           "ss_wav_read_rirs_f32", "ss_rows_gather_f32")
+           "ss_wav_read_rirs_f32", "ss_rows_gather_f32", "ss_bank_scatter_rows_f32")
 
 
 class SsRirBucket(ctypes.Structure):
@@ -109,6 +109,7 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
     lib.ss_wav_read_rirs_f32.argtypes = [vp, c_int, vp, c_ll, c_int, c_int, c_int, vp, vp, vp, c_int]
     lib.ss_rows_gather_f32.argtypes = [vp, vp, c_int, vp, c_ll, c_int, c_int]
+    lib.ss_bank_scatter_rows_f32.argtypes = [vp, c_ll, vp, vp, c_int, vp, c_ll, c_int, c_int, vp, vp]
     for name in EXPORTS:
         getattr(lib, name).restype = c_int
     _lib = lib
@@ -124,6 +125,17 @@ def check(rc: int, what: str) -> None:
 WAV_OK, WAV_UNSUPPORTED, WAV_EMPTY, WAV_MISSING, WAV_TOO_LONG = 0, 1, 2, 3, 4
 
 
+_n_threads = 0
+
+
+def _default_threads() -> int:
+    """threads of the library's host pool for this process (asked once: the affinity mask is a system call)"""
+    global _n_threads
+    if _n_threads <= 0:
+        _n_threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    return _n_threads
+
+
 def wav_read_rirs(paths, dst, cap: int, keep: int = -1, planar: bool = False, threads: int = 0):
     """ss_wav_read_rirs_f32: the float32 stereo wav files `paths` -> rows of the HOST float32 numpy array `dst`
     ([n, cap, 2] wav-interleaved, or [n, 2, cap] with planar=True; C-contiguous, typically the numpy view of a pinned
@@ -136,7 +148,7 @@ def wav_read_rirs(paths, dst, cap: int, keep: int = -1, planar: bool = False, th
         return kept, frames, status
     arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
     if threads <= 0:
-        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        threads = _default_threads()
     check(load().ss_wav_read_rirs_f32(ctypes.cast(arr, ctypes.c_void_p), n, dst.ctypes.data, 2 * cap, cap, keep, int(planar),
                                       kept.ctypes.data, frames.ctypes.data, status.ctypes.data, threads), "ss_wav_read_rirs_f32")
     return kept, frames, status

@@ -291,6 +291,7 @@ class DeferredResolver:
         self._table_keys = np.zeros((0,), np.int64)
         self._table_ids = np.zeros((0,), np.int64)
         self._table_dirs: List[str] = []
+        self._native_reader = None                          # (rir_reader, stock wav reader?, lenient?), decided on first use
         self.column_steps = self.walk_steps = 0
         # resident RIR files: sorted composite keys (table << 40 | receiver << 20 | source) -> store slot
         self._pair_keys = np.zeros((0,), np.int64)
@@ -440,25 +441,35 @@ class DeferredResolver:
             return
         if self.prefetch_azimuths and not reload and ks.shape[0] <= self.PREFETCH_MAX_POSES:
             ks = self._with_sibling_azimuths(ks)
-        paths = [os.path.join(self._table_dirs[int(k) >> 40], "{}_{}.wav".format((int(k) >> 20) & 0xFFFFF, int(k) & 0xFFFFF))
-                 for k in ks]
-        from .renderer import _native_wav
-        if _native_wav(self.rir_reader) and hasattr(store, "load_files") and store.group == 1:
+        kl = ks.tolist()
+        dirs = self._table_dirs
+        paths = [os.path.join(dirs[k >> 40], f"{(k >> 20) & 0xFFFFF}_{k & 0xFFFFF}.wav") for k in kl]
+        if self._native_reader is None or self._native_reader[0] is not self.rir_reader:
+            from .renderer import _native_wav
             import functools
-            lenient = isinstance(self.rir_reader, functools.partial) and bool(self.rir_reader.keywords.get("lenient"))
-            slots = store.load_files([("ix", int(k)) for k in ks], paths, reader=self.rir_reader, missing_ok=lenient,
+            self._native_reader = (self.rir_reader, bool(_native_wav(self.rir_reader)),
+                                   isinstance(self.rir_reader, functools.partial) and bool(self.rir_reader.keywords.get("lenient")))
+        if self._native_reader[1] and hasattr(store, "load_files") and store.group == 1:
+            slots = store.load_files([("ix", k) for k in kl], paths, reader=self.rir_reader, missing_ok=self._native_reader[2],
                                      new_batch=False)
         else:
-            slots = [store.slot(("ix", int(k)), lambda path=path: self.rir_reader(path)) for k, path in zip(ks, paths)]
+            slots = [store.slot(("ix", k), lambda path=path: self.rir_reader(path)) for k, path in zip(kl, paths)]
         slots = np.asarray(slots, np.int64)
         # loading may have evicted resident pairs (the hook removed them from the arrays): merge against what is there NOW
+        n_old = self._pair_keys.shape[0]
         pos = np.searchsorted(self._pair_keys, ks)
-        have = (pos < self._pair_keys.shape[0]) & (self._pair_keys[np.minimum(pos, max(self._pair_keys.shape[0] - 1, 0))] == ks) \
-            if self._pair_keys.shape[0] else np.zeros(ks.shape, bool)
-        self._pair_slots[pos[have]] = slots[have]
-        if (~have).any():
-            self._pair_keys = np.insert(self._pair_keys, pos[~have], ks[~have])
-            self._pair_slots = np.insert(self._pair_slots, pos[~have], slots[~have])
+        have = (self._pair_keys[np.minimum(pos, n_old - 1)] == ks) if n_old else np.zeros(ks.shape, bool)
+        if have.any():
+            self._pair_slots[pos[have]] = slots[have]
+        if not have.all():                                  # ONE merge of the new keys into both sorted arrays
+            new = ~have
+            at = pos[new] + np.arange(int(new.sum()))
+            keep = np.ones((n_old + at.shape[0],), bool)
+            keep[at] = False
+            keys2, slots2 = np.empty(keep.shape, np.int64), np.empty(keep.shape, np.int64)
+            keys2[at], slots2[at] = ks[new], slots[new]
+            keys2[keep], slots2[keep] = self._pair_keys, self._pair_slots
+            self._pair_keys, self._pair_slots = keys2, slots2
         self._tables = None
 
     def _sibling_tables(self, t: int) -> list:

@@ -461,6 +461,13 @@ class RirStore:
         self._free: List[int] = list(range(slots - group, -1, -group))
         self._batch = 0
         self._batch_of = np.full((slots,), -1, np.int64)      # batch in which the slot was last handed out
+        # victim selection without walking the dict (a FULL store is the steady state against an 867-GB data set: every miss
+        # evicts): per first slot of an entry its key, whether it is occupied, and the tick of its last use through slot()
+        # (the dict order as numbers: the tie-break among entries of one batch)
+        self._key_at: List = [None] * slots
+        self._used = np.zeros((slots,), bool)
+        self._use_seq = np.zeros((slots,), np.int64)
+        self._seq = 0
         self.hits = self.misses = self.grown = 0
         self._clipped = np.zeros((slots,), bool)              # the stored row is shorter than its RIR (truncate_to)
         # spectral=True keeps the block spectra of every row next to it (RirBank.spectra, ss_rir_spectra_f32): rows
@@ -505,6 +512,8 @@ class RirStore:
             for key, slot in list(self._slot_of.items()):
                 self._notify_evict(key, slot)
         self._slot_of.clear()
+        self._key_at = [None] * self.slots
+        self._used[:] = False
         self._pending = {}
         self._free = list(range(self.slots - self.group, -1, -self.group))
         self.host_len[:] = 0
@@ -685,21 +694,15 @@ class RirStore:
         nfl = (2 * lens).astype(np.int32)
         _lib.check(_lib.load().ss_rows_gather_f32(ctypes.cast(ptrs, ctypes.c_void_p), nfl.ctypes.data, k, blk.data_ptr(),
                                                   2 * self.cap, 2 * self.cap, threads), "ss_rows_gather_f32")
-        key = tuple(int(s_) for s_ in slots)
-        idx = self._idx_cache.get(key)
-        if idx is None:
-            if len(self._idx_cache) > 16:
-                self._idx_cache.clear()
-            idx = self._idx_cache[key] = torch.as_tensor(key, dtype=torch.long, device=self.device)
-        self.bank.data.index_copy_(0, idx, blk[:k].to(self.device, non_blocking=True).permute(0, 2, 1))
-        sl_np = np.asarray(key)
+        sl_np = np.asarray(slots, np.int64)
         lens32 = lens.astype(np.int32)
-        if not np.array_equal(self._dev_len[sl_np], lens32):
-            self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens32).to(self.device))
-            self._dev_len[sl_np] = lens32
-        if pin:
-            self._flush_ev = torch.cuda.Event()
-            self._flush_ev.record()
+        meta = getattr(self, "_flush_meta", None)
+        if meta is None or meta[0].shape[0] < k:
+            meta = self._flush_meta = tuple(torch.zeros((max(k, 64),), dtype=torch.int32, pin_memory=pin) for _ in range(2))
+        meta[0].numpy()[:k] = sl_np
+        meta[1].numpy()[:k] = lens32
+        self._flush_ev = self._scatter_staged(blk, meta[0], meta[1], k)
+        self._dev_len[sl_np] = lens32
         self.host_len[sl_np] = lens32
         self._clipped[sl_np] = lens < full
         self._stale[sl_np] = True
@@ -722,28 +725,68 @@ class RirStore:
         self._stale[:] = False
         return int(idx.shape[0])
 
+    def _bind(self, key, slot: int) -> None:
+        """`key` now owns the entry starting at `slot` (handed out for the current batch, most recently used)"""
+        self._slot_of[key] = slot
+        self._key_at[slot] = key
+        self._used[slot] = True
+        self._seq += 1
+        self._use_seq[slot] = self._seq
+        self._batch_of[slot] = self._batch
+
+    def release(self, key) -> None:
+        """Give the entry of `key` back (no eviction notice: the caller moves the key elsewhere)."""
+        slot = self._slot_of.pop(key)
+        self._key_at[slot] = None
+        self._used[slot] = False
+        self._free.append(slot)
+
     def _take_slot(self) -> int:
-        if self._free:
-            return self._free.pop()
-        # Victim = the entry whose slot was handed out / touched longest ago.  Recency lives in `_batch_of` (the batch of
-        # the last use: slot() and the column paths' touch_slots() both write it), NOT only in the dict order - the
-        # native record path (ss_ctx_observe_requests) looks slots up without ever passing through slot(), so with the
-        # dict order alone the store degraded to FIFO for exactly the modes that keep the most poses resident (ADVICE
-        # r4).  Ties (callers that never open a batch, or entries of one batch) fall back to the dict order: oldest first.
-        keys = list(self._slot_of)
-        slots_arr = np.fromiter(self._slot_of.values(), np.int64, len(keys))
-        last = self._batch_of[slots_arr]
-        j = int(np.argmin(last))
-        if self._batch and last[j] == self._batch:                   # (callers that never open a batch: no guard)
-            raise RuntimeError(f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
-                               "(an entry handed out for this launch would be overwritten); raise rir_slots")
-        slot, victim = int(slots_arr[j]), keys[j]
-        del self._slot_of[victim]
-        for g in range(self.group):                                  # a row still queued for the victim must not land later
-            self._pending.pop(slot + g, None)
-        if self.on_evict is not None or self._evict_hooks:
-            self._notify_evict(victim, slot)
-        return slot
+        return self._take_slots(1)[0]
+
+    def _take_slots(self, k: int) -> List[int]:
+        """k entries for new keys: free ones first, then the least recently used - evicted (hooks told) in LRU order.
+        Victim = the entry whose slot was handed out / touched longest ago.  Recency lives in `_batch_of` (the batch of
+        the last use: slot() and the column paths' touch_slots() both write it; the native record path,
+        ss_ctx_observe_requests, stamps it from C), NOT only in the dict order - with the dict order alone the store degraded
+        to FIFO for exactly the modes that keep the most poses resident.  Ties (callers that never open a batch,
+        entries of one batch) fall back to the order of use through slot(): oldest first.  All numpy over the slot arrays:
+        the first version rebuilt a list of the dict per victim (150 us per miss at 4096 resident poses)."""
+        out: List[int] = []
+        while self._free and len(out) < k:
+            out.append(self._free.pop())
+        r = k - len(out)
+        if r <= 0:
+            return out
+        cand = np.flatnonzero(self._used)
+        full_msg = (f"RirStore: {self.slots // self.group} entries cannot hold the distinct RIRs of one batch "
+                    "(an entry handed out for this launch would be overwritten); raise rir_slots")
+        if cand.shape[0] < r:
+            self._free.extend(reversed(out))
+            raise RuntimeError(full_msg)
+        last = self._batch_of[cand]
+        thr = np.partition(last, r - 1)[r - 1] if r < cand.shape[0] else last.max()
+        if self._batch and thr == self._batch:                       # (callers that never open a batch: no guard)
+            self._free.extend(reversed(out))
+            raise RuntimeError(full_msg)
+        below, ties = cand[last < thr], cand[last == thr]
+        need = r - below.shape[0]
+        if need < ties.shape[0]:
+            ties = ties[np.argpartition(self._use_seq[ties], need - 1)[:need]]
+        victims = np.concatenate([below, ties])
+        victims = victims[np.lexsort((self._use_seq[victims], self._batch_of[victims]))]
+        tell = self.on_evict is not None or bool(self._evict_hooks)
+        for slot in victims.tolist():
+            victim = self._key_at[slot]
+            del self._slot_of[victim]
+            self._key_at[slot] = None
+            self._used[slot] = False
+            for g in range(self.group):                              # a row still queued for the victim must not land later
+                self._pending.pop(slot + g, None)
+            if tell:
+                self._notify_evict(victim, slot)
+            out.append(slot)
+        return out
 
     def touch_slots(self, slots: np.ndarray) -> None:
         """Column paths (``DeferredResolver``, tables of ``RirIndex``) look slots up without going through ``slot()``: this
@@ -759,6 +802,8 @@ class RirStore:
         if key in self._slot_of:
             slot = self._slot_of.pop(key)
             self._slot_of[key] = slot                   # most recently used
+            self._seq += 1
+            self._use_seq[slot] = self._seq
             # a row clipped while only 1-s clips existed is reloaded once whole RIRs are needed (truncate_to = None)
             if refresh or (self.truncate_to is None and self._clipped[slot:slot + self.group].any()):
                 self._load_into(slot, loader())
@@ -768,8 +813,7 @@ class RirStore:
             return slot
         self.misses += 1
         slot = self._take_slot()
-        self._slot_of[key] = slot
-        self._batch_of[slot] = self._batch
+        self._bind(key, slot)
         self._load_into(slot, loader())
         return slot
 
@@ -822,11 +866,11 @@ class RirStore:
             stage_np = stage.numpy()
             lens = np.asarray(kept, np.int32)
             slots = []
+            taken = self._take_slots(len(part))
             for j, i in enumerate(part):
                 self.misses += 1
-                sl = self._take_slot()
-                self._slot_of[keys[i]] = sl
-                self._batch_of[sl] = self._batch
+                sl = taken[j]
+                self._bind(keys[i], sl)
                 for g in range(G):
                     r, n = rows[j * G + g], kept[j * G + g]
                     stage_np[j * G + g, :, :n] = r[:, :n]
@@ -847,6 +891,37 @@ class RirStore:
     # ---- float32 wav files, read natively (ss_wav_read_rirs_f32) ----------------------------------------------------------
     _FILE_CHUNK = 256                                            # rows per staging block (two blocks: read k+1 under copy k)
 
+    scatter_from_host = True      # the scatter kernel reads the pinned staging block itself (False: one H2D copy first)
+
+    def _scatter_staged(self, stage, pidx, plen, n_rows: int):
+        """Rows [0, n_rows) of the staging block `stage` ([*, cap, 2] wav layout) -> bank rows pidx[i] with lengths plen[i]
+        (int32 tensors next to the block: pinned on a GPU store).  GPU stores: ONE launch of the library's scatter
+        (ss_bank_scatter_rows_f32 - it reads block, slots and lengths from the pinned memory itself, transposes into the
+        planar rows and writes the length table); returns the event behind it (the block may be refilled after it).
+        Host stores (tests without a GPU): the same scatter in torch."""
+        if self.device.type != "cuda":
+            idx = pidx[:n_rows].long()
+            self.bank.data.index_copy_(0, idx, stage[:n_rows].permute(0, 2, 1))
+            self.bank.lengths.index_copy_(0, idx, plen[:n_rows])
+            return None
+        from . import _lib
+        data = self.bank.data
+        di = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        src = stage if self.scatter_from_host else stage[:n_rows].to(self.device, non_blocking=True)
+
+        def launch():
+            _lib.check(_lib.load().ss_bank_scatter_rows_f32(
+                src.data_ptr(), 2 * self.cap, pidx.data_ptr(), plen.data_ptr(), n_rows, data.data_ptr(), data.stride(0),
+                data.stride(1), self.cap, self.bank.lengths.data_ptr(), torch._C._cuda_getCurrentRawStream(di)),
+                "ss_bank_scatter_rows_f32")
+            ev = torch.cuda.Event()
+            ev.record()
+            return ev
+        if torch.cuda.current_device() == di:
+            return launch()
+        with torch.cuda.device(di):
+            return launch()
+
     def _file_stage(self, k: int):
         """pinned [_FILE_CHUNK, cap, 2] staging block k & 1 (wav layout), free to be overwritten"""
         if getattr(self, "_fstage", None) is None or self._fstage[0].shape[1] != self.cap:
@@ -854,7 +929,7 @@ class RirStore:
             self._fstage = [torch.zeros((self._FILE_CHUNK, self.cap, 2), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
             # the rows' bank slots and lengths travel the same way (a list -> device tensor conversion is a SYNCHRONOUS pageable
             # copy: two of them were a third of a step that loads one new pose)
-            self._fstage_idx = [torch.zeros((self._FILE_CHUNK,), dtype=torch.long, pin_memory=pin) for _ in range(2)]
+            self._fstage_idx = [torch.zeros((self._FILE_CHUNK,), dtype=torch.int32, pin_memory=pin) for _ in range(2)]
             self._fstage_len = [torch.zeros((self._FILE_CHUNK,), dtype=torch.int32, pin_memory=pin) for _ in range(2)]
             self._fstage_ev = [None, None]
         if self._fstage_ev[k & 1] is not None:
@@ -932,25 +1007,15 @@ class RirStore:
                 if not dense:
                     snp[row] = tgt[f]
                 lens[row], full[row] = kept[f], frames[f]
-            slots = []
-            for j, i in enumerate(part):
-                self.misses += 1
-                sl = self._take_slot()
-                self._slot_of[keys[i]] = sl
-                self._batch_of[sl] = self._batch
-                slots += [sl + g for g in range(G)]
-            sl_np = np.asarray(slots)
+            taken = self._take_slots(len(part))
+            self.misses += len(part)
+            for i, sl in zip(part, taken):
+                self._bind(keys[i], sl)
+            sl_np = np.asarray(taken) if G == 1 else (np.asarray(taken)[:, None] + np.arange(G)[None, :]).reshape(-1)
             pidx, plen = self._fstage_idx[c & 1], self._fstage_len[c & 1]
             pidx.numpy()[:n_rows] = sl_np
             plen.numpy()[:n_rows] = lens
-            idx = pidx[:n_rows].to(self.device, non_blocking=True)
-            dev_blk = stage[:n_rows].to(self.device, non_blocking=True).permute(0, 2, 1)     # [k, cap, 2] -> [k, 2, cap]
-            self.bank.data.index_copy_(0, idx, dev_blk)
-            self.bank.lengths.index_copy_(0, idx, plen[:n_rows].to(self.device, non_blocking=True))
-            if self.device.type == "cuda":
-                ev = torch.cuda.Event()
-                ev.record()
-                self._fstage_ev[c & 1] = ev
+            self._fstage_ev[c & 1] = self._scatter_staged(stage, pidx, plen, n_rows)
             self._dev_len[sl_np] = lens
             self.host_len[sl_np] = lens
             self._stale[sl_np] = True
@@ -1058,7 +1123,7 @@ class BucketedRirStore:
         nb = self._bucket_for(loaded)
         if b is not None and b != nb:                              # the key changes length class: leave the old bucket
             old = self.stores[b]
-            old._free.append(old._slot_of.pop(key))
+            old.release(key)
         self._where[key] = nb
         st = self.stores[nb]
         return self.first[nb] + st.slot(key, lambda: loaded, refresh=key in st._slot_of)

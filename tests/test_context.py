@@ -213,6 +213,55 @@ def test_failed_or_plan_only_steps_do_not_poison_the_window_cache():
 
 
 @pytest.mark.gpu
+def test_overlap_mode_orders_a_step_behind_pending_work_of_the_callers_stream():
+    """The overlap mode's input fence (event record on the caller's stream + wait on the lane) is skipped when the caller's
+    stream has nothing pending (hipStreamQuery) - and ONLY then: RIR rows rewritten by a copy that is still queued behind
+    milliseconds of other work on the caller's stream when ss_ctx_observe is called must be the rows the step renders."""
+    import torch
+    from ss_amd.renderer import RirBank
+    dev = "cuda:0"
+    rng = np.random.default_rng(41)
+    src = O.synth_sources(rng, SR, k=2)
+    rows_a = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=8)]
+    rows_b = [np.ascontiguousarray(h.T) for h in O.synth_rir(rng, SR, n=8)]
+    bank = RirBank.from_arrays(rows_a, dev)
+    data_a = bank.data.clone()
+    data_b = RirBank.from_arrays(rows_b, dev).data.clone()
+    assert data_a.shape == data_b.shape
+    ref, ctx = AudioContext(SR), AudioContext(SR)
+    for c in (ref, ctx):
+        for i, s_ in enumerate(src):
+            c.add_source(f"s{i}", s_)
+        c.set_rir_bank(bank.data, bank.lengths)
+    ctx.set_overlap(2)
+    sound, t0, rir = rng.integers(0, 2, 8), np.zeros(8, np.int64), np.arange(8)
+    want = {}
+    for name, d in (("a", data_a), ("b", data_b)):
+        bank.data.copy_(d)
+        torch.cuda.synchronize()
+        want[name] = torch.empty((8, 65, 26, 2), device=dev)
+        ref.observe(sound, t0, rir, spectrogram_out=want[name])
+        torch.cuda.synchronize()
+    assert not torch.equal(want["a"], want["b"])
+    big = torch.randn((4096, 4096), device=dev)
+    got = torch.empty((8, 65, 26, 2), device=dev)
+    for trial, name in enumerate("abab"):
+        if trial >= 2:
+            torch.cuda.synchronize()                            # idle stream at the call: the fence is skipped
+        else:
+            acc = big
+            for _ in range(6):                                  # ~ms of queued work in front of the row copy
+                acc = (acc @ big) * 1e-3
+        bank.data.copy_(data_a if name == "a" else data_b, non_blocking=True)
+        if trial >= 2:
+            torch.cuda.synchronize()
+        ctx.observe(sound, t0, rir, spectrogram_out=got)
+        ctx.join()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[name]), trial
+
+
+@pytest.mark.gpu
 def test_overlap_mode_two_lanes_equal_single_stream():
     """ss_ctx_set_overlap(2): 90 steps alternate between two internal streams with nothing but ss_ctx_join at the end -
     cache misses whose spectra the OTHER lane's next step hits, evictions under a small cache, steps of different sizes

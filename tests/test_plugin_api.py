@@ -362,6 +362,61 @@ def test_rir_store_slot_many_matches_one_by_one():
         np.testing.assert_array_equal(small.bank.data[sl, :, :n].numpy(), rirs[k][:n].T)
 
 
+def test_rir_store_victims_follow_batch_recency_then_order_of_use_against_a_reference_walk():
+    """The victim selection runs on slot arrays (``_take_slots``: no walk over the dict - a full store is the steady state
+    against the 867-GB data set): checked against the definition it replaces, a walk over the entries - least recent
+    batch first, ties in the order of use through slot(), never an entry of the open batch - under random hits, misses,
+    column-path touches (``touch_slots``) and multi-entry takes; hooks hear every eviction, in order."""
+    rng = np.random.default_rng(11)
+    for group in (1, 4):
+        st = RirStore(slots=24 * group, cap=16, device="cpu", group=group)
+        heard = []
+        st.on_evict = lambda key, slot: heard.append((key, slot))
+        order, batch_of = [], {}                                  # the reference: keys in order of use, key -> batch of last use
+
+        def expect_victims(r):
+            ranked = sorted(order, key=lambda k: (batch_of[k], order.index(k)))
+            return ranked[:r]
+        rows = [np.zeros((4, 2), np.float32)] * group
+        load = (lambda: rows[0]) if group == 1 else (lambda: rows)
+        n_keys = 0
+        for step in range(300):
+            if rng.uniform() < 0.5:
+                st.begin_batch()
+            kind = rng.uniform()
+            if kind < 0.35 and order:                               # hit through slot()
+                k = order[int(rng.integers(0, len(order)))]
+                st.slot(k, load)
+                order.remove(k); order.append(k); batch_of[k] = st._batch
+            elif kind < 0.5 and order:                              # column path: recency only
+                ks = [order[int(i)] for i in rng.integers(0, len(order), 3)]
+                st.touch_slots(np.asarray([st._slot_of[k] for k in ks]))
+                for k in ks:
+                    batch_of[k] = st._batch
+            else:                                                   # r new keys at once
+                r = int(rng.integers(1, 4))
+                free = len(st._free)
+                want = expect_victims(max(0, r - free))
+                if any(batch_of[k] == st._batch and st._batch for k in want):
+                    before = (dict(st._slot_of), list(st._free))
+                    with pytest.raises(RuntimeError):
+                        st._take_slots(r)
+                    assert (dict(st._slot_of), list(st._free)) == before       # refused: nothing changed
+                    continue
+                heard.clear()
+                got = st._take_slots(r)
+                assert [k for k, _ in heard] == want and len(set(got)) == r
+                for k in want:
+                    order.remove(k); del batch_of[k]
+                for sl in got:
+                    key = ("k", n_keys); n_keys += 1
+                    st._bind(key, sl)
+                    order.append(key); batch_of[key] = st._batch
+            assert set(st._slot_of) == set(order)
+            assert all(st._key_at[sl] == k and st._used[sl] for k, sl in st._slot_of.items())
+            assert int(st._used.sum()) == len(order) and len(order) + len(st._free) == 24
+
+
 def test_bucketed_rir_store_routes_by_length_and_never_reallocates_the_short_bucket():
     """SURVEY 8(f)2 / VERDICT r2: one capacity for every row meant that ONE long RIR reallocated and copied the whole bank
     (RirStore._ensure_cap) and lengthened every slot.  BucketedRirStore keeps a sub-store per length class: keys live in

@@ -156,3 +156,79 @@ def test_bucketed_store_load_files_routes_by_probed_length(wavs):
         assert np.array_equal(s1.stores[b].bank.data[g - s1.first[b]].numpy(), s2.stores[b].bank.data[r_ - s2.first[b]].numpy())
         assert s1.host_len[g] == s2.host_len[r_]
     assert s1.load_files(paths, paths) == got                  # hits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("from_host", [True, False])
+def test_bank_scatter_rows_equals_a_numpy_scatter(from_host):
+    """ss_bank_scatter_rows_f32 (k_scatter_rows): staged wav-layout rows -> planar bank rows + the length table, bit for
+    bit, staged block / slots / lengths in pinned host memory (the kernel reads them over the host link) or on the device;
+    odd capacities and strides (scalar path), zero-length rows, bank_len = NULL."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for cap, pad in ((16000, 0), (9001, 0), (9000, 6), (513, 1)):
+        n, R = 7, 12
+        stride = 2 * cap + pad
+        staged = torch.zeros((n, stride), dtype=torch.float32, pin_memory=True)
+        lens = np.array([cap, 0, 1, cap - 1, cap // 2, 2, 3][:n], np.int32)
+        snp = staged.numpy()
+        for i, L in enumerate(lens):
+            snp[i, :2 * L] = rng.standard_normal(2 * L).astype(np.float32)
+        slots = rng.permutation(R)[:n].astype(np.int32)
+        t_slots = torch.from_numpy(slots.copy()).pin_memory()
+        t_lens = torch.from_numpy(lens.copy()).pin_memory()
+        bank = torch.full((R, 2, cap), 7.0, device=dev)
+        bank_len = torch.full((R,), -5, dtype=torch.int32, device=dev)
+        src, sl_t, ln_t = (staged, t_slots, t_lens) if from_host else (staged.to(dev), t_slots.to(dev), t_lens.to(dev))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lib = _lib.load()
+        _lib.check(lib.ss_bank_scatter_rows_f32(src.data_ptr(), stride, sl_t.data_ptr(), ln_t.data_ptr(), n, bank.data_ptr(),
+                                                bank.stride(0), bank.stride(1), cap, bank_len.data_ptr(), stream), "scatter")
+        torch.cuda.synchronize()
+        want = np.full((R, 2, cap), 7.0, np.float32)
+        want_len = np.full((R,), -5, np.int32)
+        for i, (sl, L) in enumerate(zip(slots, lens)):
+            want[sl] = 0.0
+            want[sl, :, :L] = snp[i, :2 * L].reshape(L, 2).T
+            want_len[sl] = L
+        assert np.array_equal(bank.cpu().numpy(), want) and np.array_equal(bank_len.cpu().numpy(), want_len)
+        _lib.check(lib.ss_bank_scatter_rows_f32(src.data_ptr(), stride, sl_t.data_ptr(), ln_t.data_ptr(), n, bank.data_ptr(),
+                                                bank.stride(0), bank.stride(1), cap, None, stream), "scatter")
+        torch.cuda.synchronize()
+        assert np.array_equal(bank.cpu().numpy(), want)
+        assert lib.ss_bank_scatter_rows_f32(src.data_ptr(), 2 * cap - 2, sl_t.data_ptr(), ln_t.data_ptr(), n, bank.data_ptr(),
+                                            bank.stride(0), bank.stride(1), cap, None, stream) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("from_host", [True, False])
+def test_gpu_store_loads_files_and_live_rows_like_the_host_store(wavs, from_host):
+    """RirStore.load_files / upload_rows on a GPU store (one launch of the library's scatter per block) leave the bank the
+    host store's torch scatter leaves: rows, lengths, clipping flags - also after a second block reuses the staging memory."""
+    import torch
+    names = ["a", "ragged", "one", "empty", "long", "i16", "junk", "list", "tiny"]
+    paths = [wavs[n] for n in names]
+    for truncate_to in (16000, None):
+        g = RirStore(16, 16000, "cuda:0", truncate_to=truncate_to)
+        g.scatter_from_host = from_host
+        h = RirStore(16, 16000, "cpu", truncate_to=truncate_to)
+        sg, sh = g.load_files(paths, paths), h.load_files(paths, paths)
+        sg2, sh2 = g.load_files(paths[::-1][:4] + ["x"], paths[::-1][:4] + [wavs["a"]]), h.load_files(paths[::-1][:4] + ["x"], paths[::-1][:4] + [wavs["a"]])
+        torch.cuda.synchronize()
+        assert g.cap == h.cap
+        for a, b in zip(sg + sg2, sh + sh2):
+            assert np.array_equal(g.bank.data[a].cpu().numpy(), h.bank.data[b].numpy())
+            assert int(g.bank.lengths[a]) == int(h.bank.lengths[b]) == g.host_len[a] == h.host_len[b]
+            assert g._clipped[a] == h._clipped[b]
+    rng = np.random.default_rng(9)
+    g, h = RirStore(8, 4000, "cuda:0"), RirStore(8, 4000, "cpu")
+    g.scatter_from_host = from_host
+    for rep in range(3):
+        rows = [rng.standard_normal((int(L), 2)).astype(np.float32) for L in rng.integers(1, 9000, 5)]
+        slots = rng.permutation(8)[:5].tolist()
+        g.upload_rows(slots, rows)
+        h.upload_rows(slots, rows)
+        torch.cuda.synchronize()
+        assert g.cap == h.cap and np.array_equal(g.bank.data.cpu().numpy(), h.bank.data.numpy())
+        assert np.array_equal(g.bank.lengths.cpu().numpy(), h.bank.lengths.numpy()) and np.array_equal(g.host_len, h.host_len)
