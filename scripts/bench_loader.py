@@ -85,8 +85,9 @@ def scene_load(dev, root, sr, n, native, workers):
     return {"files": n, "seconds": round(dt, 4), "files_per_s": round(n / dt, 1), "GBps": round(n * sr * 8 / dt / 1e9, 3)}
 
 
-def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources, profile=False):
-    """trainer half of a vector step with round(rate * n_envs) envs on a never-seen pose"""
+def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources, profile=False, full_store=False):
+    """trainer half of a vector step with round(rate * n_envs) envs on a never-seen pose; full_store: a store that holds the
+    resident set and little more, so every miss evicts (the steady state against a data set larger than the HBM set aside)"""
     from ss_amd.deferred import DeferredResolver, attach_deferred
     from ss_amd.rollout import RolloutStorage
     from ss_amd import sim_audio
@@ -108,7 +109,7 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
     rng.shuffle(poses)
     n_res = 4 * n_envs                                         # poses resident before the clock starts
     assert len(poses) >= n_res + (steps + warm) * m, "scene too small for this miss rate"
-    eng = AudioEngine(sr, device=dev, rir_slots=n_res + (steps + warm + 1) * m + 64)
+    eng = AudioEngine(sr, device=dev, rir_slots=(n_res + 2 * m + 8) if full_store else n_res + (steps + warm + 1) * m + 64)
     sims = [DSim(sounds, n_nodes, rng) for _ in range(n_envs)]
     for s_ in sims:
         s_._duration = 10 ** 9
@@ -171,6 +172,7 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
         print(st.getvalue()[:7000], flush=True)
     hm = float(np.median(host))
     return {"mode": mode, "reader": "native" if native else "scipy", "miss_rate": rate, "new_poses_per_step": m,
+            "store": f"full: {eng.store.slots} slots, every miss evicts" if full_store else "roomy: no evictions",
             "trainer_half_us_per_step_median": round(1e6 * hm, 1), "trainer_half_us_per_step_mean": round(1e6 * float(np.mean(host)), 1),
             "env_steps_per_s_trainer_half": round(n_envs / float(np.mean(host)), 1),
             "env_steps_per_s_wall_incl_worker_half": round(n_envs * steps / wall, 1),
@@ -284,6 +286,10 @@ def main():
                 r = miss_steps(dev, root, sr, n_nodes, a.envs, rate, a.steps, native, mode, sources)
                 out["miss_steps"].append(r)
                 print(json.dumps(r), flush=True)
+    for rep in range(2):                                        # ... and with a FULL store (every miss evicts an old pose)
+        r = miss_steps(dev, root, sr, n_nodes, a.envs, 0.05, a.steps, True, "deferred", sources, full_store=True)
+        out["miss_steps"].append(r)
+        print(json.dumps(r), flush=True)
     for envs in (8, a.envs):                                    # the reference's per-GPU env count, and the headline's
         for prefetch in (True, False, True, False):
             r = walk_steps(dev, root, sr, n_nodes, envs, 320 if envs < 32 else 160, prefetch, sources)

@@ -4,7 +4,8 @@
 # traffic.json in place under profiles/r5/ - the headline lines again so that roofline.traffic is filled in; the RIR miss path
 # (scripts/bench_loader.py), SS2.0 deferred mode, the boundary modes, the eager profile, the feature kernels.  Everything lands
 # in gpurun_out/prof_r5/ (copy to profiles/r5/).  The same-box A/B files of the round (kbench_parts_*.txt, kbench_lanes.txt,
-# ab_sort_*.json) come from scripts/gpu_r5_{a,b,c,f}.sh with the -DSS_AB library (prebuilt into gpurun_in/).
+# ab_sort_*.json, host_profile.txt) come from scripts/gpu_r5_{a,b,c,f}.sh / gpu_host_profile.sh with the -DSS_AB library (prebuilt
+# into gpurun_in/); pmc_cfg1.txt from gpu_pmc_small.sh, miss_breakdown.txt from gpu_r5_i.sh.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r5"
@@ -23,11 +24,13 @@ timeout 600 python scripts/bench_loader.py --out "$OUT/loader.json" > "$OUT/load
 for i in 1 2 3; do
   timeout 300 python scripts/bench_deferred_continuous.py >> "$OUT/bench_deferred_continuous.jsonl" 2> /dev/null
   timeout 300 python scripts/bench_deferred_continuous.py --walk >> "$OUT/bench_deferred_continuous.jsonl" 2> /dev/null
+  timeout 300 python scripts/bench_deferred_continuous.py --scatter-copy >> "$OUT/bench_deferred_continuous.jsonl" 2> /dev/null
 done
 cut -c1-330 "$OUT/bench_deferred_continuous.jsonl"
 timeout 600 python scripts/bench_boundary.py > "$OUT/bench_boundary.jsonl" 2> "$OUT/bench_boundary.err"; echo "boundary rc=$?"
 timeout 300 python scripts/prof_eager.py > "$OUT/prof_eager.txt" 2>&1; echo "eager rc=$?"; grep "^eager" "$OUT/prof_eager.txt"
 timeout 300 python scripts/kbench_features.py > "$OUT/kbench_features.json" 2>/dev/null; cat "$OUT/kbench_features.json"
+for r in 0.01 0.05 0.25; do timeout 200 python scripts/miss_breakdown.py --rate $r 2>&1 | grep -v amdgpu | tail -12 >> "$OUT/miss_breakdown.txt"; done
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/prof_r5/bench_*.json')):

@@ -294,8 +294,9 @@ class DeferredResolver:
         self._native_reader = None                          # (rir_reader, stock wav reader?, lenient?), decided on first use
         self.column_steps = self.walk_steps = 0
         # resident RIR files: sorted composite keys (table << 40 | receiver << 20 | source) -> store slot
-        self._pair_keys = np.zeros((0,), np.int64)
-        self._pair_slots = np.zeros((0,), np.int64)
+        self._pk = np.zeros((0,), np.int64)                 # resident (table, receiver, source) keys, sorted: _pair_keys
+        self._ps = np.zeros((0,), np.int64)                 # ... and their store slots: _pair_slots
+        self._evq: List[int] = []                           # keys the store has evicted since the arrays were last read
         self._tables = None                       # the arrays above as the C struct of ss_ctx_observe_requests (rebuilt on change)
         # pose_cache workers: env -> [epoch, {pose: pool row}], pools of cached output rows on the device
         self._pose_maps: Dict[int, list] = {}
@@ -424,11 +425,43 @@ class DeferredResolver:
                 self._lv_slots[key[1], key[2]], self._lv_seqs[key[1], key[2]] = -1, 0
             return
         if isinstance(key, tuple) and len(key) == 2 and key[0] == "ix":
-            pos = int(np.searchsorted(self._pair_keys, key[1]))
-            if pos < self._pair_keys.shape[0] and self._pair_keys[pos] == key[1]:
-                self._pair_keys = np.delete(self._pair_keys, pos)
-                self._pair_slots = np.delete(self._pair_slots, pos)
-                self._tables = None
+            # queued: a miss step against a full store evicts one pose per new pose, and one np.delete per array and victim
+            # was most of what such a step cost beyond a step into free slots (profiles/r5/NOTES.md section 2)
+            self._evq.append(key[1])
+            self._tables = None                             # (the C tables point at arrays that still hold the key)
+
+    def _drop_evicted(self) -> None:
+        ev = np.asarray(self._evq, np.int64)
+        self._evq = []
+        n = self._pk.shape[0]
+        if n == 0:
+            return
+        pos = np.minimum(np.searchsorted(self._pk, ev), n - 1)
+        pos = pos[self._pk[pos] == ev]
+        if pos.shape[0]:
+            keep = np.ones((n,), bool)
+            keep[pos] = False
+            self._pk, self._ps = self._pk[keep], self._ps[keep]
+
+    @property
+    def _pair_keys(self) -> np.ndarray:
+        if self._evq:
+            self._drop_evicted()
+        return self._pk
+
+    @_pair_keys.setter
+    def _pair_keys(self, v) -> None:
+        self._pk = v
+
+    @property
+    def _pair_slots(self) -> np.ndarray:
+        if self._evq:
+            self._drop_evicted()
+        return self._ps
+
+    @_pair_slots.setter
+    def _pair_slots(self, v) -> None:
+        self._ps = v
 
     def _load_pairs(self, pair_keys: np.ndarray, which: np.ndarray, reload: bool = False) -> None:
         """RIR files of the composite keys at positions `which` -> store slots -> the resident-pair arrays (the
