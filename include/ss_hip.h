@@ -371,7 +371,7 @@ int ss_wav_read_rirs_f32(const char* const* paths, int n, float* dst, long long 
  * staged[i*staged_row_stride + 2*j + c] - into the planar bank rows bank[slots[i]*unit_stride + c*chan_stride + j], zeros
  * behind each row's length up to `cap`, and lens[i] into bank_len[slots[i]] (bank_len may be NULL).  `staged`, `slots`
  * and `lens` may be PINNED HOST memory (the kernel pulls the samples over the host link: one launch, no staging copy) or
- * device memory; bank / bank_len are device memory.  Asynchronous on `stream`: the caller keeps the staged block alive and
+ * device memory (pageable host memory is refused: SS_EINVAL); bank / bank_len are device memory.  Asynchronous on `stream`: the caller keeps the staged block alive and
  * unchanged until the launch has run.  Replaces the reference's per-file host path simulator.py:615-624 -> numpy -> (no
  * device at all there) for what follows ss_wav_read_rirs_f32 / ss_rows_gather_f32.  Returns 0 / SS_EINVAL / -hipError_t. */
 int ss_bank_scatter_rows_f32(const float* staged, long long staged_row_stride, const int* slots, const int* lens, int n,

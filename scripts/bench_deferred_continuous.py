@@ -19,6 +19,8 @@ ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--profile", action="store_true", help="cProfile of the trainer half over the timed steps")
 ap.add_argument("--scatter-copy", action="store_true", help="A/B: H2D copy of the staged rows, then the scatter on the device copy "
                 "(default: the scatter kernel reads the pinned block itself)")
+ap.add_argument("--gather-threads", type=int, default=0, help="A/B: host threads of the row gather (default: the store's 8)")
+ap.add_argument("--breakdown", action="store_true", help="perf_counter around the stages of the trainer half")
 ap.add_argument("--walk", action="store_true", help="force the per-request walk (round 4's path: fast=False) - same-box A/B")
 a = ap.parse_args()
 sr, N, L = 16000, a.envs, a.rir_len
@@ -54,6 +56,29 @@ for i, s in enumerate(sims):
     attach_deferred(s, env_rank=i, continuous=True)
 eng = AudioEngine(sr, device="cuda:0", rir_slots=2 * N + 8, rir_cap=L, step_time=0.25, wrap=True)
 eng.store.scatter_from_host = not a.scatter_copy
+if a.gather_threads > 0:
+    eng.store.gather_threads = a.gather_threads
+acc = {}
+if a.breakdown:
+    from ss_amd import renderer as _R, deferred as _D
+
+    def _wrap(obj, name, tag):
+        f = getattr(obj, name)
+
+        def g(*ar, **kw):
+            t = time.perf_counter()
+            try:
+                return f(*ar, **kw)
+            finally:
+                acc[tag] = acc.get(tag, 0) + time.perf_counter() - t
+        setattr(obj, name, g)
+    _wrap(_R.RirStore, "upload_rows", "upload_rows")
+    _wrap(_R.RirStore, "_scatter_staged", "scatter_staged")
+    _wrap(_R.AudioEngine, "observe_columns", "observe_columns")
+    _wrap(_D.DeferredResolver, "_live_columns", "live_columns (incl. upload_rows)")
+    _wrap(_D.DeferredResolver, "resolve", "resolve")
+    from ss_amd import _lib as _L
+    _wrap(_L.load(), "ss_rows_gather_f32", "ss_rows_gather_f32")
 res = DeferredResolver(eng, fast=False) if a.walk else DeferredResolver(eng)
 sg = torch.empty((N, 65, 26, 2), device="cuda:0")
 w_us, t_us = [], []
@@ -62,6 +87,7 @@ pr = cProfile.Profile()
 for k in range(a.warmup + a.steps):
     if k == a.warmup:
         torch.cuda.synchronize(); t_start = time.perf_counter()
+        acc.clear()
     t0 = time.perf_counter()
     reqs = [s.get_current_spectrogram_observation(None) for s in sims]
     t1 = time.perf_counter()
@@ -84,5 +110,8 @@ print(json.dumps({"mode": "deferred, SoundSpaces 2.0 live RIRs + CROSSFADE", "sc
                   "worker_half_us_per_step_all_envs": round(float(np.median(w_us)), 1),
                   "h2d_mb_per_step": round(N * 2 * L * 4 / 1e6, 2), "pcie_floor_us_per_step": round(N * 2 * L * 4 / 63e3, 1),
                   "both_halves_and_sim_steps_serial_env_steps_per_s": round(N * a.steps / dt, 1)}))
+if a.breakdown:
+    nst = a.steps
+    print("breakdown, us per step (mean over the %d timed steps): " % nst + ", ".join("%s %.1f" % (k_, 1e6 * v / nst) for k_, v in acc.items()))
 if a.profile:
     st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(22); print(st.getvalue()[:5000])

@@ -1227,8 +1227,10 @@ static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audio
     // pending - a trainer that has just read its actions back, a vector env between two policy steps - needs none.
     static const bool always_fence = ab_flag("SS_HIP_ALWAYS_FENCE");        // (A/B builds only)
     hipError_t e = always_fence ? hipErrorNotReady : hipStreamQuery(static_cast<hipStream_t>(stream));
-    if (e == hipErrorNotReady) {
-        if (!always_fence) (void)hipGetLastError();            // (not an error: do not leave it for the launch's own check)
+    if (e != hipSuccess) {
+        // work pending - or a stream that cannot be asked (one being captured into a graph): order the lane behind it, and
+        // let the fence's own calls report whatever is really wrong with the stream
+        if (!always_fence) (void)hipGetLastError();            // (do not leave the query's answer for the launch's own check)
         e = hipEventRecord(c.ev_in, static_cast<hipStream_t>(stream));
         if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
     }
@@ -1555,6 +1557,13 @@ extern "C" int ss_bank_scatter_rows_f32(const float* staged, long long staged_ro
     if (n == 0) return 0;
     if (!staged || !slots || !lens || !bank || n < 0 || cap <= 0 || unit_stride <= 0 || chan_stride <= 0 ||
         staged_row_stride < 2LL * cap) return SS_EINVAL;
+    // the kernel dereferences all three inputs: pageable host memory here would be a GPU memory fault (the process dies), not
+    // an error code - refuse anything the runtime does not know as device-accessible (pinned / registered host, device, managed)
+    for (const void* ptr : {static_cast<const void*>(staged), static_cast<const void*>(slots), static_cast<const void*>(lens)}) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return SS_EINVAL; }
+        if (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) return SS_EINVAL;
+    }
     ssk::ScatterRowsParams p;
     p.staged = staged; p.slots = slots; p.lens = lens; p.bank = bank; p.bank_len = bank_len;
     p.staged_stride = staged_row_stride; p.unit_stride = unit_stride; p.chan_stride = chan_stride; p.cap = cap;

@@ -199,6 +199,14 @@ def test_bank_scatter_rows_equals_a_numpy_scatter(from_host):
         assert np.array_equal(bank.cpu().numpy(), want)
         assert lib.ss_bank_scatter_rows_f32(src.data_ptr(), 2 * cap - 2, sl_t.data_ptr(), ln_t.data_ptr(), n, bank.data_ptr(),
                                             bank.stride(0), bank.stride(1), cap, None, stream) == -1
+        # pageable host memory would be a GPU memory fault inside the kernel: refused, nothing launched
+        pageable = np.zeros((n, stride), np.float32)
+        assert lib.ss_bank_scatter_rows_f32(pageable.ctypes.data, stride, sl_t.data_ptr(), ln_t.data_ptr(), n, bank.data_ptr(),
+                                            bank.stride(0), bank.stride(1), cap, None, stream) == -1
+        assert lib.ss_bank_scatter_rows_f32(src.data_ptr(), stride, slots.ctypes.data, ln_t.data_ptr(), n, bank.data_ptr(),
+                                            bank.stride(0), bank.stride(1), cap, None, stream) == -1
+        torch.cuda.synchronize()
+        assert np.array_equal(bank.cpu().numpy(), want)
 
 
 @pytest.mark.gpu
@@ -232,3 +240,24 @@ def test_gpu_store_loads_files_and_live_rows_like_the_host_store(wavs, from_host
         torch.cuda.synchronize()
         assert g.cap == h.cap and np.array_equal(g.bank.data.cpu().numpy(), h.bank.data.numpy())
         assert np.array_equal(g.bank.lengths.cpu().numpy(), h.bank.lengths.numpy()) and np.array_equal(g.host_len, h.host_len)
+
+
+def test_upload_rows_takes_read_only_rows_and_routes_odd_layouts_row_by_row():
+    """``RirStore.upload_rows`` reads the rows' addresses through a ctypes view of their buffers (a quarter of the cost of
+    ``__array_interface__`` at 128 rows per step); read-only arrays (``np.frombuffer`` of a pipe's bytes) have no such view
+    and take the slow way; a step with a row in another layout (float64, planar, a strided view) goes row by row through
+    ``_upload``.  Same bank either way."""
+    rng = np.random.default_rng(3)
+    base = [rng.standard_normal((int(L), 2)).astype(np.float32) for L in (100, 1, 777, 1500)]
+    ro = [np.frombuffer(r.tobytes(), np.float32).reshape(r.shape) for r in base]
+    assert not ro[0].flags.writeable
+    odd = [base[0].astype(np.float64), np.ascontiguousarray(base[1].T), base[2], rng.standard_normal((1500, 4)).astype(np.float32)[:, :2]]
+    want = [base[0], base[1], base[2], odd[3]]
+    for rows, ref in ((base, base), (ro, base), (odd, want)):
+        a, b = RirStore(8, 2000, "cpu"), RirStore(8, 2000, "cpu")
+        a.upload_rows([5, 0, 3, 6], rows)
+        for sl, r in zip([5, 0, 3, 6], ref):
+            b._upload(sl, r)
+        b.flush_uploads()
+        assert np.array_equal(a.bank.data.numpy(), b.bank.data.numpy())
+        assert np.array_equal(a.bank.lengths.numpy(), b.bank.lengths.numpy()) and np.array_equal(a.host_len, b.host_len)
