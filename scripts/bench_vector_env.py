@@ -94,12 +94,12 @@ def run(mode, a, root, n_nodes, sounds):
     res = None
     if mode == "deferred":
         from ss_amd.deferred import DeferredResolver
-        from ss_amd.renderer import AudioEngine, load_scene_rirs
+        from ss_amd.renderer import AudioEngine
         from ss_amd.sim_audio import wav_rir_reader
         eng = AudioEngine(SR, device=dev, rir_slots=4 * n_nodes * n_nodes + 64)
         res = DeferredResolver(eng, rir_reader=wav_rir_reader, fast=True)
         if not a.no_preload:
-            load_scene_rirs(eng.store, root, wav_rir_reader)
+            res.preload_scene(root)
     rng = np.random.default_rng(7)
     trainer_us = []
     try:

@@ -505,6 +505,36 @@ class DeferredResolver:
             self._pair_keys, self._pair_slots = keys2, slots2
         self._tables = None
 
+    def preload_scene(self, binaural_rir_dir: str, azimuths=(0, 90, 180, 270), limit: Optional[int] = None) -> int:
+        """Bulk load of one scene's RIR files, `<binaural_rir_dir>/<azimuth>/<receiver>_<source>.wav` (soundspaces/README.md:
+        38-42, simulator.py:615-616), into the HBM store UNDER THIS RESOLVER'S KEYS, so that no step of an episode in the scene
+        goes through the miss path (``renderer.load_scene_rirs`` keys the rows by file path: that serves the eager adapter).
+        At most as many poses as the store has free entries (nothing resident is evicted for a pre-load), `limit` if given.
+        Returns the number of poses loaded."""
+        store = self.engine.store
+        ks = []
+        for az in azimuths:
+            d = os.path.join(binaural_rir_dir, str(az))
+            if not os.path.isdir(d):
+                continue
+            if name_key(d) not in self._key_names:
+                self._learn_table(os.path.join(d, "x.wav"))
+            elif self._key_names[name_key(d)] != d:
+                raise KeyError(f"deferred audio: {d!r} and {self._key_names[name_key(d)]!r} share a CRC-32 key")
+            t = self._table_dirs.index(d)
+            for name in os.listdir(d):
+                r, sep, s_ = name[:-4].partition("_")
+                if name.endswith(".wav") and sep and r.isdigit() and s_.isdigit() and int(r) < (1 << 20) and int(s_) < (1 << 20):
+                    ks.append((t << 40) | (int(r) << 20) | int(s_))
+        ks = np.unique(np.asarray(ks, np.int64))
+        ks = ks[self._lookup(self._pair_keys, self._pair_slots, ks) < 0] if ks.shape[0] else ks
+        room = len(getattr(store, "_free", ())) if hasattr(store, "_free") else ks.shape[0]
+        n = min(ks.shape[0], room, ks.shape[0] if limit is None else int(limit))
+        for lo in range(0, n, 256):
+            store.begin_batch()
+            self._load_pairs(ks, np.arange(lo, min(lo + 256, n)), reload=True)      # (reload: no sibling prefetch on top)
+        return n
+
     def _sibling_tables(self, t: int) -> list:
         """ids of the other azimuth directories next to table t's (`<binaural_rir_dir>/<azimuth>`), registered on first need"""
         sib = self._siblings.get(t)

@@ -333,3 +333,39 @@ def test_pose_miss_prefetches_the_other_azimuths_of_the_pair(tmp_path):
     attach_deferred(sim2, env_rank=0)
     small.resolve([sim2.get_current_spectrogram_observation(None)], want_audiogoal=True)
     assert small.prefetched == 0 and small.engine.store.misses == 1
+
+
+def test_preload_scene_makes_every_pose_of_the_scene_a_hit(tmp_path):
+    """``DeferredResolver.preload_scene``: the scene's files enter the store under the resolver's own keys (the workers' CRC of
+    `<binaural_rir_dir>/<azimuth>` + receiver + source), so the steps that follow are plain hits of the C record path - no miss
+    step, no file read - and render what the reference renders; capped by the store's free entries."""
+    from scipy.io import wavfile
+    from ss_amd.sim_audio import wav_rir_reader
+    rng = np.random.default_rng(12)
+    sounds, _ = make_world()
+    rirs = {}
+    for az in (0, 90, 180, 270):
+        (tmp_path / str(az)).mkdir()
+        for r in range(3):
+            h = np.ascontiguousarray(O.synth_rir(rng, SR, n=1)[0].T)
+            wavfile.write(str(tmp_path / str(az) / f"{r}_7.wav"), SR, h)
+            rirs[(az, r)] = h
+        open(str(tmp_path / str(az) / "notes.txt"), "w").write("not a RIR")
+    sim = FakeSim(SR, sounds, {})
+    sim.binaural_rir_dir = str(tmp_path)
+    attach_deferred(sim, env_rank=0)
+    eng = OracleColumnEngine(SR, slots=16).enable_native_requests()
+    res = DeferredResolver(eng, rir_reader=wav_rir_reader)
+    assert res.preload_scene(str(tmp_path)) == 12 and eng.store.misses == 12
+    assert res.preload_scene(str(tmp_path)) == 0                                # resident already
+    for k, (rot, recv) in enumerate([(0, 0), (90, 1), (180, 2), (270, 0), (90, 2)]):
+        sim._rotation_angle, sim._receiver_position_index = rot, recv
+        sim._episode_step_count += 1
+        out = res.resolve([pickle.loads(pickle.dumps(sim.get_current_spectrogram_observation(None)))], want_audiogoal=True)
+        ref = O.compute_audiogoal(sounds[sim._current_sound], rirs[(sim.azimuth_angle, recv)], SR)
+        assert O.relerr(out["audiogoal"][0].numpy(), ref) < 1e-5
+    # (the very first step registers the worker's sound: a miss step of the record path without a file read)
+    assert eng.store.misses == 12 and res.miss_steps <= 1
+    small = DeferredResolver(OracleColumnEngine(SR, slots=5).enable_native_requests(), rir_reader=wav_rir_reader)
+    assert small.preload_scene(str(tmp_path)) == 5 and small.engine.store.misses == 5
+    assert small.preload_scene(str(tmp_path), limit=3) == 0                     # no free entry left: nothing is evicted for it
