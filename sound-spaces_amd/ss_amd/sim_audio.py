@@ -90,8 +90,9 @@ def _render_to_host(backend, req, want_spectrogram: bool, want_audiogoal: bool =
         n_ag, n_sg = 2 * sr, shp[0] * shp[1] * shp[2]
         dbuf = torch.empty(n_ag + n_sg, dtype=torch.float32, device=eng.renderer.device)
         hbuf = torch.empty(n_ag + n_sg, dtype=torch.float32).pin_memory()
-        st = backend._stage = (dbuf, hbuf, hbuf.numpy(), shp, n_ag, n_sg, torch, ops)
-    dbuf, hbuf, h, shp, n_ag, n_sg, torch, ops = st
+        st = backend._stage = (dbuf, hbuf, hbuf.numpy(), shp, n_ag, n_sg, torch, ops, dbuf[:0],
+                               torch.ops.ss_hip.eager_obs if ops.NATIVE_OPS else None)
+    dbuf, hbuf, h, shp, n_ag, n_sg, torch, ops, dbuf0, eager_op = st
     n = n_ag + n_sg if want_spectrogram else n_ag
     if ops.NATIVE_OPS and hasattr(eng, "context") and not getattr(eng, "_no_native_eager", False):
         # ONE C++ dispatch (csrc/ss_torch_ops.cpp::eager_obs): the library's planner + window cache + launch
@@ -102,9 +103,9 @@ def _render_to_host(backend, req, want_spectrogram: bool, want_audiogoal: bool =
             eng._no_native_eager = True
             return _render_to_host(backend, req, want_spectrogram, want_audiogoal)
         wrap = 1 if req.wrap is None else int(bool(req.wrap))
-        torch.ops.ss_hip.eager_obs(ctx.handle, int(req.sound), int(req.t0), int(req.rir), int(req.dis_sound), int(req.dis_rir),
-                                   int(req.last_rir), wrap, wrap if req.last_wrap is None else int(bool(req.last_wrap)),
-                                   dbuf[:0] if EAGER_DIRECT_HOST else dbuf, hbuf, sr, want_spectrogram, want_audiogoal)
+        eager_op(ctx.handle, int(req.sound), int(req.t0), int(req.rir), int(req.dis_sound), int(req.dis_rir),
+                 int(req.last_rir), wrap, wrap if req.last_wrap is None else int(bool(req.last_wrap)),
+                 dbuf0 if EAGER_DIRECT_HOST else dbuf, hbuf, sr, want_spectrogram, want_audiogoal)
     else:
         eng.observe([req], want_audiogoal=True, want_spectrogram=want_spectrogram, audiogoal_out=dbuf[:n_ag].view(1, 2, sr),
                     spectrogram_out=dbuf[n_ag:].view((1,) + shp) if want_spectrogram else None)
@@ -134,6 +135,7 @@ class HipSimAudio:
         self._ag_wanted = False                      # an audiogoal read has been seen: fetch both outputs per launch
         self._pending = {}                           # pose -> (spectrogram it belongs to, request) awaiting an audiogoal read
         self._refs = []
+        self._paths = {}                             # (rir dir, azimuth, receiver, source) -> the RIR file path
         self._env_id = next(HipSimAudio._ids)        # stable key of this env's live RIR row (USE_RENDERED_OBSERVATIONS False)
         for name in ("_audiogoal_cache", "_spectrogram_cache"):
             if not isinstance(getattr(sim, name, None), dict):
@@ -147,8 +149,12 @@ class HipSimAudio:
     def _rir_slot(self, source_index, from_file: bool = False) -> int:
         sim = self.sim
         if from_file or sim.config.USE_RENDERED_OBSERVATIONS:
-            path = os.path.join(sim.binaural_rir_dir, str(sim.azimuth_angle),
-                                "{}_{}.wav".format(sim._receiver_position_index, source_index))      # :615-616, :650-651
+            key = (sim.binaural_rir_dir, sim.azimuth_angle, sim._receiver_position_index, source_index)
+            path = self._paths.get(key)                  # (the string is built once per pose: 2 us of a 45-us eager call)
+            if path is None:
+                if len(self._paths) >= 1 << 16:
+                    self._paths.clear()
+                path = self._paths[key] = os.path.join(key[0], str(key[1]), "{}_{}.wav".format(key[2], source_index))  # :615-616, :650-651
             self._refs.append(path)
             return self.engine.rir_slot(path, lambda: self.rir_reader(path))
         # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded.  The key is a
