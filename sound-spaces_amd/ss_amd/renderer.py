@@ -1361,12 +1361,12 @@ class AudioEngine:
         ctx = self.context()
         n_sync = self.store.sync_spectra()
         bank = self.store.bank
-        key = (bank.data.data_ptr(), bank.data.shape[2], None if bank.spectra is None else bank.spectra.data_ptr())
-        if self._ctx_bank != key or n_sync:
+        cur = self._ctx_bank                                     # (the tensors the context was last pointed at: identity, not
+        if n_sync or cur is None or cur[0] is not bank.data or cur[1] is not bank.spectra:   # two data_ptr() calls per step)
             ctx.set_rir_bank(bank.data, bank.lengths)
             if bank.spectra is not None and self.store.spectral:
                 ctx.set_rir_spectra(bank.spectra)
-            self._ctx_bank = key
+            self._ctx_bank = (bank.data, bank.spectra)
         return ctx
 
     def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None) -> int:
