@@ -491,8 +491,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test "
                                                       "the multi-rank flow on a 1-GPU box)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams that consecutive steps alternate between; 0 = auto: 1 on one GPU (per-launch durations "
-                         "stay comparable with the rocprofv3 kernel trace), 2 when the all-gather overlaps the kernels")
+                    help="internal streams (lanes) of the product path's overlap mode: 1 .. 4; 0 = auto: 2, or 3 for steps "
+                         "that fill at most half the chip (<= 128 (unit, ear) rows)")
     ap.add_argument("--regions", type=int, default=0,
                     help="timed regions of --steps steps each for the headline pass (value = the median region); 0 = auto: 25 "
                          "when --steps <= 50 (a 20-step region is 0.5 ms), else 1")
@@ -672,7 +672,7 @@ def main():
         mel_start, mel_w = torch.from_numpy(ms_np).to(dev), torch.from_numpy(mw_np).to(dev)
         T_fr = 1 + sr // 160
         feat_sets = []
-        for _ in range(2):                                     # one output set per lane of the overlap mode
+        for _ in range(4):                                     # one output set per lane of the overlap mode
             lm = torch.empty((N, n_mels, T_fr, 2), dtype=torch.float32, device=dev) if "logmel" in feats else None
             gc = torch.empty((N, 65, T_fr), dtype=torch.float32, device=dev) if "gccphat" in feats else None
             feat_sets.append(ctx.features(lm, mel_start, mel_w, 1e-6, gc, 32, 1e-8))
@@ -703,20 +703,21 @@ def main():
                                      exchange_cls=PeerCopyExchange if args.exchange in ("peercopy", "gather") else None, **kw)
         ex = cx.exchange if cx is not None else None
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
-        sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(max(2, S, lanes))]
-        ag_bufs = ([torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(max(S, lanes))] if want_ag
-                   else [None] * max(S, lanes))
+        n_out = 16 if lanes == 3 else max(2, S, lanes)             # (3 lanes: lane = ring slot % 3, the ring has 16 slots)
+        sg_buf = [torch.empty((N,) + r.spectrogram_shape, dtype=torch.float32, device=dev) for _ in range(n_out)]
+        ag_bufs = ([torch.empty((N, 2, sr), dtype=torch.float32, device=dev) for _ in range(n_out)] if want_ag
+                   else [None] * n_out)
 
         main_stream = torch.cuda.current_stream(dev).cuda_stream
 
         def render(k, plans, columns, rows, ag):
             if use_ctx and feat_sets is not None:
-                ctx.observe_prepared_features(columns[k], rows.data_ptr(), ag.data_ptr(), main_stream, feat_sets[k & 1])
+                ctx.observe_prepared_features(columns[k], rows.data_ptr(), ag.data_ptr(), main_stream, feat_sets[k % 4])
             elif use_ctx:                                          # (unit columns converted to the C struct once, above)
                 ctx.observe_prepared(columns[k], rows.data_ptr(), None if ag is None else ag.data_ptr(), main_stream)
             elif feat_sets is not None:                            # same two launches as the product path, pre-planned units:
                 r.render_audiogoal(plans[k], out=ag)               # convolution (waveform written), then k_features, which
-                fk = feat_sets[k & 1]["keep"]                      # also pools the spectrogram from the spectra it holds
+                fk = feat_sets[k % 4]["keep"]                      # also pools the spectrogram from the spectra it holds
                 ops_mod.audio_features_into(ag, rows, fk[0], fk[3], fk[1], fk[2])
             else:
                 r.render(plans[k], spectrogram_out=rows, audiogoal_out=ag)
@@ -739,7 +740,7 @@ def main():
 
             def step(k, plans=descs, columns=preps):               # noqa: F811
                 if feat_sets is not None:
-                    ctx.observe_prepared_features(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream, feat_sets[k & 1])
+                    ctx.observe_prepared_features(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream, feat_sets[k % 4])
                 else:
                     ctx.observe_prepared(columns[k], sg_ptrs[k % n_sg], ag_ptrs[k % n_ag], main_stream)
 
@@ -885,7 +886,13 @@ def main():
         spectra = r.rirs.spectra
     exchanging = world > 1 and args.exchange != "none"
     G_head = args.gather_every if exchanging else 0
-    LANES = 2 if args.streams == 0 else max(1, min(2, args.streams))
+    # lanes of the overlap mode: 2 (the head of step k+1 under the tail of step k); 3 for steps that fill at most half the chip
+    # (<= 128 (unit, ear) rows: cfg1, cfg3, the reference's 5-10 envs) - those are throughput-bound by how many rows are in
+    # flight, not by one launch's latency (same box: +10-30 % at 5-32 envs, +2-10 % at 64, -6 % at 128: profiles/r5/NOTES.md
+    # section 1f).  Not 4: the runtime multiplexes its streams onto 4 hardware queues by default and a fourth lane then shares
+    # one (slower than 2; with GPU_MAX_HW_QUEUES=8 in the environment --streams 4 is the fastest)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    LANES = (3 if 2 * 2 * N <= n_cus else 2) if args.streams == 0 else max(1, min(4, args.streams))
 
     def rate(e):
         return {"value": round(world * N * args.steps / e, 1), "ms_per_step": round(1e3 * e / args.steps, 5)}

@@ -275,7 +275,9 @@ typedef struct ss_features {
 } ss_features;
 int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* audiogoal, float* spectrogram,
                             const ss_features* f, void* stream);
-/* Overlap mode.  ss_ctx_set_overlap(ctx, 2): consecutive ss_ctx_observe calls run on two internal streams in turn, each
+/* Overlap mode.  ss_ctx_set_overlap(ctx, n), n = 2 .. 4: consecutive ss_ctx_observe calls run on n internal streams in turn
+ * (2: the head of step k+1 under the tail of step k; 3 - 4: for steps of few rows, where several launches fit the chip side by
+ * side - fused rows are then split over fewer workgroups, ConvParams::parts_log2 - and the caller has that many to issue), each
  * ordered behind what the CALLER's stream holds at the time of the call (the consumers of the output rows it overwrites,
  * uploads of the RIR rows it reads), so the head of step k+1 (descriptor and row loads: HBM latency, nothing to compute)
  * overlaps the tail of step k (STFT: no memory traffic) - what the reference's serial per-env loop

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Soak test of the context's overlap mode under window-cache churn: the same random steps (multi-second clips -> many
-(sound, t0) keys, a cache of a few dozen entries -> evictions every step, distractors on some steps) go through a context with two
-overlap lanes, eight steps in flight between joins, and through a plain single-stream context; every step's outputs must be
+(sound, t0) keys, a cache of a few dozen entries -> evictions every step, distractors on some steps) go through contexts with two,
+four and three overlap lanes, eight steps in flight between joins, and through a plain single-stream context; every step's outputs must be
 BIT-IDENTICAL (same kernels, same inputs - anything else is a race: a window spectrum overwritten while a step in flight
 still reads it, a descriptor slot reused too early).  usage: soak_ctx.py [rounds] [units]"""
 import os, sys, time
@@ -22,7 +22,8 @@ src = [O.synth_sources(rng, sr, k=1, seconds=s_)[0] for s_ in secs]
 R = 256
 bank = RirBank(torch.from_numpy(O.synth_rir(rng, sr, n=R)).to(dev), torch.full((R,), sr, dtype=torch.int32, device=dev))
 ctxs = []
-for lanes in (2, 1):
+LANES = (2, 4, 3, 1)                                               # the last one is the single-stream reference
+for lanes in LANES:
     c = AudioContext(sr, max_window_sets=64)
     for i, s_ in enumerate(src):
         c.add_source(f"s{i}", s_)
@@ -52,11 +53,12 @@ for rd in range(rounds):
             c.observe(snd, t0, rir, spectrogram_out=sg[ci][k], audiogoal_out=ag[ci][k] if want_ag else None, **kw)
         c.join()
     torch.cuda.synchronize()
-    for k in range(K):
-        if not torch.equal(sg[0][k], sg[1][k]) or (k % 2 == 0 and not torch.equal(ag[0][k], ag[1][k])):
-            bad += 1
-            print(f"round {rd} step {k}: overlap and single-stream outputs differ "
-                  f"(max |d sg| {float((sg[0][k] - sg[1][k]).abs().max()):.3e})", flush=True)
+    for ci in range(len(ctxs) - 1):
+        for k in range(K):
+            if not torch.equal(sg[ci][k], sg[-1][k]) or (k % 2 == 0 and not torch.equal(ag[ci][k], ag[-1][k])):
+                bad += 1
+                print(f"round {rd} step {k}: {LANES[ci]}-lane and single-stream outputs differ "
+                      f"(max |d sg| {float((sg[ci][k] - sg[-1][k]).abs().max()):.3e})", flush=True)
     if bad > 5:
         break
 st = ctxs[0].stats()

@@ -28,7 +28,8 @@ constexpr int kGroup = 4;         // slots released per completion event
 constexpr int kGuardTicks = 8;    // a cache entry used within the last kGuardTicks observe() calls is never evicted
                                   // (overlap mode: kRing - steps on the other lane may still be reading it; whatever is
                                   //  older than a full ring has finished, see the ring's completion events)
-constexpr int kLanes = 2;         // internal streams of the overlap mode (ss_ctx_set_overlap)
+constexpr int kLanes = 4;         // internal streams of the overlap mode (ss_ctx_set_overlap): at most kGroup - the last
+                                  // n_lanes ticks of a ring group are then on n_lanes different lanes, each lane's last
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }   // a >= 0, b > 0
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
@@ -117,7 +118,8 @@ struct Context {
     hipEvent_t ev_win[kLanes] = {};               // after the lane's latest k_source_windows launch
     long long win_seq[kLanes] = {};               // ... and how many it has recorded
     long long win_seen[kLanes][kLanes] = {};      // [waiting lane][recording lane]: highest seq already waited for
-    hipEvent_t ev_done2[kRing / kGroup] = {};     // ring release, lane 1's half of a group (ev_done: lane 0 / single stream)
+    hipEvent_t ev_done_l[kLanes][kRing / kGroup] = {};   // ring release, lane l's share of a group (l >= 1; lane 0 / single
+                                                         // stream: ev_done)
     bool lanes_made = false;
 };
 

@@ -804,7 +804,8 @@ static void ctx_free_device(ssctx::Context& c) {
             (void)hipStreamDestroy(c.lane_stream[l]);
         }
         (void)hipEventDestroy(c.ev_in);
-        for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done2[k]);
+        for (int l = 1; l < ssctx::kLanes; ++l)
+            for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done_l[l][k]);
         c.lanes_made = false;
     }
     c.pool = nullptr; c.src_dev = nullptr; c.d_desc = nullptr; c.d_win = nullptr; c.h_desc = nullptr; c.h_win = nullptr;
@@ -1036,7 +1037,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     const int k = c.ring_k, g = k / ssctx::kGroup;
     if (k % ssctx::kGroup == 0) {
         e = hipEventSynchronize(c.ev_done[g]);                 // every launch that read the group's slots has finished
-        if (e == hipSuccess && lane >= 0) e = hipEventSynchronize(c.ev_done2[g]);   // ... on either lane
+        for (int l = 1; lane >= 0 && l < c.n_lanes && e == hipSuccess; ++l) e = hipEventSynchronize(c.ev_done_l[l][g]);   // ... on every lane
         if (e != hipSuccess) return hip_err(e);
         c.group_open = lane < 0;
         c.group_stream = st;
@@ -1062,7 +1063,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     auto close_slot = [&]() -> int {
         hipError_t ee = hipSuccess;
         if (lane >= 0) {
-            if (k % ssctx::kGroup >= ssctx::kGroup - c.n_lanes) ee = hipEventRecord(lane == 0 ? c.ev_done[g] : c.ev_done2[g], st);
+            if (k % ssctx::kGroup >= ssctx::kGroup - c.n_lanes) ee = hipEventRecord(lane == 0 ? c.ev_done[g] : c.ev_done_l[lane][g], st);
         } else if (k % ssctx::kGroup == ssctx::kGroup - 1) {
             ee = hipEventRecord(c.ev_done[g], st);
             c.group_open = false;
@@ -1160,8 +1161,10 @@ int ss_ctx_set_overlap(ss_ctx* h, int n_streams) {
         e = hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming);
         if (e != hipSuccess) return hip_err(e);
         for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) {
-            e = hipEventCreateWithFlags(&c.ev_done2[k], hipEventDisableTiming);
-            if (e != hipSuccess) return hip_err(e);
+            for (int l = 1; l < ssctx::kLanes; ++l) {
+                e = hipEventCreateWithFlags(&c.ev_done_l[l][k], hipEventDisableTiming);
+                if (e != hipSuccess) return hip_err(e);
+            }
         }
         c.lanes_made = true;
     }

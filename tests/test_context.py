@@ -233,7 +233,7 @@ def test_overlap_mode_orders_a_step_behind_pending_work_of_the_callers_stream():
         for i, s_ in enumerate(src):
             c.add_source(f"s{i}", s_)
         c.set_rir_bank(bank.data, bank.lengths)
-    ctx.set_overlap(2)
+    ctx.set_overlap(4)
     sound, t0, rir = rng.integers(0, 2, 8), np.zeros(8, np.int64), np.arange(8)
     want = {}
     for name, d in (("a", data_a), ("b", data_b)):
@@ -262,8 +262,9 @@ def test_overlap_mode_orders_a_step_behind_pending_work_of_the_callers_stream():
 
 
 @pytest.mark.gpu
-def test_overlap_mode_two_lanes_equal_single_stream():
-    """ss_ctx_set_overlap(2): 90 steps alternate between two internal streams with nothing but ss_ctx_join at the end -
+@pytest.mark.parametrize("n_lanes", [2, 3, 4])
+def test_overlap_mode_two_lanes_equal_single_stream(n_lanes):
+    """ss_ctx_set_overlap(n), n = 2 .. 4: 90 steps alternate between the internal streams with nothing but ss_ctx_join at the end -
     cache misses whose spectra the OTHER lane's next step hits, evictions under a small cache, steps of different sizes
     (descriptors in place and uploaded), a refused step in the middle - every row equal to the single-stream context's."""
     import torch
@@ -279,7 +280,9 @@ def test_overlap_mode_two_lanes_equal_single_stream():
         for i, s_ in enumerate(src):
             c.add_source(f"s{i}", s_)
         c.set_rir_bank(bank.data, bank.lengths)
-    ctxs[1].set_overlap(2)
+    ctxs[1].set_overlap(n_lanes)
+    with pytest.raises(SsHipError):
+        ctxs[0].set_overlap(5)                                                   # (at most four lanes)
     steps = []
     for k in range(90):
         n = int(rng.choice([3, 40, 300]))

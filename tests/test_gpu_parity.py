@@ -1546,7 +1546,7 @@ def test_randomized_sweep_soundspaces2_through_the_context(sr, step_time, seed):
 
 
 def test_overlap_mode_soak_under_window_cache_churn():
-    """scripts/soak_ctx.py: 1200 steps with eight in flight on two overlap lanes, 167 (sound, second) keys against a window cache
+    """scripts/soak_ctx.py: 1200 steps with eight in flight on two / four / three overlap lanes, 167 (sound, second) keys against a window cache
     that has to evict on most steps - every output bit-identical to a single-stream context's (the overlap mode's
     eviction guard)."""
     import os
