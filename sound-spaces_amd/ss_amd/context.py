@@ -150,8 +150,10 @@ class AudioContext:
         self._spectra = hspec
 
     def set_overlap(self, n_streams: int = 2) -> None:
-        """Consecutive observe() calls alternate between ``n_streams`` internal streams (ss_ctx_set_overlap): the load
-        phase of step k+1 overlaps the STFT phase of step k.  Results are visible to a stream after ``join()``."""
+        """Consecutive observe() calls alternate between ``n_streams`` (2 .. 4) internal streams (ss_ctx_set_overlap): the
+        load phase of step k+1 overlaps the STFT phase of step k; 3 pays for steps that fill at most half the chip (<= 64 envs),
+        4 only with more than the runtime's default four hardware queues (GPU_MAX_HW_QUEUES=8).  Results are visible to a stream
+        after ``join()``; steps in flight must write disjoint output rows."""
         _lib.check(self.lib.ss_ctx_set_overlap(self._h, int(n_streams)), "ss_ctx_set_overlap")
         self.overlap = int(n_streams)
 
