@@ -19,7 +19,7 @@ worst = [0.0]
 for rnd in range(rounds):
     rng = np.random.default_rng(1000 * seed + rnd)
     sr = 44100 if rnd % 4 == 3 else 16000                       # every fourth round: the fused-rows kernel (k_obs_rows)
-    overlap = rnd % 5 in (1, 2, 4)                              # overlap mode: consecutive steps on two internal lanes
+    overlap = rnd % 5 in (1, 2, 4)                              # overlap mode: consecutive steps on 2 / 3 / 4 internal lanes
     t4 = 69 if sr == 44100 else 26
     secs = [1, 1, 1, 2, 4][:int(rng.integers(2, 6))]
     many_keys = rnd % 3 == 1                                    # dozens of (sound, second) windows against a small cache:
@@ -38,7 +38,7 @@ for rnd in range(rounds):
         ctx.add_source(f"s{i}", s)
     r.set_rir_bank(bank)
     ctx.set_rir_bank(bank.data, bank.lengths)
-    ctx.set_overlap(2 if overlap else 1)
+    ctx.set_overlap((2, 3, 4)[rnd % 3] if overlap else 1)     # (the caller changes streams under it: busy streams take the fence)
     spectral = rnd % 2 == 1
     if spectral:
         spectra = ops.rir_spectra(bank.data)
