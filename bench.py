@@ -685,7 +685,7 @@ def main():
         lanes = 0: pre-planned descriptors through the stateless entry points on S torch streams (kernel-rate passes; with
         S = 1 the event average IS the kernel's average launch duration, the figure the rocprofv3 kernel trace reports).
         lanes >= 1: the product path, ss_ctx_observe on the step's unit columns (planning, window cache, descriptor ring in
-        the timed region); lanes = 2: its overlap mode (consecutive steps on two internal streams, joined when a slab is
+        the timed region); lanes >= 2: its overlap mode (consecutive steps on that many internal streams, joined when a slab is
         gathered and at the end of the region).
         Per-step event records put a marker packet between consecutive launches (measured: +2-3 us per step), so the
         headline loop records only the two ends and the distribution comes from a separate pass."""
@@ -728,7 +728,7 @@ def main():
                 if cx is not None and not state["no_exchange"]:
                     render(k, plans, columns, cx.step_rows(streams), ag_bufs[k % len(ag_bufs)])
                     if use_ctx and cx.will_gather():
-                        ctx.join()                                 # the slab is complete once both lanes have drained
+                        ctx.join()                                 # the slab is complete once every lane has drained
                     cx.step_done(streams)                          # all-gather of the chunk once it is full
                 else:
                     render(k, plans, columns, sg_buf[k % len(sg_buf)], ag_bufs[k % len(ag_bufs)])
