@@ -284,7 +284,13 @@ int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* au
  * (ss_baselines/common/sync_vector_env.py:397-410) cannot do.  Results become visible to a stream through
  * ss_ctx_join(ctx, stream) (the stream waits for every step issued so far); a caller that needs step k before it issues
  * step k+1 joins every step and gets the single-stream behaviour.  n_streams = 1 switches back (synchronises the device).
- * Steps must write disjoint output rows while they are in flight (rollout rows are). */
+ * Steps must write disjoint output rows while they are in flight (rollout rows are).
+ * Threading: the ordering behind the caller's stream is elided when that stream is IDLE at the time of the call (one
+ * hipStreamQuery instead of an event record + a stream wait).  That test is only sound for a single-threaded user of `stream`:
+ * a second host thread that enqueues work on the same stream between the query and the lane's launch is NOT ordered in front
+ * of the step.  Callers that share the stream between threads must serialise ss_ctx_observe with those enqueues (the
+ * reference has one env loop per process: ss_baselines/common/sync_vector_env.py:397-410).  A stream that is being captured
+ * into a graph is never queried (hipStreamIsCapturing first); the step is then always fenced. */
 int ss_ctx_set_overlap(ss_ctx* ctx, int n_streams);
 int ss_ctx_join(ss_ctx* ctx, void* stream);
 /* One step straight from the simulators' state, struct-of-arrays (ss_amd/vector.py::VectorSimState: the int64 columns a

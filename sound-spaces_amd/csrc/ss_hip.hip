@@ -1229,11 +1229,20 @@ static int ctx_observe_any(ss_ctx* h, const ss_units* units, int n, float* audio
     // the host IS the step's bound) and a barrier packet in front of the lane's launch.  A caller's stream that has nothing
     // pending - a trainer that has just read its actions back, a vector env between two policy steps - needs none.
     static const bool always_fence = ab_flag("SS_HIP_ALWAYS_FENCE");        // (A/B builds only)
-    hipError_t e = always_fence ? hipErrorNotReady : hipStreamQuery(static_cast<hipStream_t>(stream));
+    //  a stream being captured into a graph must not be QUERIED - that is an illegal operation which invalidates
+    // the capture: ask the capture status first and go straight to the fence in that case.  Single-threaded use of `stream` is
+    // assumed between the query and the lane's launch (include/ss_hip.h, ss_ctx_set_overlap).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!always_fence && hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusActive;                    // cannot tell: do not query, fence
+    }
+    hipError_t e = (always_fence || cap != hipStreamCaptureStatusNone) ? hipErrorNotReady
+                                                                       : hipStreamQuery(static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
-        // work pending - or a stream that cannot be asked (one being captured into a graph): order the lane behind it, and
-        // let the fence's own calls report whatever is really wrong with the stream
-        if (!always_fence) (void)hipGetLastError();            // (do not leave the query's answer for the launch's own check)
+        // work pending (hipErrorNotReady: the only answer that is cleared here - a genuine sticky error stays for the fence's
+        // own calls and the launch check to report): order the lane behind the caller's stream
+        if (!always_fence && cap == hipStreamCaptureStatusNone && e == hipErrorNotReady) (void)hipGetLastError();
         e = hipEventRecord(c.ev_in, static_cast<hipStream_t>(stream));
         if (e == hipSuccess) e = hipStreamWaitEvent(c.lane_stream[lane], c.ev_in, 0);
     }

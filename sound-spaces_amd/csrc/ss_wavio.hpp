@@ -11,6 +11,7 @@
 // (integer PCM, RIFX, malformed chunks -> ValueError -> zero RIR) exactly.
 #pragma once
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -40,7 +41,24 @@ enum Status : int {
 // and returns when all are done.  One job at a time (callers are serialised by a mutex).
 class Pool {
 public:
-    static Pool& get() { static Pool p; return p; }
+    // One pool per PROCESS: a child of fork() inherits `workers_` without the threads behind it - run() would wait
+    // for helpers that do not exist, ~Pool would join them.  The pool remembers the pid that built it; a process with another
+    // pid gets a fresh one (the inherited object is abandoned, never destroyed: its mutexes may have been held at the fork).
+    // Pools are not destroyed at exit either: the parked workers end with the process.
+    static Pool& get() {
+        static std::atomic<Pool*> inst{nullptr};
+        static std::atomic_flag making = ATOMIC_FLAG_INIT;
+        static std::once_flag fork_once;
+        std::call_once(fork_once, [] { ::pthread_atfork(nullptr, nullptr, [] { making.clear(); }); });
+        const pid_t me = ::getpid();
+        Pool* p = inst.load(std::memory_order_acquire);
+        if (p && p->pid_ == me) return *p;
+        while (making.test_and_set(std::memory_order_acquire)) std::this_thread::yield();
+        p = inst.load(std::memory_order_acquire);
+        if (!p || p->pid_ != me) { p = new Pool(); p->pid_ = me; inst.store(p, std::memory_order_release); }
+        making.clear(std::memory_order_release);
+        return *p;
+    }
     void run(int n, int threads, const std::function<void(int)>& fn) {
         if (n <= 0) return;
         int helpers = (threads < 1 ? 1 : threads) - 1;
@@ -95,6 +113,7 @@ private:
     int n_ = 0, pending_ = 0, wanted_ = 0;
     unsigned long long epoch_ = 0;
     bool stop_ = false;
+    pid_t pid_ = 0;
 };
 
 inline bool read_exact(int fd, void* buf, size_t n) {
@@ -153,7 +172,14 @@ inline int read_one(const char* path, float* dst, int cap, int keep, bool planar
             *frames_out = frames;
             if (frames == 0) return kEmpty;
             const int n = keep >= 0 && keep < frames ? keep : frames;
-            if (n > cap) return kTooLong;
+            if (n > cap) {
+                //  only a file that HOLDS the frames its header claims may make the caller grow every row of its
+                // bank: a truncated / corrupt one goes to the Python reader first (scipy reads it leniently or it becomes the
+                // zero RIR, simulator.py:617-621)
+                struct stat st;
+                if (::fstat(fd, &st) != 0 || static_cast<uint64_t>(st.st_size) < pos + static_cast<uint64_t>(n) * 8) return kUnsupported;
+                return kTooLong;
+            }
             const size_t want = static_cast<size_t>(n) * 8;                          // bytes of samples to store
             const size_t in_head = have - pos < want ? have - pos : want;            // ... of which the first read holds
             float* tgt = dst;

@@ -612,12 +612,20 @@ class DeferredResolver:
         el, pl = env[li], par[li]
         unalloc = (self._lv_slots[el, 0] < 0) | (self._lv_slots[el, 1] < 0)
         if unalloc.any():
+            #  this step's rows that already exist are marked in use BEFORE rows are allocated for the new envs: with a
+            # full store the allocation may evict, and a victim among this step's own rows would reach the scatter as slot -1
+            have = self._lv_slots[el[~unalloc]].ravel()
+            if have.size:
+                store.touch_slots(have)
             for e in np.unique(el[unalloc]):                     # an env's first step: its two rows
                 for k in (0, 1):
                     if self._lv_slots[e, k] < 0:
                         self._lv_slots[e, k] = store.slot(("live", int(e), k), lambda: None, refresh=True)
                         self._lv_seqs[e, k] = 0
         cur = self._lv_slots[el, pl]
+        if (cur < 0).any() or (self._lv_slots[el, pl ^ 1] < 0).any():
+            raise KeyError("deferred audio: the RIR store is too small for this step's live rows (two per env); "
+                           "an allocation evicted a row the step itself needs")
         new_cur = np.flatnonzero(self._lv_seqs[el, pl] != seq[li])
         up_slots = cur[new_cur].tolist()
         up_rows = [rir[j] for j in li[new_cur].tolist()]

@@ -935,6 +935,12 @@ class RirStore:
     def _file_stage(self, k: int):
         """pinned [_FILE_CHUNK, cap, 2] staging block k & 1 (wav layout), free to be overwritten"""
         if getattr(self, "_fstage", None) is None or self._fstage[0].shape[1] != self.cap:
+            # (ADVICE r5) the scatter of an earlier chunk may still be READING the old pinned blocks (scatter_from_host: the
+            # kernel pulls them over the host link itself, and torch's caching host allocator knows nothing of that read): wait
+            # for every outstanding scatter before the blocks are dropped, or the next torch.zeros() hands them out zero-filled
+            for ev in getattr(self, "_fstage_ev", None) or ():
+                if ev is not None:
+                    ev.synchronize()
             pin = self.device.type == "cuda"
             self._fstage = [torch.zeros((self._FILE_CHUNK, self.cap, 2), dtype=torch.float32, pin_memory=pin) for _ in range(2)]
             # the rows' bank slots and lengths travel the same way (a list -> device tensor conversion is a SYNCHRONOUS pageable

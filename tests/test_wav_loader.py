@@ -261,3 +261,40 @@ def test_upload_rows_takes_read_only_rows_and_routes_odd_layouts_row_by_row():
         b.flush_uploads()
         assert np.array_equal(a.bank.data.numpy(), b.bank.data.numpy())
         assert np.array_equal(a.bank.lengths.numpy(), b.bank.lengths.numpy()) and np.array_equal(a.host_len, b.host_len)
+
+
+def test_a_file_that_claims_more_frames_than_it_holds_never_grows_the_bank(wavs, tmp_path):
+    """ whole-RIR mode: a corrupt header (3000 frames on disk, 200000 claimed) must reach the Python reader as
+    'unsupported' - not make every slot of the store 200000 frames long before anyone has looked at the file."""
+    raw = bytearray(open(wavs["a"], "rb").read())
+    i = raw.index(b"data")
+    raw[i + 4:i + 8] = (200000 * 8).to_bytes(4, "little")
+    p = str(tmp_path / "liar.wav")
+    open(p, "wb").write(bytes(raw[:i + 8 + 3000 * 8]))
+    dst = np.zeros((1, 1000, 2), np.float32)
+    kept, frames, status = _lib.wav_read_rirs([p], dst, 1000, keep=-1)
+    assert status[0] == _lib.WAV_UNSUPPORTED and kept[0] == 0 and not dst.any()
+    st = RirStore(8, 4000, "cpu", truncate_to=None, max_cap=1 << 20)
+    st.load_files([("liar",)], [p])                     # the scipy fallback decides (a lenient read or the zero RIR) ...
+    assert st.cap < 200000                              # ... and the rows never grow to the claimed length
+
+
+def test_the_reader_pool_survives_fork(wavs):
+    """ the persistent thread pool belongs to the process that built it: a fork()ed child (multiprocessing 'fork',
+    as bench.py's CPU baseline uses) gets its own instead of waiting for threads that do not exist there."""
+    import multiprocessing as mp
+    paths = [wavs["a"], wavs["ragged"], wavs["tiny"], wavs["a"]]
+    dst = np.zeros((len(paths), 16384, 2), np.float32)
+    _lib.wav_read_rirs(paths, dst, 16384, keep=16000, threads=4)          # the parent's pool has workers now
+    q = mp.get_context("fork").Queue()
+
+    def child():
+        d = np.zeros((len(paths), 16384, 2), np.float32)
+        kept, _, status = _lib.wav_read_rirs(paths, d, 16384, keep=16000, threads=4)
+        q.put((kept.tolist(), status.tolist(), float(np.abs(d - dst).max())))
+    pr = mp.get_context("fork").Process(target=child)
+    pr.start()
+    pr.join(30)
+    assert not pr.is_alive(), "the forked child hung in the reader pool"
+    kept, status, diff = q.get(timeout=5)
+    assert status == [_lib.WAV_OK] * 4 and diff == 0.0 and kept[0] == 16000
