@@ -590,6 +590,12 @@ def main():
     from ss_amd import ops as ops_mod
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
+    import ctypes
+    bench_so = os.path.join(ROOT, "sound-spaces_amd", "csrc", "libss_bench.so")
+    assert os.path.exists(bench_so), "libss_bench.so missing: run `python sound-spaces_amd/build.py` (or __graft_entry__.build())"
+    bench_lib = ctypes.CDLL(bench_so)
+    bench_lib.ssb_policy_token.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    bench_lib.ssb_policy_token.restype = ctypes.c_int
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -679,7 +685,8 @@ def main():
 
     spin_steps = args.spinup_steps if args.spinup_steps >= 0 else max(64, 1500 * 128 // max(N, 128) * 16000 // sr)
 
-    def run_loop(S, gather_every, spectral, per_step_events=False, lanes=0, regions=1, sustain_s=0.0):
+    def run_loop(S, gather_every, spectral, per_step_events=False, lanes=0, regions=1, sustain_s=0.0, dependent=0,
+                 host_sync=False, exchange=None):
         """warm-up + EXACTLY args.steps timed steps bracketed by barrier + synchronize -> (elapsed s, GPU ms per step from
         HIP events on the launch stream: the region average, or the per-step list with per_step_events; note).
         lanes = 0: pre-planned descriptors through the stateless entry points on S torch streams (kernel-rate passes; with
@@ -688,8 +695,21 @@ def main():
         the timed region); lanes >= 2: its overlap mode (consecutive steps on that many internal streams, joined when a slab is
         gathered and at the end of the region).
         Per-step event records put a marker packet between consecutive launches (measured: +2-3 us per step), so the
-        headline loop records only the two ends and the distribution comes from a separate pass."""
+        headline loop records only the two ends and the distribution comes from a separate pass.
+        dependent = G >= 1: the TRAINER-SHAPED loop.  In the reference step k+1's observation cannot be asked
+        for before the policy has consumed step k's (ss_baselines/av_nav/ppo/ppo_trainer.py:133-150: actor_critic.act on
+        rollouts.observations[step], envs.step, batch_obs, rollouts.insert).  Here: the env set is G groups of N / G envs; per
+        step and group ss_ctx_observe renders into the group's rows of rollouts.observations['spectrogram'][step + 1]
+        (a [T+1, N, 65, T4, 2] tensor, T = 16 slots cycled), ss_ctx_join makes the group's caller stream see the rows, and a
+        ONE-workgroup kernel on that stream reads them and writes a token (libss_bench.so: the stand-in for the policy).  The
+        group's next step is issued on the same caller stream, i.e. ordered behind the token (the library fences a lane behind a
+        caller stream that has work pending).  G = 1: one chain, nothing overlaps (one internal stream).  G = 2: the double-buffered
+        sampler - group B renders while group A's policy runs (two caller streams, two lanes).  host_sync: the host also WAITS
+        for every token before it issues the next step of that group (a trainer that reads its actions back: actions.item())."""
         r.rirs.spectra = spectra if spectral else None
+        if dependent:
+            lanes = 1 if dependent == 1 else 2
+        ex_mode = args.exchange if exchange is None else exchange
         use_ctx = lanes >= 1
         if use_ctx:
             ctx.set_rir_bank(bank, lengths_dev)                    # (drops the spectral form)
@@ -697,10 +717,10 @@ def main():
                 ctx.set_rir_spectra(spectra)
             ctx.set_overlap(lanes)
         cx = None
-        if world > 1 and gather_every > 0:
-            kw = {"learners": [0]} if args.exchange == "gather" else {}
+        if world > 1 and gather_every > 0 and ex_mode != "none":
+            kw = {"learners": [0]} if ex_mode == "gather" else {}
             cx = ChunkedSlabExchange(N, r.spectrogram_shape, gather_every, device=dev,
-                                     exchange_cls=PeerCopyExchange if args.exchange in ("peercopy", "gather") else None, **kw)
+                                     exchange_cls=PeerCopyExchange if ex_mode in ("peercopy", "gather") else None, **kw)
         ex = cx.exchange if cx is not None else None
         streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [torch.cuda.current_stream(dev)]
         n_out = 16 if lanes == 3 else max(2, S, lanes)             # (3 lanes: lane = ring slot % 3, the ring has 16 slots)
@@ -722,18 +742,71 @@ def main():
             else:
                 r.render(plans[k], spectrogram_out=rows, audiogoal_out=ag)
 
+        unit_floats = int(np.prod(r.spectrogram_shape))
+        tok_dev = torch.zeros((4,), dtype=torch.float32, device=dev)
+        tok_host = torch.zeros((4,), dtype=torch.float32).pin_memory() if host_sync else None
+
+        def policy_token(rows_ptr, n_units, g, stream):
+            """the stand-in for actor_critic.act on this group's rows, on the group's caller stream"""
+            tp = (tok_host.data_ptr() if host_sync else tok_dev.data_ptr()) + 4 * g
+            rc = bench_lib.ssb_policy_token(rows_ptr, n_units * unit_floats, tp, stream)
+            assert rc == 0, f"ssb_policy_token: hip error {rc}"
+
         def step(k, plans=descs, columns=preps):
             st = streams[k % S]
             with torch.cuda.stream(st):
                 if cx is not None and not state["no_exchange"]:
-                    render(k, plans, columns, cx.step_rows(streams), ag_bufs[k % len(ag_bufs)])
+                    rows = cx.step_rows(streams)
+                    render(k, plans, columns, rows, ag_bufs[k % len(ag_bufs)])
+                    if dependent:                                  # (one chain per rank: each rank's policy consumes its own slab,
+                        policy_token(rows.data_ptr(), N, 0, st.cuda_stream)   #  ddppo_trainer.py:140-142; the gather serves the learner)
+                        if host_sync:
+                            st.synchronize()
                     if use_ctx and cx.will_gather():
                         ctx.join()                                 # the slab is complete once every lane has drained
                     cx.step_done(streams)                          # all-gather of the chunk once it is full
                 else:
                     render(k, plans, columns, sg_buf[k % len(sg_buf)], ag_bufs[k % len(ag_bufs)])
 
-        if use_ctx and cx is None:                                 # the lean loop: one bound call per step, nothing else
+        if dependent and cx is None:
+            # rollouts.observations['spectrogram']: [T + 1, N, 65, T4, 2]; step k writes slot 1 + k % T (rollout_storage.py:78-102)
+            G, T_roll = dependent, 16
+            roll = torch.empty((T_roll + 1, N) + r.spectrogram_shape, dtype=torch.float32, device=dev)
+            roll_ag = torch.empty((2, N, 2, sr), dtype=torch.float32, device=dev) if want_ag else None
+            cs = [main_stream] if G == 1 else [torch.cuda.Stream(device=dev) for _ in range(G)]
+            cs_raw = [c_ if isinstance(c_, int) else c_.cuda_stream for c_ in cs]
+            bounds = [(g * N // G, (g + 1) * N // G) for g in range(G)]
+            row_b, ag_b = unit_floats * 4, 2 * sr * 4
+
+            def split(cl):
+                return [[ctx.prepare(**{kk: vv[lo:hi] for kk, vv in c.items()}) for lo, hi in bounds] for c in cl]
+            dep_preps = preps if G == 1 else split(cols)
+            dep_spin = spin_preps if G == 1 else split(spin_cols)
+            assert G == 1 or feat_sets is None, "dependent groups > 1: without the extension features"
+
+            def step(k, plans=descs, columns=preps):               # noqa: F811
+                cg = dep_spin if columns is spin_preps else dep_preps
+                slot = roll.data_ptr() + (1 + k % T_roll) * N * row_b
+                agp0 = None if roll_ag is None else roll_ag.data_ptr() + (k & 1) * N * ag_b
+                for g in range(G):
+                    lo, hi = bounds[g]
+                    sgp = slot + lo * row_b
+                    agp = None if agp0 is None else agp0 + lo * ag_b
+                    if G == 1:
+                        if feat_sets is not None:
+                            ctx.observe_prepared_features(cg[k], sgp, agp, cs_raw[0], feat_sets[k % 4])
+                        else:
+                            ctx.observe_prepared(cg[k], sgp, agp, cs_raw[0])
+                    else:
+                        ctx.observe_prepared(cg[k][g], sgp, agp, cs_raw[g])
+                        ctx.join(cs_raw[g])                        # the group's rows become visible to its caller stream
+                    policy_token(sgp, hi - lo, g, cs_raw[g])
+                    if host_sync:                                  # the trainer reads the group's actions back before envs.step
+                        if G == 1:
+                            torch.cuda.current_stream(dev).synchronize()
+                        else:
+                            cs[g].synchronize()
+        elif use_ctx and cx is None:                               # the lean loop: one bound call per step, nothing else
             sg_ptrs = [b_.data_ptr() for b_ in sg_buf]
             ag_ptrs = [None if b_ is None else b_.data_ptr() for b_ in ag_bufs]
             n_sg, n_ag = len(sg_ptrs), len(ag_ptrs)
@@ -896,12 +969,37 @@ def main():
 
     def rate(e):
         return {"value": round(world * N * args.steps / e, 1), "ms_per_step": round(1e3 * e / args.steps, 5)}
-    # ---- headline: the product path (one call site, ss_ctx_observe, overlap mode), exchange on when there are ranks ------
-    elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, lanes=LANES, regions=REGIONS, sustain_s=args.sustain)
+    # ---- headline (round 6): the product path in the TRAINER-SHAPED loop - one env group, step k+1 ordered behind the consumer
+    # of step k's observation (run_loop: dependent), writing into rollouts.observations['spectrogram'][step + 1]; exchange on
+    # when there are ranks.  The pipelined figure (independent steps on LANES internal streams: what r1-r5 reported as `value`)
+    # is measured right after it and reported as `pipelined`.
+    elapsed, head_ev, exchange_note = run_loop(1, G_head, args.spectral, regions=REGIONS, sustain_s=args.sustain, dependent=1)
     head_regions = list(last_regions)
     head_sustained = dict(last_sustained)
     head_host_us = last_host[0]
     side = {}
+    e_p, _, _ = run_loop(1, G_head, args.spectral, lanes=LANES, regions=REGIONS)
+    pipe_regions = list(last_regions)
+    side["pipelined"] = dict(rate(e_p), lanes=LANES, independent_groups_presumed=LANES, host_us_per_call=last_host[0],
+                             note=f"consecutive steps issued with NO dependency between them on {LANES} internal streams of the "
+                                  f"library (ss_ctx_set_overlap): realisable only by a caller that has {LANES} independent env "
+                                  "groups of this size in flight; r1-r5 reported this figure as `value`",
+                             **({} if len(pipe_regions) < 2 else
+                                {"spread": {k_: round(world * N * args.steps / float(np.quantile(pipe_regions, q_)), 1)
+                                            for k_, q_ in (("min", 1.0), ("p10", 0.9), ("p90", 0.1), ("max", 0.0))}}))
+    dep = {"groups": 1, "envs_per_group": n_env, "consumer": "one-workgroup kernel per step and group on the caller's stream "
+           "(libss_bench.so: stands in for actor_critic.act, ppo_trainer.py:133-150); the next step is ordered behind it",
+           "writes_into": "rollouts.observations['spectrogram'][step + 1] ([17, N, 65, T4, 2], 16 slots cycled)"}
+    if world == 1 and not args.no_secondary:
+        if N % 2 == 0 and not feats:
+            e2, _, _ = run_loop(1, 0, args.spectral, regions=REGIONS, dependent=2)
+            dep["two_groups"] = dict(rate(e2), envs_per_group=n_env // 2 if rot == 1 else f"{N // 2} units",
+                                     note="double-buffered sampler: two groups of half the envs, each a dependent chain on its own "
+                                          "caller stream; group B renders while group A's policy runs")
+        eh, _, _ = run_loop(1, 0, args.spectral, regions=REGIONS, dependent=1, host_sync=True)
+        dep["host_sync"] = dict(rate(eh), note="as `value`, and the host also waits for every step's token before it issues the "
+                                               "next step (a trainer that reads its actions back: actions.item())")
+    side["dependent"] = dep
     step_dist = None
     # ---- the kernel's own rate: pre-planned descriptors, ONE stream - per-launch durations are separable only without
     # overlap, and this is the average the rocprofv3 kernel trace of the same command reports for the kernel
@@ -916,11 +1014,21 @@ def main():
         step_dist["note"] = "separate single-stream pass with one HIP event record per step (the records themselves add 2-3 us per step)"
         e1, _, _ = run_loop(1, 0, args.spectral, lanes=1)
         side["ctx_single_stream"] = dict(rate(e1), note="ss_ctx_observe without overlap (a caller that joins every step)")
-    if exchanging and not args.no_secondary:
-        e1, _, _ = run_loop(1, 1, args.spectral, lanes=LANES)      # per-step gather, same run
-        side["exchange_per_step_gather"] = rate(e1)
-        e0, _, _ = run_loop(1, 0, args.spectral, lanes=LANES)      # no collective (the reference's DD-PPO arrangement)
-        side["exchange_none"] = rate(e0)
+    if world > 1 and not args.no_secondary:
+        #  every exchange arrangement from ONE run of `bench.py --gpus N`, same dependent-step protocol:
+        #   exchange_none  no collective (the reference's DD-PPO arrangement: every rank's learner consumes its own slab)
+        #   allgather      RCCL all_gather_into_tensor of the step slabs, a chunk of --gather-every steps at a time
+        #   gather         peer copies to ONE learner rank (PeerCopyExchange(learners=[0]): xGMI writes, no collective)
+        for key, mode, ge in (("exchange_none", "none", 0), ("allgather", "allgather", args.gather_every),
+                              ("gather", "gather", args.gather_every), ("exchange_per_step_gather", args.exchange, 1)):
+            if mode == args.exchange and ge == G_head:
+                side[key] = dict(rate(elapsed), note="= the headline of this run")
+                continue
+            try:
+                e_x, _, note_x = run_loop(1, ge, args.spectral, dependent=1, exchange=mode)
+                side[key] = dict(rate(e_x), **({"note": note_x} if note_x else {}))
+            except Exception as ex_:                               # one arrangement failing must not take the line down
+                side[key] = {"value": None, "note": f"{type(ex_).__name__}: {ex_}"}
     if world == 1 and not args.no_secondary:
         eo, _, _ = run_loop(1, 0, not args.spectral, lanes=LANES)  # the other RIR bank format, same protocol as the headline
         _, ps_o, _ = run_loop(1, 0, not args.spectral)
@@ -932,19 +1040,27 @@ def main():
 
     # ---- secondary measurement: the convolution kernel alone (audiogoal written), same inputs -------------
     conv_ms = None
+    conv_ms_other = None
     if rank == 0 and not args.no_secondary:
         ag = torch.empty((N, 2, sr), dtype=torch.float32, device=dev)
-        for k in range(min(10, total)):
-            r.render_audiogoal(descs[k], out=ag)
-        torch.cuda.synchronize()
-        reps = min(100, args.steps)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for k in range(reps):
-            r.render_audiogoal(descs[args.warmup + k], out=ag)
-        e1.record()
-        torch.cuda.synchronize()
-        conv_ms = [e0.elapsed_time(e1) / reps]
+
+        def conv_alone():
+            for k in range(min(10, total)):
+                r.render_audiogoal(descs[k], out=ag)
+            torch.cuda.synchronize()
+            reps = min(100, args.steps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(reps):
+                r.render_audiogoal(descs[args.warmup + k], out=ag)
+            e1.record()
+            torch.cuda.synchronize()
+            return [e0.elapsed_time(e1) / reps]
+        conv_ms = conv_alone()
+        if spectra is not None:                                # the other bank form, same steps
+            r.rirs.spectra = None if args.spectral else spectra
+            conv_ms_other = conv_alone()
+            r.rirs.spectra = spectra if args.spectral else None
 
     if rank == 0:
         kernel_ms = float(np.mean(per_step)) if per_step else 1e3 * elapsed / args.steps
@@ -998,18 +1114,22 @@ def main():
                                                  + 65 * t4 * 2 * 4 + (0 if fused else 2 * 2 * sr * 4)
                                                  + (2 * sr * 4 if (fused and want_ag) else 0)),
                        "exchange": (exchange_note or ((args.exchange + f" every {args.gather_every} steps") if exchanging else "none")),
-                       "path": "AudioContext.observe_prepared -> ss_ctx_observe (planner + window cache + descriptor ring inside "
-                               "the timed region; the steps' unit columns were converted to the C struct ss_units OUTSIDE it, "
-                               "AudioContext.prepare: a vector env that owns its columns), "
-                               f"{LANES} internal stream(s)" + (", consecutive steps overlap" if LANES > 1 else ""),
-                       "streams": LANES, "kernel": kname, "features": feats or None},
+                       "path": "DEPENDENT steps (one env group): AudioContext.observe_prepared -> ss_ctx_observe (planner + window "
+                               "cache + descriptor ring inside the timed region; the steps' unit columns were converted to the C "
+                               "struct ss_units OUTSIDE it, AudioContext.prepare: a vector env that owns its columns) into "
+                               "rollouts.observations['spectrogram'][step + 1], then a one-workgroup consumer of those rows on the "
+                               "caller's stream (the policy's stand-in); step k+1 is ordered behind it.  One stream, nothing "
+                               f"overlaps.  `pipelined` = the r1-r5 protocol ({LANES} internal streams, independent steps)",
+                       "streams": 1, "pipelined_streams": LANES, "kernel": kname, "features": feats or None},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
                          "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5),
                          "pass": "single-stream pass of the same run over the same steps (preplanned_single_stream): per-launch "
                                  "durations are only separable without overlap; HIP events around its timed region",
-                         "pipeline_achieved": round(bpu * N / (elapsed / args.steps) / 1e9, 1),
-                         "pipeline_frac": round(bpu * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "dependent_achieved": round(bpu * N / (elapsed / args.steps) / 1e9, 1),
+                         "dependent_frac": round(bpu * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "pipeline_achieved": round(bpu * N / (e_p / args.steps) / 1e9, 1),
+                         "pipeline_frac": round(bpu * N / (e_p / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
         }
         trs = [measured_traffic(N, sr, k_) for k_ in traffic_kernels]
         if all(t_ is not None for t_ in trs):
@@ -1033,6 +1153,19 @@ def main():
                                          "frac": round(a2 / HBM_PEAK_GBS, 4),
                                          "kernel": "k_conv_spec<FUSE=false>" if args.spectral else "k_conv<FUSE=false>",
                                          "bytes_per_unit": b["conv"], "avg_launch_ms": round(cm, 5)}
+            if conv_ms_other is not None:
+                # the same convolution from the OTHER bank form.  Spectral rows are 2 x the bytes (block spectra: 2 x 128 KiB per
+                # RIR block and unit) for no forward FFT: `achieved` stays on SURVEY 8(d)'s algorithmic bytes, `actual_*` are the
+                # bytes that kernel really reads + writes (profiles/r6/conv_roofline.txt has the counter view of both)
+                co = float(np.mean(conv_ms_other))
+                other_spectral = not args.spectral
+                act = ((2 * P.ceil_div(L, P.KB) * P.SPEC_FLOATS * 4) if other_spectral else 2 * L * 4) + 2 * sr * 4
+                a3, a4 = b["conv"] * N / (co * 1e-3) / 1e9, act * N / (co * 1e-3) / 1e9
+                out["roofline_conv_only_spectral" if other_spectral else "roofline_conv_only_time_domain"] = {
+                    "bound": "hbm", "achieved": round(a3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a3 / HBM_PEAK_GBS, 4),
+                    "kernel": "k_conv_spec<FUSE=false>" if other_spectral else "k_conv<FUSE=false>", "bytes_per_unit": b["conv"],
+                    "avg_launch_ms": round(co, 5), "actual_bytes_per_unit": act, "actual_achieved": round(a4, 1),
+                    "actual_frac": round(a4 / HBM_PEAK_GBS, 4)}
         out.update(side)
         if fused and sr > P.KB:
             flops = (23.1e6 + 6.4e6) * N                      # SURVEY 8(d) @44.1 kHz: conv 23.1 MFLOP + STFT 6.4 MFLOP per unit

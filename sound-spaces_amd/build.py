@@ -45,6 +45,7 @@ def up_to_date():
 
 
 def build(force=False, verbose=True):
+    build_bench_token(force, verbose)
     if not force and up_to_date():
         if not os.path.exists(KERNEL_STAMP):
             with open(KERNEL_STAMP, "w") as f:
@@ -72,6 +73,28 @@ def build(force=False, verbose=True):
     with open(KERNEL_STAMP, "w") as f:
         f.write(kernel_hash() + "\n")
     return SO
+
+
+BENCH_SO = os.path.join(CSRC, "libss_bench.so")
+BENCH_STAMP = os.path.join(CSRC, ".libss_bench.srchash")
+
+
+def build_bench_token(force=False, verbose=True):
+    """libss_bench.so: bench.py's stand-in for the policy step between two observations (csrc/ss_bench_token.hip: one
+    workgroup reading the slot a step has written).  A library of its own: bench-only code stays out of libss_hip.so."""
+    import hashlib
+    h = hashlib.sha256(open(os.path.join(CSRC, "ss_bench_token.hip"), "rb").read()).hexdigest()
+    if not force and os.path.exists(BENCH_SO) and os.path.exists(BENCH_STAMP) and open(BENCH_STAMP).read().strip() == h:
+        return BENCH_SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "ss_bench_token.hip", "-o", BENCH_SO + ".tmp"]
+    if verbose:
+        print("[ss_amd] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(BENCH_SO + ".tmp", BENCH_SO)
+    with open(BENCH_STAMP, "w") as f:
+        f.write(h + "\n")
+    return BENCH_SO
 
 
 def build_torch_ops(verbose=True):
