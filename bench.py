@@ -704,11 +704,13 @@ def main():
         ONE-workgroup kernel on that stream reads them and writes a token (libss_bench.so: the stand-in for the policy).  The
         group's next step is issued on the same caller stream, i.e. ordered behind the token (the library fences a lane behind a
         caller stream that has work pending).  G = 1: one chain, nothing overlaps (one internal stream).  G = 2: the double-buffered
-        sampler - group B renders while group A's policy runs (two caller streams, two lanes).  host_sync: the host also WAITS
+        sampler - group B renders while group A's policy runs: a context and a caller stream PER GROUP (each chain is plain
+        in-order work on its own stream: no cross-stream events at all; ss_ctx_set_chip_share(2) makes each group's launch take
+        half the chip so the two run side by side).  host_sync: the host also WAITS
         for every token before it issues the next step of that group (a trainer that reads its actions back: actions.item())."""
         r.rirs.spectra = spectra if spectral else None
         if dependent:
-            lanes = 1 if dependent == 1 else 2
+            lanes = 1                                              # (two groups: two single-stream contexts, see below)
         ex_mode = args.exchange if exchange is None else exchange
         use_ctx = lanes >= 1
         if use_ctx:
@@ -778,8 +780,21 @@ def main():
             bounds = [(g * N // G, (g + 1) * N // G) for g in range(G)]
             row_b, ag_b = unit_floats * 4, 2 * sr * 4
 
+            ctxs = [ctx]
+            if G > 1:
+                for _ in range(G - 1):                             # one context per group: same sounds, same bank
+                    c2 = AudioContext(sr, max_window_sets=max(256, 4 * args.sounds))
+                    for i in range(len(r.sources)):
+                        c2.add_source(f"sound{i}", r.sources._host[i])
+                    c2.set_rir_bank(bank, lengths_dev)
+                    if spectral:
+                        c2.set_rir_spectra(spectra)
+                    ctxs.append(c2)
+                for c_ in ctxs:
+                    c_.set_chip_share(G)
+
             def split(cl):
-                return [[ctx.prepare(**{kk: vv[lo:hi] for kk, vv in c.items()}) for lo, hi in bounds] for c in cl]
+                return [[ctxs[g].prepare(**{kk: vv[lo:hi] for kk, vv in c.items()}) for g, (lo, hi) in enumerate(bounds)] for c in cl]
             dep_preps = preps if G == 1 else split(cols)
             dep_spin = spin_preps if G == 1 else split(spin_cols)
             assert G == 1 or feat_sets is None, "dependent groups > 1: without the extension features"
@@ -798,8 +813,7 @@ def main():
                         else:
                             ctx.observe_prepared(cg[k], sgp, agp, cs_raw[0])
                     else:
-                        ctx.observe_prepared(cg[k][g], sgp, agp, cs_raw[g])
-                        ctx.join(cs_raw[g])                        # the group's rows become visible to its caller stream
+                        ctxs[g].observe_prepared(cg[k][g], sgp, agp, cs_raw[g])
                     policy_token(sgp, hi - lo, g, cs_raw[g])
                     if host_sync:                                  # the trainer reads the group's actions back before envs.step
                         if G == 1:
@@ -943,6 +957,7 @@ def main():
             per_step = region_ev[0] if per_step_events else [float(np.median([e[0] for e in region_ev]))]
         if use_ctx:
             ctx.set_overlap(1)
+            ctx.set_chip_share(0)
         state["regions"] = region_s
         last_regions[:] = region_s
         last_sustained.clear()

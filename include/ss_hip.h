@@ -293,6 +293,12 @@ int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* au
  * into a graph is never queried (hipStreamIsCapturing first); the step is then always fenced. */
 int ss_ctx_set_overlap(ss_ctx* ctx, int n_streams);
 int ss_ctx_join(ss_ctx* ctx, void* stream);
+/* Small steps are rendered by several workgroups per row while CUs would idle (ConvParams::parts_log2).  A caller that keeps
+ * SEVERAL launch sources busy at once - e.g. two env groups stepped alternately, each with a context of its own on its own
+ * stream (the double-buffered sampler of bench.py's `dependent.two_groups`; ss_baselines/common/sync_vector_env.py has one
+ * group) - says so here: every launch of this context then splits its rows over 1 / n_sources of the chip, so that the
+ * sources' launches run side by side instead of queueing behind each other.  0 (default): the context's own lane count. */
+int ss_ctx_set_chip_share(ss_ctx* ctx, int n_sources);
 /* One step straight from the simulators' state, struct-of-arrays (ss_amd/vector.py::VectorSimState: the int64 columns a
  * vector env keeps per env; HOST memory, n entries each).  Does, for all envs at once, what SoundSpacesSim does per env:
  *   silent = step_count > duration (simulator.py:610) or sound < 0;   t0 = clip is 1 s ? 0 : audio_index * sr (:629-634);

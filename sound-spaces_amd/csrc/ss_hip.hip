@@ -1116,7 +1116,7 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     static const bool no_tab = ab_flag("SS_HIP_NO_UNIT_TAB");
     SS_PROF_MARK(4);                                           // new windows (upload + k_source_windows), descriptor upload
     g_host_desc = no_tab ? nullptr : hd;                       // (see fill_unit_tab; cleared right after the dispatch below)
-    g_launch_share = c.n_lanes;
+    g_launch_share = c.chip_share > 0 ? c.chip_share : c.n_lanes;
     if (!c.buckets.empty()) {
         const int nb = static_cast<int>(c.buckets.size());
         rc = spectrogram ? ss_audio_obs_buckets_f32(c.pool, c.buckets.data(), nb, c.rir_len, dd, audiogoal, spectrogram, n,
@@ -1174,6 +1174,12 @@ int ss_ctx_set_overlap(ss_ctx* h, int n_streams) {
     c.group_open = false;
     c.have_last_stream = false;
     for (int l = 0; l < ssctx::kLanes; ++l) { c.lane_dirty[l] = false; for (int o = 0; o < ssctx::kLanes; ++o) c.win_seen[l][o] = c.win_seq[o]; }
+    return 0;
+}
+
+int ss_ctx_set_chip_share(ss_ctx* h, int n_sources) {
+    if (!h || n_sources < 0 || n_sources > 8) return SS_EINVAL;
+    h->c.chip_share = n_sources;
     return 0;
 }
 

@@ -157,6 +157,11 @@ class AudioContext:
         _lib.check(self.lib.ss_ctx_set_overlap(self._h, int(n_streams)), "ss_ctx_set_overlap")
         self.overlap = int(n_streams)
 
+    def set_chip_share(self, n_sources: int) -> None:
+        """This context is one of ``n_sources`` launch sources kept busy at once (e.g. two env groups stepped alternately, each
+        with its own context and stream): its small steps split their rows over 1 / n_sources of the chip (ss_ctx_set_chip_share)."""
+        _lib.check(self.lib.ss_ctx_set_chip_share(self._h, int(n_sources)), "ss_ctx_set_chip_share")
+
     def join(self, stream: Optional[int] = None) -> None:
         """Make `stream` (default: the current torch stream) wait for every step issued so far (no-op without overlap)."""
         if getattr(self, "overlap", 1) <= 1:

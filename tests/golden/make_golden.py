@@ -300,10 +300,25 @@ def main():
     out["clip1s/intensity"] = np.asarray(inten(s, observations=None, episode=None))
 
     # ---- A3 spectrogram composition (librosa/skimage stubs = oracle restatements)
-    fake_librosa = NS(stft=lambda sig, n_fft, hop_length, win_length: O.stft(sig))
+    #  the day a box has librosa / scikit-image this pins the spectrogram half for real: the REAL libraries
+    # are bound when importable, the oracle's restatements otherwise; which one it was is recorded in the npz meta
+    stand_ins = {}
+    try:
+        import librosa as real_librosa
+        fake_librosa = real_librosa
+        stand_ins["librosa.stft"] = "real librosa " + real_librosa.__version__
+    except ImportError:
+        fake_librosa = NS(stft=lambda sig, n_fft, hop_length, win_length: O.stft(sig))
+        stand_ins["librosa.stft"] = "absent here: oracle.ss_oracle.stft (restated from librosa's documented defaults)"
+    try:
+        from skimage.measure import block_reduce as real_block_reduce
+        block_reduce = real_block_reduce
+        stand_ins["skimage.block_reduce"] = "real scikit-image"
+    except ImportError:
+        block_reduce = lambda a, block_size, func: O.block_reduce_mean(a, block_size)     # noqa: E731
+        stand_ins["skimage.block_reduce"] = "absent here: oracle.ss_oracle.block_reduce_mean"
     spec = load_fn("soundspaces/tasks/nav.py", "SpectrogramSensor", "compute_spectrogram",
-                   {"librosa": fake_librosa,
-                    "block_reduce": lambda a, block_size, func: O.block_reduce_mean(a, block_size)})
+                   {"librosa": fake_librosa, "block_reduce": block_reduce})
     for name in cases:
         out[name + "/spectrogram"] = spec(out[name + "/audiogoal"]).astype(np.float32)
     out["ones16k/spectrogram_shape"] = np.asarray(spec(np.ones((2, 16000))).shape)
@@ -320,7 +335,7 @@ def main():
             meta[name]["audiogoal_stride"] = 5
         else:
             meta[name]["audiogoal_stride"] = 1
-    out["meta"] = np.frombuffer(json.dumps({"cases": cases, "params": meta}).encode(), dtype=np.uint8)
+    out["meta"] = np.frombuffer(json.dumps({"cases": cases, "params": meta, "stand_ins": stand_ins}).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(cases), "cases")
