@@ -503,11 +503,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plugin-path", action="store_true", help="skip the plugin-path (boundary) measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the conv-only / spectral-bank / 2-stream side measurements")
-    ap.add_argument("--rir-bank", choices=["spectral", "time"], default="time",
+    ap.add_argument("--rir-bank", choices=["auto", "spectral", "time"], default="auto",
                     help="format of the HBM-resident RIR bank the headline loop reads: 'time' = the reference's time-domain "
                          "samples (the format SURVEY 8(d) defines the metric and its algorithmic bytes on); 'spectral' = block "
                          "spectra computed once at bank load (ss_rir_spectra_f32), no forward FFT per step, 2x the bytes per "
-                         "RIR.  The other format is timed in the same run and reported beside it")
+                         "RIR.  The other format is timed in the same run and reported beside it.  'auto' (default) = what "
+                         "AudioEngine(rir_spectral=None) does with both forms resident: 16-kHz steps of <= 64 units read the "
+                         "spectral rows (cfg1, cfg3, the reference's 5-10 envs per GPU), everything else the time-domain rows "
+                         "(44.1 kHz: the metric's declared format; the engine itself prefers the spectral rows there)")
     ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg3", "cfg4"], default="headline",
                     help="BASELINE.json configs[] presets: cfg1 = 32 envs @16 kHz; cfg2 = 128 envs x 4 rotations @44.1 kHz "
                          "(512 units / launch); cfg4 = savi: 256 envs, 21 sounds of 1-20 s, distractor, audiogoal + "
@@ -529,7 +532,6 @@ def main():
                          "21 sounds of 1-20 s (all windowing branches of simulator.py:629-647), a distractor on every env "
                          "(two convolutions + add), audiogoal AND spectrogram written; use with --envs 256")
     args = ap.parse_args()
-    args.spectral = args.rir_bank == "spectral"
     if args.config == "cfg1":
         args.envs, args.sr, args.rotations = 32, 16000, 1
     elif args.config == "cfg2":
@@ -545,6 +547,10 @@ def main():
     elif args.config == "cfg4":
         args.envs, args.sr, args.rotations, args.workload = 256, 16000, 1, "savi"
 
+    # (after the presets: 'auto' needs the step's size)
+    units_per_step = (args.envs // args.gpus if args.scaling == "strong" else args.envs) * args.rotations
+    args.spectral = args.rir_bank == "spectral" or (args.rir_bank == "auto" and args.sr <= 16384 and units_per_step <= 64
+                                                    and args.workload != "savi")
     feats = args.features if args.features is not None else ("logmel,gccphat" if args.workload == "savi" else "none")
     feats = [f for f in feats.split(",") if f and f != "none"]
     assert all(f in ("logmel", "gccphat") for f in feats), "--features: logmel, gccphat"

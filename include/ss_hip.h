@@ -293,6 +293,13 @@ int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* au
  * into a graph is never queried (hipStreamIsCapturing first); the step is then always fenced. */
 int ss_ctx_set_overlap(ss_ctx* ctx, int n_streams);
 int ss_ctx_join(ss_ctx* ctx, void* stream);
+/* A context that holds BOTH bank forms (ss_ctx_set_rir_bank + ss_ctx_set_rir_spectra) renders from the spectral one.  For
+ * rows of one block (16 kHz) that pays for SMALL steps only - no forward FFT on a chip that is mostly idle: 12.9-15.6 us
+ * against 17.1-19.0 us per step of 1-32 envs, the reference's 5-10 envs per GPU (ss_baselines/av_nav/config/audionav/
+ * {replica,mp3d}/train_telephone/audiogoal_depth_ddppo.yaml:3) - while at 128 envs the forward FFT hides under the rows' loads
+ * and the spectral rows are twice the bytes.  max_units > 0: steps of more than max_units units of one-block rows take the
+ * time-domain rows; rows of several blocks (44.1 / 48 kHz) are not affected.  0 (default): the spectral form whenever set. */
+int ss_ctx_set_spectral_policy(ss_ctx* ctx, int max_units);
 /* Small steps are rendered by several workgroups per row while CUs would idle (ConvParams::parts_log2).  A caller that keeps
  * SEVERAL launch sources busy at once - e.g. two env groups stepped alternately, each with a context of its own on its own
  * stream (the double-buffered sampler of bench.py's `dependent.two_groups`; ss_baselines/common/sync_vector_env.py has one

@@ -1097,7 +1097,10 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
         e = hipMemcpyAsync(dd, hd, sizeof(int) * 8 * static_cast<size_t>(n), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return fail(hip_err(e));
     }
-    const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE);       // (cross-faded steps take the time-domain rows)
+    // cross-faded steps take the time-domain rows; so do LARGE steps of one-block rows when the caller keeps both forms and said
+    // so (ss_ctx_set_spectral_policy): there the forward FFT hides under the row's load and the spectral rows are twice the bytes
+    const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE) &&
+                          !(c.spectral_max_units > 0 && c.rir && c.out_len <= ssk::kB && n > c.spectral_max_units);
     const int nbh_bank = spectral ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
     if (spectrogram && !audiogoal && c.out_len > ssk::kB && !wide_one_block_ok(c.out_len, c.n_valid, res.flags, spectral) &&
         !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags, spectral, true)) {  // cross-faded / very long rows hand over through memory (the context's own buffer)
@@ -1174,6 +1177,12 @@ int ss_ctx_set_overlap(ss_ctx* h, int n_streams) {
     c.group_open = false;
     c.have_last_stream = false;
     for (int l = 0; l < ssctx::kLanes; ++l) { c.lane_dirty[l] = false; for (int o = 0; o < ssctx::kLanes; ++o) c.win_seen[l][o] = c.win_seq[o]; }
+    return 0;
+}
+
+int ss_ctx_set_spectral_policy(ss_ctx* h, int max_units) {
+    if (!h || max_units < 0) return SS_EINVAL;
+    h->c.spectral_max_units = max_units;
     return 0;
 }
 

@@ -157,6 +157,11 @@ class AudioContext:
         _lib.check(self.lib.ss_ctx_set_overlap(self._h, int(n_streams)), "ss_ctx_set_overlap")
         self.overlap = int(n_streams)
 
+    def set_spectral_policy(self, max_units: int) -> None:
+        """With both bank forms set: steps of more than ``max_units`` units of one-block rows (16 kHz) take the time-domain
+        rows, smaller ones the spectral rows (ss_ctx_set_spectral_policy); 0 = the spectral form whenever it is set."""
+        _lib.check(self.lib.ss_ctx_set_spectral_policy(self._h, int(max_units)), "ss_ctx_set_spectral_policy")
+
     def set_chip_share(self, n_sources: int) -> None:
         """This context is one of ``n_sources`` launch sources kept busy at once (e.g. two env groups stepped alternately, each
         with its own context and stream): its small steps split their rows over 1 / n_sources of the chip (ss_ctx_set_chip_share)."""

@@ -154,7 +154,8 @@ class AudioGoalDataset(_TorchDataset):
         slot per distinct RIR file, LRU beyond ``rir_slots``)."""
         if self._engine is None:
             from .renderer import AudioEngine
-            self._engine = AudioEngine(self.rir_sampling_rate, device=self.device, rir_slots=self._rir_slots)
+            # (mini-batches are hundreds of items: the time-domain rows; no block spectra to keep in step with the loads)
+            self._engine = AudioEngine(self.rir_sampling_rate, device=self.device, rir_slots=self._rir_slots, rir_spectral=False)
         if not self._sound_ids:
             for name in sorted(self.source_sound_dict):                   # (sorted: ids do not depend on os.listdir's order)
                 self._sound_ids[name] = self._engine.source_id("savi-pretraining/" + name, self.source_sound_dict[name])

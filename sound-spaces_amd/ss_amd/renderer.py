@@ -358,6 +358,13 @@ class BatchedAudioRenderer:
                     ops.FLAG_NO_DISTRACTOR | self._bucket_flag(int(rir.max()) if rir.size else -1))
 
     # ---- rendering ---------------------------------------------------------------------------------------
+    # With BOTH bank forms resident, launches of more than this many units of one-block rows (16 kHz) read the time-domain rows
+    # (ss_ctx_set_spectral_policy has the numbers); 0 = the spectral form whenever it exists.  AudioEngine sets it.
+    spectral_max_units = 0
+
+    def _spectral_for(self, n_units: int) -> bool:
+        return self.spectral_max_units <= 0 or self.out_len > P.KB or n_units <= self.spectral_max_units
+
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
         """One launch on the current stream - including SS2.0 steps at 44.1 kHz (one rendered block of a longer row: the
@@ -367,7 +374,7 @@ class BatchedAudioRenderer:
         N = len(plan)
         xfade = bool(plan.flags & ops.FLAG_CROSSFADE)
         spectral = (self.rirs.spectra is not None if not isinstance(self.rirs, BucketedRirBank) else bool(self.rirs.spectra)) \
-            and not xfade
+            and not xfade and self._spectral_for(N)
         need_ag = (want_audiogoal or audiogoal_out is not None or
                    (self.out_len > P.KB and not P.wide_one_block(self.out_len, self.n_valid, spectral)
                     and (xfade or self.n_valid <= P.KB or self.out_len > 3 * P.KB)))
@@ -378,10 +385,9 @@ class BatchedAudioRenderer:
         if sg is None:
             sg = torch.empty((N,) + self.spectrogram_shape, dtype=torch.float32, device=self.device)
         if isinstance(self.rirs, BucketedRirBank):
-            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE)
             ops.audio_obs_buckets_into(self._spec, self.rirs.c_array(spectral), len(self.rirs.banks), self.rirs.lengths,
                                        plan.desc, ag, sg, self.n_valid, self.out_len, self.pad_mode, flags=plan.flags)
-        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        elif spectral:
             ops.audio_obs_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, ag, sg, self.n_valid,
                                     self.out_len, self.pad_mode, flags=plan.flags)
         else:
@@ -394,10 +400,10 @@ class BatchedAudioRenderer:
         if out is None:
             out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
         if isinstance(self.rirs, BucketedRirBank):
-            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE)
+            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE) and self._spectral_for(len(plan))
             ops.audio_obs_buckets_into(self._spec, self.rirs.c_array(spectral), len(self.rirs.banks), self.rirs.lengths,
                                        plan.desc, out, None, self.n_valid, self.out_len, self.pad_mode, flags=plan.flags)
-        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE):
+        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE) and self._spectral_for(len(plan)):
             ops.fftconv_binaural_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, out, self.n_valid,
                                            flags=plan.flags)
         else:
@@ -1118,6 +1124,9 @@ class BucketedRirStore:
     def sync_spectra(self) -> int:
         return sum(st.sync_spectra() for st in self.stores)
 
+    def flush_uploads(self) -> int:
+        return sum(st.flush_uploads() for st in self.stores)
+
     def _bucket_for(self, loaded) -> int:
         items = [loaded] if self.group == 1 else (list(loaded) if loaded is not None else [None])
         n = max([self.stores[0]._kept_len(_planar(r).shape[1]) for r in items] + [0])
@@ -1292,19 +1301,28 @@ class AudioEngine:
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
                  rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: Optional[bool] = None,
                  rir_buckets: Optional[Sequence[Tuple[int, int]]] = None, spectral_hbm_fraction: float = 0.5,
-                 **renderer_kwargs):
+                 spectral_max_units: int = 64, **renderer_kwargs):
         """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec /
         k_obs_rows<SPECTRAL> (no forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change
         every step and stay on the time-domain kernels.  None (default) = decided here: ON for file-backed stores at rates
         whose rows span several partition blocks (44.1 / 48 kHz - the reference's Replica rate,
         configs/audionav/av_nav/replica/audiogoal.yaml:18: every observation is three forward FFTs per ear and a stash round
         trip there; cfg[2]: 271 vs 334 us per 512 units) when rows + spectra fit `spectral_hbm_fraction` of the device's free
-        memory; OFF at 16 kHz, where the forward FFT hides under the row's load (+-2 us per 128 envs) and the bytes double."""
+        memory.  Round 6: at 16 kHz too, under the same condition - but there only SMALL steps read the spectral rows
+        (<= `spectral_max_units` = 64 units per launch, chosen per launch: the reference steps 5-10 envs per GPU,
+        ss_baselines/av_nav/config/audionav/{replica,mp3d}/train_telephone/audiogoal_depth_ddppo.yaml:3, an eager call renders 1 -
+        no forward FFT on a mostly idle chip: 12.9 / 15.6 us against 17.1 / 19.0 us per step of 1 / 32 envs); steps of more
+        units read the time-domain rows, whose forward FFT hides under the rows' loads there (+-2 us per 128 envs at half the
+        bytes).  An explicit rir_spectral=True keeps r5's meaning: the spectral rows for every launch."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
+        self.spectral_max_units = 0
         if rir_spectral is None:
             rir_spectral = self._auto_spectral(sampling_rate, rir_slots if not rir_buckets else sum(b[0] for b in rir_buckets),
                                                rir_cap or sampling_rate, full, spectral_hbm_fraction)
+            if rir_spectral and sampling_rate <= P.KB:
+                self.spectral_max_units = int(spectral_max_units)
+        self.renderer.spectral_max_units = self.spectral_max_units
         self.rir_spectral = bool(rir_spectral) and not full
         if rir_buckets:
             # length-bucketed bank: [(slots, cap samples), ...] ascending, e.g. [(4096, 16000), (256, 49152), (64, 65536)]
@@ -1322,7 +1340,7 @@ class AudioEngine:
 
     def _auto_spectral(self, sr: int, slots: int, cap: int, full: bool, fraction: float) -> bool:
         dev = self.renderer.device
-        if full or sr <= P.KB or dev.type != "cuda":
+        if full or dev.type != "cuda":
             return False
         blocks = P.ceil_div(cap + (cap & 1), P.KB)
         need = slots * 2 * (cap * 4 + blocks * P.SPEC_FLOATS * 4)          # time-domain rows + their block spectra
@@ -1350,6 +1368,8 @@ class AudioEngine:
             if isinstance(self.store, BucketedRirStore):
                 raise NotImplementedError("AudioEngine.context(): length-bucketed stores use ss_ctx_set_rir_buckets directly")
             ctx = AudioContext(r.sr, n_valid=r.n_valid, wrap=r.wrap, pad_mode=r.pad_mode)
+            if self.spectral_max_units:
+                ctx.set_spectral_policy(self.spectral_max_units)
             for sid, (name, _) in enumerate(sorted(r.sources.names.items(), key=lambda kv: kv[1])):
                 assert ctx.add_source(name, r.sources._host[sid]) == sid
             self._ctx = ctx
@@ -1363,9 +1383,16 @@ class AudioEngine:
             self.store.on_grow = on_grow
         return self._ctx
 
-    def _sync_context_bank(self):
+    def _sync_context_bank(self, n_units: int = 0):
+        """n_units: size of the step about to be launched (0 = unknown).  Under the small-step policy (spectral_max_units) the
+        block spectra of freshly loaded rows are only built when a launch is going to read them: large steps (which take the
+        time-domain rows) skip the transform, the rows stay marked and are transformed before the next small step."""
         ctx = self.context()
-        n_sync = self.store.sync_spectra()
+        if n_units <= 0 or self.renderer._spectral_for(n_units):
+            n_sync = self.store.sync_spectra()
+        else:
+            n_sync = 0
+            self.store.flush_uploads()                             # (sync_spectra's first half: queued row uploads go out)
         bank = self.store.bank
         cur = self._ctx_bank                                     # (the tensors the context was last pointed at: identity, not
         if n_sync or cur is None or cur[0] is not bank.data or cur[1] is not bank.spectra:   # two data_ptr() calls per step)
@@ -1378,7 +1405,7 @@ class AudioEngine:
     def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None) -> int:
         """One step from the packed request records of ``ss_amd.deferred`` (``ss_ctx_observe_requests``: lookups + planner +
         launch in one C call).  Returns the number of unresolved requests (0: the step is on the stream)."""
-        ctx = self._sync_context_bank()
+        ctx = self._sync_context_bank(n)
         if getattr(self, "_req_miss", None) is None or self._req_miss["buf"].shape[0] < n:
             import ctypes
             buf, cnt = np.zeros((max(n, 256),), np.int32), ctypes.c_int(0)
@@ -1395,7 +1422,7 @@ class AudioEngine:
     def observe_columns(self, cols: Dict[str, np.ndarray], spectrogram_out=None, audiogoal_out=None) -> None:
         """One step from unit columns {sound, t0, rir[, dis_sound, dis_rir, last_rir, wrap, last_wrap]} (numpy, one entry
         per env; rir < 0 = silent) through the context: ONE ctypes call, outputs written into the given device tensors."""
-        ctx = self._sync_context_bank()
+        ctx = self._sync_context_bank(len(cols["sound"]))
         ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **cols)
 
     def begin_batch(self) -> None:
@@ -1409,7 +1436,10 @@ class AudioEngine:
 
     def observe(self, units: Sequence[UnitRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None) -> Dict[str, torch.Tensor]:
-        self.store.sync_spectra()
+        if self.renderer._spectral_for(len(units)):
+            self.store.sync_spectra()
+        else:
+            self.store.flush_uploads()
         plan = self.renderer.plan(units)
         if not want_spectrogram:
             return {"audiogoal": self.renderer.render_audiogoal(plan, out=audiogoal_out)}

@@ -1629,13 +1629,52 @@ def test_split_rows_small_steps_vs_reference_run_vectors(n_units, group):
             check(sg_only[n], ref_s)
 
 
+@pytest.mark.parametrize("n_units", [1, 2, 16, 32, 64, 65, 128])
+def test_engine_default_small_16k_steps_read_the_spectral_rows(n_units):
+    """AudioEngine(rir_spectral=None) at 16 kHz keeps both bank forms; launches of <= 64 units (the reference
+    steps 5-10 envs per GPU) read the spectral rows (no forward FFT: k_conv_spec, split rows), larger ones the time-domain rows -
+    chosen per launch in the Python planner path (engine.observe), in the C++ context (observe_columns: ss_ctx_set_spectral_policy)
+    and for the eager call.  Every unit is a reference-run case; rows loaded before a LARGE step get their block spectra only when a
+    small step needs them."""
+    from ss_amd.renderer import AudioEngine, UnitRequest
+    names = [c for c in SIM_CASES if case_inputs(c)["rir"].shape[0] <= 16000 and len(case_inputs(c)["source"]) == 16000]
+    assert len(names) >= 3
+    ins = [case_inputs(c) for c in names]
+    eng = AudioEngine(16000, device=DEV, rir_slots=32)
+    assert eng.rir_spectral and eng.store.spectral and eng.renderer._spectral_for(64) and not eng.renderer._spectral_for(65)
+    sids = [eng.source_id(f"s{k}", d["source"]) for k, d in enumerate(ins)]
+    slots = [eng.rir_slot(f"r{k}.wav", (lambda d=d: d["rir"])) for k, d in enumerate(ins)]
+    ks = [n % len(names) for n in range(n_units)]
+    small = n_units <= 64
+    # 1. the Python planner path
+    out = eng.observe([UnitRequest(sids[k], 0, slots[k]) for k in ks], want_audiogoal=True)
+    assert bool(eng.store._stale[slots].any()) == (not small)           # spectra built iff this launch reads them
+    ag, sg = out["audiogoal"].cpu().numpy(), out["spectrogram"].cpu().numpy()
+    # 2. the column path (C++ planner + the library's own per-step choice)
+    sg2 = torch.empty((n_units, 65, 26, 2), device=DEV)
+    eng.observe_columns(dict(sound=np.asarray([sids[k] for k in ks]), t0=np.zeros(n_units, np.int64),
+                             rir=np.asarray([slots[k] for k in ks])), spectrogram_out=sg2)
+    sg2 = sg2.cpu().numpy()
+    for n, k in enumerate(ks):
+        ref_a, ref_s, stride = case_outputs(names[k])
+        check(ag[n][:, ::stride], ref_a)
+        check(sg[n], ref_s)
+        check(sg2[n], ref_s)
+    if n_units == 128:                                                  # a small step afterwards: the rows are transformed now
+        out = eng.observe([UnitRequest(sids[0], 0, slots[0])])
+        assert not eng.store._stale[slots].any()
+        check(out["spectrogram"][0].cpu().numpy(), case_outputs(names[0])[1])
+
+
 def test_engine_keeps_the_spectral_form_by_default_at_the_replica_rate():
     """AudioEngine(rir_spectral=None): file-backed stores at 44.1 kHz (configs/audionav/av_nav/replica/audiogoal.yaml:18) keep
     the rows' block spectra when they fit the HBM budget (no forward FFT, no stash per observation); 16 kHz stores, SS2.0
     engines (live RIRs) and stores that would not fit stay on the time-domain kernels.  Same observation either way."""
     from ss_amd.renderer import AudioEngine, UnitRequest
     assert AudioEngine(44100, device=DEV, rir_slots=16).rir_spectral
-    assert not AudioEngine(16000, device=DEV, rir_slots=16).rir_spectral
+    e16 = AudioEngine(16000, device=DEV, rir_slots=16)          # round 6: kept at 16 kHz too, for SMALL steps only (next test)
+    assert e16.rir_spectral and e16.spectral_max_units == 64 and AudioEngine(44100, device=DEV, rir_slots=16).spectral_max_units == 0
+    assert not AudioEngine(16000, device=DEV, rir_slots=16, rir_spectral=False).rir_spectral
     assert not AudioEngine(44100, device=DEV, rir_slots=16, step_time=0.25, wrap=True).rir_spectral
     assert not AudioEngine(44100, device=DEV, rir_slots=16, spectral_hbm_fraction=1e-9).rir_spectral
     d = case_inputs("clip1s_44k")
