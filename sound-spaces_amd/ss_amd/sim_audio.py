@@ -119,10 +119,11 @@ class HipSimAudio:
     _ids = __import__("itertools").count()
 
     def __init__(self, sim, engine, rir_reader: Callable[[str], Optional[np.ndarray]] = wav_rir_reader,
-                 lazy_audiogoal: bool = False):
+                 lazy_audiogoal: bool = True):
         """engine: ss_amd.renderer.AudioEngine (or any object with source_id / rir_slot / observe).
 
-        lazy_audiogoal (opt-in, for tasks whose only audio sensor is the SpectrogramSensor - av_nav's default): a spectrogram
+        lazy_audiogoal (default since round 6; False = fetch both outputs with every launch, as the reference computes them;
+        it pays for tasks whose only audio sensor is the SpectrogramSensor - av_nav's default): a spectrogram
         request computes and fetches the spectrogram ONLY (the waveform stays on the CU: no 128 KB over PCIe, no host copy);
         the simulator's ``_audiogoal_cache`` is then filled on demand - an AudioGoalSensor read of a pose whose spectrogram
         was rendered re-renders the waveform from the SAME request (same clip window, ``_audio_index`` not advanced again:
@@ -271,7 +272,7 @@ class HipSimAudio:
         return sim._spectrogram_cache[key]
 
 
-def attach(sim, engine, rir_reader=wav_rir_reader, lazy_audiogoal: bool = False) -> HipSimAudio:
+def attach(sim, engine, rir_reader=wav_rir_reader, lazy_audiogoal: bool = True) -> HipSimAudio:
     """Install the HIP audio path on a live SoundSpacesSim: the task sensors (the reference's or ss_amd's) keep
     calling ``sim.get_current_*_observation`` and now reach the GPU renderer.  lazy_audiogoal: see ``HipSimAudio``."""
     backend = HipSimAudio(sim, engine, rir_reader, lazy_audiogoal)

@@ -15,7 +15,10 @@ from ss_amd.renderer import RirStore, UnitRequest
 SR = 16000
 
 
-def make(has_distractor=False, seconds=1):
+def make(has_distractor=False, seconds=1, lazy=False):
+    """lazy=False: both outputs fetched with every launch, as the reference computes them (attach()'s default since round 6 is
+    lazy_audiogoal=True: the waveform on demand - pinned by test_attach_default_fetches_the_waveform_on_demand and the
+    lazy_audiogoal tests below)"""
     rng = np.random.default_rng(3)
     sounds = {"telephone.wav": O.synth_sources(rng, SR, k=1, seconds=seconds)[0],
               "dist.wav": O.synth_sources(rng, SR, k=1)[0]}
@@ -26,8 +29,29 @@ def make(has_distractor=False, seconds=1):
             "rirs/replica/apartment_0/90/5_7.wav": None}                         # unreadable
     sim = FakeSim(SR, sounds, rirs, has_distractor)
     eng = OracleEngine(SR)
-    backend = sim_audio.attach(sim, eng, rir_reader=sim.reader)
+    backend = sim_audio.attach(sim, eng, rir_reader=sim.reader, **({} if lazy is None else {"lazy_audiogoal": lazy}))
     return sim, eng, backend, sounds, rirs
+
+
+def test_attach_default_fetches_the_waveform_on_demand():
+    """attach() without options (round 6): a SpectrogramSensor read renders the spectrogram only; the first AudioGoalSensor read
+    of that pose renders the waveform of the SAME request (one more launch, once), and from then on both travel together -
+    what is observed equals the reference's either way (simulator.py:678-701)."""
+    sim, eng, backend, sounds, rirs = make(lazy=None)
+    assert backend.lazy_audiogoal
+    sg_sensor = sensors.SpectrogramSensor(sim=sim, config=NS())
+    ag_sensor = sensors.AudioGoalSensor(sim=sim, config=NS())
+    s1 = sg_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 1 and not sim._audiogoal_cache
+    a1 = ag_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 2
+    ref = O.compute_audiogoal(sounds["telephone.wav"], rirs["rirs/replica/apartment_0/90/3_7.wav"], SR)
+    assert O.relerr(a1, ref) < 1e-5 and O.relerr(s1, O.compute_spectrogram(ref)) < 1e-5
+    assert ag_sensor.get_observation(observations=None, episode=None) is a1 and eng.calls == 2
+    sim._rotation_angle = 180
+    sg_sensor.get_observation(observations=None, episode=None)
+    ag_sensor.get_observation(observations=None, episode=None)
+    assert eng.calls == 3                                                         # an audiogoal read was seen: one launch for both
 
 
 def test_sensor_contract():
