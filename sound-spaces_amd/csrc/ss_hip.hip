@@ -231,12 +231,48 @@ int get_stash(hipStream_t st, size_t bytes, float** out) {
     return 0;
 }
 
+// k_obs_blocks' hand-off area per (device, stream): [kSyncRows][2] tails of kTailFloats floats + as many flag words, zeroed once;
+// `epoch` counts the launches that used it (a flag holds the epoch of the launch that set it: nothing is reset in between -
+// which is also why such a launch cannot be replayed from a captured graph: the library never captures)
+constexpr int kSyncRows = 512;                                  // (unit, ear) rows a k_obs_blocks launch may have: more than CUs / 2
+struct SyncBuf { float* tails = nullptr; int* flags = nullptr; int epoch = 0; };
+std::map<std::pair<int, hipStream_t>, SyncBuf> g_sync;
+
+int get_block_sync(hipStream_t st, float** tails, int** flags, int* epoch) {
+    if (st == hipStreamPerThread) return SS_EINVAL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_err(e);
+    std::lock_guard<std::mutex> lk(g_mu);
+    SyncBuf& b = g_sync[std::make_pair(dev, st)];
+    if (!b.tails) {
+        const size_t n_hand = static_cast<size_t>(kSyncRows) * 2;
+        const size_t bytes = n_hand * ssk::kTailFloats * sizeof(float) + n_hand * sizeof(int);
+        void* ptr = nullptr;
+        e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) return hip_err(e);
+        e = hipMemsetAsync(ptr, 0, bytes, st);                  // (stream-ordered in front of the first launch that reads it)
+        if (e != hipSuccess) { (void)hipFree(ptr); return hip_err(e); }
+        b.tails = static_cast<float*>(ptr);
+        b.flags = reinterpret_cast<int*>(b.tails + n_hand * ssk::kTailFloats);
+        b.epoch = 0;
+    }
+    b.epoch = b.epoch == 0x7fffffff ? 1 : b.epoch + 1;
+    *tails = b.tails; *flags = b.flags; *epoch = b.epoch;
+    return 0;
+}
+
 // a stream is about to be destroyed (the context's overlap lanes): its stash goes with it (~96 MiB per lane
 // leaked by every create / destroy of a context with overlap); the caller has synchronised the stream
 void drop_stash(hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    auto sy = g_sync.find(std::make_pair(dev, st));
+    if (sy != g_sync.end()) {
+        if (sy->second.tails) (void)hipFree(sy->second.tails);
+        g_sync.erase(sy);
+    }
     auto it = g_stash.find(std::make_pair(dev, st));
     if (it == g_stash.end()) return;
     if (it->second.ptr) (void)hipFree(it->second.ptr);
@@ -255,9 +291,41 @@ inline bool obs_rows_ok(int out_len, int n_valid, int nbh_max, int flags, bool s
     return out_len > ssk::kB && out_len <= 3 * ssk::kB && n_valid <= out_len && nbh_max >= 1 && nbh_max <= 16;
 }
 
+// Small steps of rows longer than one block (the reference's Replica arrangement: 5 envs per GPU at 44.1 kHz): one workgroup
+// per OUTPUT BLOCK of a row instead of one per row (k_obs_blocks) - while the whole grid fits the launch's share of the chip at
+// one workgroup per CU, which is also what makes the kernel's inter-workgroup hand-off safe.  Spare CUs go to parts (the STFT
+// phase of a block split 2 / 4 / 8 ways).  Returns 1 when the launch does not qualify (the caller falls through to k_obs_rows).
+template <bool SPECTRAL>
+int launch_obs_blocks(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStream_t st) {
+    static const bool off = ab_flag("SS_HIP_NO_OBS_BLOCKS");   // (A/B builds only)
+    const int n_rows = 2 * n_units, nb = (p.out_len + ssk::kB - 1) / ssk::kB;
+    const int budget = n_cus / (g_launch_share > 1 ? g_launch_share : 1);
+    if (off || (flags & SS_FLAG_CROSSFADE) || p.n_valid != p.out_len || nb < 2 || nb > 3 || n_rows * nb > budget ||
+        n_rows > kSyncRows || st == hipStreamPerThread)
+        return 1;
+    int k = 0;
+    while (k < 3 && ((n_rows * nb) << (k + 1)) <= budget) ++k;
+    p.parts_log2 = k;
+    p.nb_y = nb;
+    p.n_terms = (flags & SS_FLAG_NO_DISTRACTOR) ? 1 : 2;
+    p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
+    float* tails = nullptr;
+    int* fl = nullptr;
+    int epoch = 0;
+    int rc = get_block_sync(st, &tails, &fl, &epoch);
+    if (rc) return rc;
+    const int grid = (n_rows * nb) << k;
+    hipLaunchKernelGGL((ssk::k_obs_blocks<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows, tails, fl, epoch);
+    return hip_err(hipGetLastError());
+}
+
 template <bool SPECTRAL>
 int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStream_t st) {
     const int n_rows = 2 * n_units;
+    {
+        const int rc = launch_obs_blocks<SPECTRAL>(p, n_units, flags, n_cus, st);
+        if (rc != 1) return rc;
+    }
     // small steps (the reference steps 5-10 envs per GPU at this rate): a row on 2 / 4 / 8 CUs, each rendering the row and
     // its share of every phase's pooled STFT blocks - only while every (row, part) still gets a workgroup of its own
     // Time-domain bank: every part also repeats the row's stash round trip (640 KiB per row), and the launch turns
@@ -330,6 +398,15 @@ int ss_release_scratch(void) {
         kv.second.bytes = 0;
     }
     for (auto it = g_stash.begin(); it != g_stash.end();) it = it->second.ptr ? std::next(it) : g_stash.erase(it);
+    for (auto& kv : g_sync) {                                   // k_obs_blocks' hand-off areas likewise
+        if (!kv.second.tails) continue;
+        e = hipSetDevice(kv.first.first);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = hip_err(e); continue; }
+        (void)hipFree(kv.second.tails);
+        kv.second.tails = nullptr;
+    }
+    for (auto it = g_sync.begin(); it != g_sync.end();) it = it->second.tails ? std::next(it) : g_sync.erase(it);
     (void)hipSetDevice(cur);
     return rc;
 }

@@ -1847,11 +1847,47 @@ __device__ __forceinline__ void rows_product(const f32x4* hp, const f32x4* sp, i
     }
 }
 
+// Hand-off between WORKGROUPS of one launch (k_obs_blocks: the samples an output block leaves for the STFT frames that straddle
+// into the next block travel through global memory): agent-scope release / acquire on a flag word, the data itself read with
+// agent-scope loads (the XCDs' L2s are not coherent with each other for plain accesses).  The wait is BOUNDED: a consumer
+// that never sees its flag goes on with whatever the buffer holds - wrong numbers that the parity tests catch, never a hung GPU.
+struct BlockSync { int* flag_out; const int* flag_in; int epoch; };
+__device__ __forceinline__ void flag_release(int* f, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *f = v;
+#endif
+}
+__device__ __forceinline__ bool flag_acquire(const int* f, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == v) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+#else
+    return *f == v;                                       // (host build: workgroups run one after the other, producers first)
+#endif
+}
+__device__ __forceinline__ float ld_agent(const float* q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *q;
+#endif
+}
+
 // STFT of the pooled blocks [b0, b1) that output block j completes (see the kernel comment).  y = the block's kB samples
 // (packed pairs t + 1024 a).  `last`: j is the row's last block (right centre padding, frames up to n_frames - 1).
+// tail_in: the previous block's last samples (k_obs_rows: the workgroup's own LDS; GLOBAL_TAIL, k_obs_blocks: global memory
+// written by the workgroup that rendered block j - 1, waited for through sync.flag_in); tail_out (may be null): where the next
+// block's context goes, sync.flag_out (GLOBAL_TAIL) is released behind it.
+template <bool GLOBAL_TAIL = false>
 __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, int t, int unit, int ch, int j, int b0, int b1,
                                                 bool last, const c32 (&y)[8], const float* s_win, const c32* s_tw512,
-                                                const c32* s_wq, float* s_res, float* s_tail, int part = 0) {
+                                                const c32* s_wq, float* s_res, const float* tail_in, float* tail_out,
+                                                int part = 0, BlockSync sync = BlockSync{nullptr, nullptr, 0}) {
     float* buf = reinterpret_cast<float*>(lds);           // buf[k] = row sample 640 b0 - 256 + k
     const int base = kB * j;                              // first sample of this block
     const int ctx = j == 0 ? kNfft / 2 : base - (kHop * kPool * b0 - kNfft / 2);    // even, <= kTailFloats
@@ -1865,19 +1901,24 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
             const int n = base + 2 * (t + 1024 * a);
             yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);   // zeros beyond n_valid
         }
-        if (j > 0 && t < ctx) buf[t] = s_tail[t];         // the previous block's last samples
+        if (GLOBAL_TAIL) {
+            if (j > 0 && t == 0) (void)flag_acquire(sync.flag_in, sync.epoch);     // block j - 1 has left its last samples
+        } else if (j > 0 && t < ctx) buf[t] = tail_in[t]; // the previous block's last samples
     }
     lds_barrier();
+    if (GLOBAL_TAIL && j > 0 && t < ctx) buf[t] = ld_agent(tail_in + t);
     if (j == 0 && t < kNfft / 2) yl[-1 - t] = p.pad_mode == 0 ? yl[1 + t] : 0.f;              // left centre padding
     if (last && t >= 256 && t < 256 + kNfft / 2) {        // right centre padding: sample len + k = sample len - 2 - k
         const int k = t - 256;
         yl[len - base + k] = p.pad_mode == 0 ? yl[len - base - 2 - k] : 0.f;
     }
-    if (!last) {                                          // context of the next block: samples [640 b1 - 256, base + kB)
+    if (!last && tail_out) {                              // context of the next block: samples [640 b1 - 256, base + kB)
         const int s0n = kHop * kPool * b1 - kNfft / 2;
-        if (t < kTailFloats && s0n + t < base + kB) s_tail[t] = yl[s0n - base + t];
+        if (t < kTailFloats && s0n + t < base + kB) tail_out[t] = yl[s0n - base + t];
     }
     lds_barrier();
+    if (GLOBAL_TAIL && sync.flag_out && t == 0) flag_release(sync.flag_out, sync.epoch);      // (behind the barrier: every
+                                                          //  thread's tail store happened-before this agent-scope release)
     const int lane = t & 63, wv = t >> 6, cnt = b1 - b0;
     const c32 wq = s_wq[lane & 15];
     // frames relative to the buffer: pooled block b0 + k starts at buf + 640 k; both rounds are pulled into registers
@@ -2132,7 +2173,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                 lds_barrier();
             } else if (b1c > b0) {
                 rows_stft_phase(lds, p, tl, row_j >> 1, row_j & 1, j, b0, b1c, last && b1c == b1, y, s_win, s_tw512, s_wq, s_res, s_tail,
-                                part);
+                                s_tail, part);
             } else {
                 lds_barrier();                            // (the phase's entry barrier: pass-1' reads of the buffer are over)
             }
@@ -2148,6 +2189,124 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         }
         lds_barrier();                                    // s_res / the scratches are reused by the next row
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_obs_blocks (round 6): the fused observation of rows longer than one block for SMALL steps - the reference's own arrangement
+// at its Replica rate: 5 envs per GPU at 44.1 kHz (ss_baselines/av_nav/config/audionav/replica/train_telephone/
+// audiogoal_depth_ddppo.yaml:3, configs/audionav/av_nav/replica/audiogoal.yaml:18).  k_obs_rows gives a row ONE workgroup that
+// renders its output blocks one after the other (44.1 kHz: three forward and three inverse transforms, six products, three STFT
+// phases, a stash round trip: 51-72 us however few rows there are, on a chip that is 90 % idle).  Here every OUTPUT BLOCK of a
+// row has a workgroup (or 2^parts_log2 of them) of its own, on a CU of its own:
+//   workgroup (row, j):  Y_j = sum_i H'_i * S'_{j-i} exactly as k_conv<loop> / k_conv_spec<loop> render block j (time-domain
+//     bank: the j + 1 forward transforms accumulate in registers - redundant across the row's workgroups, on CUs that would
+//     idle; no stash) -> inverse -> the block's samples in registers -> the STFT phase of k_obs_rows for the pooled blocks
+//     [b0_j, b1_j) that block j completes (rows_stft_phase; split further over the block's parts).
+//   The STFT frames that straddle into block j start in block j - 1: its workgroup leaves its last <= 640 samples in global
+//     memory (`tails`) and releases a flag; workgroup (row, j) acquires it just before its STFT phase - long after it was set,
+//     block j - 1 has one transform / product less to do.  Flags carry the launch's epoch: nothing is reset between launches.
+// The launcher only uses this kernel when the whole grid fits the chip at one workgroup per CU, so every workgroup a flag is
+// waited for is running or about to; the wait is bounded anyway (flag_acquire).  Same arithmetic per output sample and per
+// pooled column as k_obs_rows: identical results.  Preconditions (launcher): n_valid == out_len (SoundSpaces 1.0 rows), no
+// cross-fade, 2 or 3 output blocks.
+template <bool SPECTRAL>
+__global__ __launch_bounds__(1024) void k_obs_blocks(ConvParams p, int n_rows, float* tails, int* flags, int epoch) {
+    __shared__ c32 lds[16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
+    __shared__ float s_win[kNfft];
+    __shared__ c32 s_tw512[kTw512Lds];
+    __shared__ float s_res[kRowsResFloats];
+    __shared__ c32 s_wq[16];
+    const int t = threadIdx.x;
+    const ThreadTw tw = load_thread_tw(p.tb.twM, p.tb.twItem, t);
+    {   // the STFT's tables (unconditional clamped loads: see k_conv); consumed behind the phase's first barriers
+        const float win_v = p.tb.win[t & (kNfft - 1)];
+        const c32 tw512_v = p.tb.tw512[t & 255];
+        const c32 wq0 = p.tb.twM[64 * (t & 15)];
+        if (t < kNfft) s_win[t] = win_v;
+        if (t < 256) s_tw512[posN(t)] = tw512_v;
+        if (t < 16) s_wq[t] = wq0;
+    }
+    const int nb_rows = (p.out_len + kB - 1) / kB;
+    // slot = ((row, part), j), j fastest: the workgroups of a row sit next to each other (one XCD: the block spectra H'_i that
+    // block j re-reads after block j - 1 come out of that L2, as in k_conv_spec)
+    const int slot = row_slot(blockIdx.x, (int)gridDim.x, p.xcd_map);
+    const int rp = __builtin_amdgcn_readfirstlane(slot / nb_rows), j = slot - rp * nb_rows;
+    const int part = rp & ((1 << p.parts_log2) - 1), row = rp >> p.parts_log2;
+    if (row >= n_rows) return;
+    const int unit = row >> 1, ch = row & 1;
+    i32x4 dws[2];
+    uniform_load8(p.desc + 8 * unit, dws[0], dws[1]);
+    if (p.n_terms < 2) dws[1].x = -1;
+    const bool last = j == nb_rows - 1;
+    const int b0 = j == 0 ? 0 : min(p.t4, pooled_blocks_complete(kB * j));
+    const int b1 = last ? p.t4 : min(p.t4, pooled_blocks_complete(kB * (j + 1)));
+    if (dws[0].x < 0 && dws[1].x < 0) {                   // silent unit (simulator.py:610-612): exact zeros; nobody waits for it
+        if (part) return;                                 // (the row's other workgroups are silent too)
+        if (p.out) {
+            const int lo = kB * j, hi = min(p.out_len, kB * (j + 1));
+            for (int n = lo + t; n < hi; n += kT) p.out[(size_t)row * p.out_len + n] = 0.f;
+        }
+        float* o = p.sgram + (size_t)unit * kBins4 * p.t4 * 2 + ch;
+        const int nz = b1 - b0;
+        for (int e = t; e < kBins4 * nz; e += kT) {
+            const int b = e / nz, k = b0 + (e - b * nz);
+            o[((size_t)b * p.t4 + k) * 2] = 0.f;
+        }
+        return;
+    }
+    c32 acc[2][8];
+    c32 y[8];
+    bool any = false;
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+        const i32x4 dw = term ? dws[1] : dws[0];
+        const int ridx = dw.x;
+        if (ridx < 0) continue;
+        const int spec0 = dw.y, m_min = dw.z, m_cnt = dw.w;
+        const int L = uniform_load(p.rir_len + ridx);
+        int nbh = (L + kB - 1) / kB;
+        if (SPECTRAL) {
+            const BankSpec bs = bank_spec(p, ridx, ch);
+            nbh = min(nbh, bs.h_blocks);
+            for (int i = 0; i < nbh; ++i) {
+                const int m = j - i;
+                if (m < m_min || m >= m_min + m_cnt) continue;
+                int tl = t;
+                SSK_OPAQUE1(tl);
+                spec_block_product(p.spec, tl, bs.hp + (size_t)i * (kSpecComplex / 2) + tl, spec0 + (m - m_min), any, acc);
+                any = true;
+            }
+        } else {
+            const BankRow br = bank_row(p, ridx, ch);
+            nbh = min(nbh, (br.cap + kB - 1) / kB);
+            for (int i = 0; i < nbh; ++i) {
+                const int m = j - i;
+                if (m < m_min || m >= m_min + m_cnt) continue;
+                int tl = t;
+                SSK_OPAQUE1(tl);                          // (per transform: see k_conv)
+                if (!any) {
+                    conv_block<false, false>(lds, p, tw, tl, br, L, i, spec0 + (m - m_min), acc);
+                    any = true;
+                } else {
+                    lds_barrier();                        // the previous transform's item reads are done
+                    conv_block<true, false>(lds, p, tw, tl, br, L, i, spec0 + (m - m_min), acc);
+                }
+            }
+        }
+    }
+    if (any) {
+        if (!SPECTRAL) lds_barrier();
+        items_to_time(lds, tw, t, acc, y);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) y[a] = mk2(0.f, 0.f);
+    }
+    if (part == 0) store_row_block(p, t, (size_t)row, j, y);
+    const size_t hand = (size_t)row * (nb_rows - 1);      // the row's hand-off slots: [row][j] = block j -> block j + 1
+    BlockSync sync{(!last && part == 0) ? flags + hand + j : nullptr, j > 0 ? flags + hand + (j - 1) : nullptr, epoch};
+    rows_stft_phase<true>(lds, p, t, unit, ch, j, b0, b1, last, y, s_win, s_tw512, s_wq, s_res,
+                          j > 0 ? tails + (hand + (j - 1)) * kTailFloats : nullptr,
+                          (!last && part == 0) ? tails + (hand + j) * kTailFloats : nullptr, part, sync);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -130,6 +130,9 @@ void hs_set_bucket2(const float* rir, int first, int cap) { g_b2_rir = rir; g_b2
 // the next hs_spectrogram call: rows are known to be zero from sample n_valid on (the library's own two-launch path)
 void hs_set_spec_n_valid(int n_valid) { g_spec_n_valid = n_valid; }
 void hs_set_parts_log2(int k) { g_parts_log2 = k; }
+// the next hs_obs_rows call runs k_obs_blocks (one workgroup per OUTPUT BLOCK of a row, tails handed over through memory)
+static int g_obs_blocks = 0;
+void hs_set_obs_blocks(int on) { g_obs_blocks = on; }
 
 int hs_source_windows(const float* src, const int* desc, float* spec, int n_windows) {
     ssk::SrcParams p;
@@ -345,7 +348,31 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     apply_bucket2(p);
     p.parts_log2 = g_parts_log2;                        // split rows: one workgroup per (row, part), whatever `wgs` says
     g_parts_log2 = 0;
-    const int n_rows = 2 * n_units, grid = p.parts_log2 ? (n_rows << p.parts_log2) : (wgs < n_rows ? wgs : n_rows);
+    const int n_rows = 2 * n_units;
+    if (g_obs_blocks) {
+        g_obs_blocks = 0;
+        if (crossfade || n_valid != out_len) return -3;
+        const int nb = (out_len + ssk::kB - 1) / ssk::kB, grid_b = (n_rows * nb) << p.parts_log2;
+        p.nb_y = nb;
+        p.xcd_map = 0;                                  // workgroups run in blockIdx order here: (row, j - 1) before (row, j)
+        p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
+        std::vector<float> tails(static_cast<size_t>(n_rows) * 2 * ssk::kTailFloats, 12345.0f);
+        std::vector<int> fl(static_cast<size_t>(n_rows) * 2, 0);
+        gridDim = dim3{(unsigned)grid_b, 1, 1};
+        for (int b = 0; b < grid_b; ++b) {
+            blockIdx = dim3{(unsigned)b, 0, 0};
+            int rc = run_block(ssk::kT, [&] {
+                if (hspec) ssk::k_obs_blocks<true>(p, n_rows, tails.data(), fl.data(), 7);
+                else ssk::k_obs_blocks<false>(p, n_rows, tails.data(), fl.data(), 7);
+            });
+            if (rc) return rc;
+        }
+        for (int r = 0; r < n_rows; ++r)                // every hand-off of a non-silent row was released exactly once
+            for (int j = 0; j + 1 < nb; ++j)
+                if (fl[static_cast<size_t>(r) * (nb - 1) + j] != 7 && fl[static_cast<size_t>(r) * (nb - 1) + j] != 0) return -4;
+        return 0;
+    }
+    const int grid = p.parts_log2 ? (n_rows << p.parts_log2) : (wgs < n_rows ? wgs : n_rows);
     std::vector<float> stash;
     p.stash = nullptr; p.stash_nbh = 0; p.stash_terms = 0;
     (void)use_stash;                                    // (the time-domain path always has its stash)

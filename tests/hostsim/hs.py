@@ -34,7 +34,7 @@ def _p(a, t):
 
 def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_spectrogram=False, pad_mode=0,
         interleaved=False, simple=True, persist=0, crossfade=False, spectral=False, row_wgs=0, want_audiogoal=True, row_stash=False,
-        bucket2=None, core32=False, tab=False, parts_log2=0):
+        bucket2=None, core32=False, tab=False, parts_log2=0, row_blocks=False):
     """sources: list of f32 arrays; rir_bank f32 [R,2,cap] planar (zero padded); units: list of dicts
     {sound, t0, rir, wrap=False, dis_sound=None, dis_t0=0, dis_rir=-1} (rir < 0: silent); with crossfade=True a unit's
     {last_rir, last_wrap} is the previous step's RIR (term 1 of the descriptor, SS_FLAG_CROSSFADE).
@@ -122,6 +122,8 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
             hspec = np.zeros((R, 2, hb, P.SPEC_FLOATS), np.float32)
             rc = L.hs_rir_spectra(_p(rir_bank, ctypes.c_float), _p(hspec, ctypes.c_float), R, ctypes.c_longlong(2 * cap), cap, cap)
             assert rc == 0, rc
+        if row_blocks:                                   # k_obs_blocks: one workgroup per output block of a row
+            L.hs_set_obs_blocks(1)
         rc = L.hs_obs_rows(_p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(hspec, ctypes.c_float) if spectral else None,
                            _p(rl, ctypes.c_int), _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
                            _p(sg, ctypes.c_float), int(N), ctypes.c_longlong(us), int(cs), int(es), int(cap), int(hb), int(n_valid),

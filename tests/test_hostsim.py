@@ -797,3 +797,32 @@ def test_split_rows_of_the_44k_kernel_equal_one_workgroup_per_row(parts_log2, va
         ref_a, ref_s, stride = case_outputs("clip1s_44k")
         check(s2[0], ref_s)
         assert not s2[1].any()
+
+
+@pytest.mark.parametrize("parts_log2", [0, 2])
+@pytest.mark.parametrize("variant", ["time", "spectral", "multi_second", "long_rir"])
+def test_one_workgroup_per_output_block_equals_the_row_kernel(parts_log2, variant):
+    """k_obs_blocks (round 6: small steps at the reference's Replica rate - one workgroup per OUTPUT BLOCK of a row, the samples
+    behind a block boundary handed to the next block's workgroup through global memory and a flag) against k_obs_rows on the same
+    launch: the same arithmetic per output sample and pooled column up to the order of a block's sum - time-domain bank (forward transforms
+    accumulated in registers, no stash) and spectral bank, a silent unit, a distractor, a 3-s clip in the steady branch
+    (simulator.py:641-647: pairs from several windows), a 1.5-s RIR (five RIR blocks), rows split over parts."""
+    name = {"multi_second": "multi_L1.0_i2_44k", "long_rir": "multi_L1.5_i2_44k"}.get(variant, "clip1s_44k")
+    d = case_inputs(name)
+    sr = d["sr"]
+    rng = np.random.default_rng(5)
+    L = d["rir"].shape[0]
+    bank = np.concatenate([planar(d["rir"]), planar(np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T))])
+    lens = [L] * 2
+    t0 = P.window_start_sim(len(d["source"]), sr, d.get("audio_index", 0))
+    short = O.synth_sources(np.random.default_rng(9), sr, k=1)[0]
+    units = [dict(sound=0, t0=t0, rir=0), dict(sound=0, t0=0, rir=-1), dict(sound=0, t0=t0, rir=1, dis_sound=1, dis_t0=0, dis_rir=0)]
+    kw = dict(fuse=True, row_wgs=64, spectral=variant == "spectral")
+    a1, s1 = hs.run([d["source"], short], bank, lens, units, sr, sr, **kw)
+    a2, s2 = hs.run([d["source"], short], bank, lens, units, sr, sr, parts_log2=parts_log2, row_blocks=True, **kw)
+    for n in (0, 2):                                       # (the products of a block are summed in another order: equal to rounding)
+        assert O.relerr(s2[n], s1[n]) < 2e-6 and O.relerr(a2[n], a1[n]) < 2e-6
+    ref_a, ref_s, stride = case_outputs(name)
+    check(s2[0], ref_s)
+    check(a2[0][:, ::stride], ref_a)
+    assert not s2[1].any() and not a2[1].any()
