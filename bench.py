@@ -509,7 +509,8 @@ def main():
                          "spectra computed once at bank load (ss_rir_spectra_f32), no forward FFT per step, 2x the bytes per "
                          "RIR.  The other format is timed in the same run and reported beside it.  'auto' (default) = what "
                          "AudioEngine(rir_spectral=None) does with both forms resident: 16-kHz steps of <= 64 units read the "
-                         "spectral rows (cfg1, cfg3, the reference's 5-10 envs per GPU), everything else the time-domain rows "
+                         "spectral rows (cfg1, cfg3, the reference's 5-10 envs per GPU) and so do 16-kHz steps with distractor "
+                         "terms (cfg4: two forward transforms per row), everything else the time-domain rows "
                          "(44.1 kHz: the metric's declared format; the engine itself prefers the spectral rows there)")
     ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg3", "cfg4"], default="headline",
                     help="BASELINE.json configs[] presets: cfg1 = 32 envs @16 kHz; cfg2 = 128 envs x 4 rotations @44.1 kHz "
@@ -549,8 +550,8 @@ def main():
 
     # (after the presets: 'auto' needs the step's size)
     units_per_step = (args.envs // args.gpus if args.scaling == "strong" else args.envs) * args.rotations
-    args.spectral = args.rir_bank == "spectral" or (args.rir_bank == "auto" and args.sr <= 16384 and units_per_step <= 64
-                                                    and args.workload != "savi")
+    args.spectral = args.rir_bank == "spectral" or (args.rir_bank == "auto" and args.sr <= 16384 and
+                                                    (units_per_step <= 64 or args.workload == "savi"))   # (savi: distractor terms)
     feats = args.features if args.features is not None else ("logmel,gccphat" if args.workload == "savi" else "none")
     feats = [f for f in feats.split(",") if f and f != "none"]
     assert all(f in ("logmel", "gccphat") for f in feats), "--features: logmel, gccphat"

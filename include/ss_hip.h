@@ -298,7 +298,9 @@ int ss_ctx_join(ss_ctx* ctx, void* stream);
  * against 17.1-19.0 us per step of 1-32 envs, the reference's 5-10 envs per GPU (ss_baselines/av_nav/config/audionav/
  * {replica,mp3d}/train_telephone/audiogoal_depth_ddppo.yaml:3) - while at 128 envs the forward FFT hides under the rows' loads
  * and the spectral rows are twice the bytes.  max_units > 0: steps of more than max_units units of one-block rows take the
- * time-domain rows; rows of several blocks (44.1 / 48 kHz) are not affected.  0 (default): the spectral form whenever set. */
+ * time-domain rows - unless the step has distractor terms (two forward transforms per row do not hide under one row's load:
+ * savi's 256-env step is 87.9 against 96.3 us); rows of several blocks (44.1 / 48 kHz) are not affected.  0 (default): the
+ * spectral form whenever set. */
 int ss_ctx_set_spectral_policy(ss_ctx* ctx, int max_units);
 /* Small steps are rendered by several workgroups per row while CUs would idle (ConvParams::parts_log2).  A caller that keeps
  * SEVERAL launch sources busy at once - e.g. two env groups stepped alternately, each with a context of its own on its own

@@ -360,7 +360,9 @@ int launch_obs_rows(ssk::ConvParams p, int n_units, int flags, int n_cus, hipStr
             return hip_err(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
+    // one bank allocation (every launch but those of a length-bucketed store): the instantiation without the bucket descriptors
+    if (p.n_buckets == 1) hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL, false, false>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
+    else hipLaunchKernelGGL((ssk::k_obs_rows<SPECTRAL>), dim3(grid), dim3(ssk::kT), 0, st, p, n_rows);
     return hip_err(hipGetLastError());
 }
 
@@ -1176,8 +1178,11 @@ static int ctx_observe_on(ss_ctx* h, const ss_units* units, int n, float* audiog
     }
     // cross-faded steps take the time-domain rows; so do LARGE steps of one-block rows when the caller keeps both forms and said
     // so (ss_ctx_set_spectral_policy): there the forward FFT hides under the row's load and the spectral rows are twice the bytes
+    // (... unless its units carry a second term - a distractor, simulator.py:649-664: two forward transforms per row do not hide
+    // under one row's load; savi's 256-env step: 87.9 against 96.3 us)
     const bool spectral = c.hspec && !(res.flags & SS_FLAG_CROSSFADE) &&
-                          !(c.spectral_max_units > 0 && c.rir && c.out_len <= ssk::kB && n > c.spectral_max_units);
+                          !(c.spectral_max_units > 0 && c.rir && c.out_len <= ssk::kB && n > c.spectral_max_units &&
+                            (res.flags & SS_FLAG_NO_DISTRACTOR));
     const int nbh_bank = spectral ? c.h_blocks : (c.rir_cap > 0 ? ssctx::ceil_div(c.rir_cap, c.kb) : 1);
     if (spectrogram && !audiogoal && c.out_len > ssk::kB && !wide_one_block_ok(c.out_len, c.n_valid, res.flags, spectral) &&
         !obs_rows_ok(c.out_len, c.n_valid, nbh_bank, res.flags, spectral, true)) {  // cross-faded / very long rows hand over through memory (the context's own buffer)

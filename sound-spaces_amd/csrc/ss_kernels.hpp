@@ -943,8 +943,12 @@ __device__ __forceinline__ int row_slot(int b, int G, int on) {
 
 // Time-domain row of bank entry ridx, ear ch: address, row capacity and element stride (wave-uniform).
 struct BankRow { const float* h; int cap, es; };
+// BUCKETS = false: the launch's bank is ONE allocation (n_buckets == 1: the launcher checks) - the three bucket descriptors
+// (24 scalar registers) and the compare chains never enter the kernel (k_obs_rows: 81-118 -> SGPR spills)
+template <bool BUCKETS = true>
 __device__ __forceinline__ BankRow bank_row(const ConvParams& p, int ridx, int ch) {
     BankRow r{p.rir + (size_t)ridx * p.rir_unit_stride + (size_t)ch * p.rir_chan_stride, p.rir_cap, p.rir_elem_stride};
+    if (!BUCKETS) return r;
 #pragma unroll
     for (int b = 0; b < kMaxBuckets - 1; ++b)
         if (b + 1 < p.n_buckets && ridx >= p.bk[b].first) {
@@ -956,8 +960,10 @@ __device__ __forceinline__ BankRow bank_row(const ConvParams& p, int ridx, int c
 }
 // Spectral row of bank entry ridx, ear ch: first block spectrum and the number of blocks stored per row.
 struct BankSpec { const f32x4* hp; int h_blocks; };
+template <bool BUCKETS = true>
 __device__ __forceinline__ BankSpec bank_spec(const ConvParams& p, int ridx, int ch) {
     BankSpec r{p.hspec + ((size_t)ridx * 2 + ch) * (size_t)p.h_blocks * (kSpecComplex / 2), p.h_blocks};
+    if (!BUCKETS) return r;
 #pragma unroll
     for (int b = 0; b < kMaxBuckets - 1; ++b)
         if (b + 1 < p.n_buckets && ridx >= p.bk[b].first) {
@@ -1946,7 +1952,7 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     }
 }
 
-template <bool SPECTRAL, bool XFADE = false>
+template <bool SPECTRAL, bool XFADE = false, bool BUCKETS = true>
 __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
     static_assert(!(SPECTRAL && XFADE), "cross-faded rows are rendered from the time-domain bank");
     __shared__ c32 lds[16 * kWaveScratch > kLdsComplex ? 16 * kWaveScratch : kLdsComplex];
@@ -1996,11 +2002,11 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         if (dws[0].x >= 0) nbh0 = min(kRowsMaxNbh, (uniform_load(p.rir_len + dws[0].x) + kB - 1) / kB);
         if (dws[1].x >= 0) nbh1 = min(kRowsMaxNbh, (uniform_load(p.rir_len + dws[1].x) + kB - 1) / kB);
         if (SPECTRAL) {
-            if (dws[0].x >= 0) nbh0 = min(nbh0, bank_spec(p, dws[0].x, 0).h_blocks);
-            if (dws[1].x >= 0) nbh1 = min(nbh1, bank_spec(p, dws[1].x, 0).h_blocks);
+            if (dws[0].x >= 0) nbh0 = min(nbh0, bank_spec<BUCKETS>(p, dws[0].x, 0).h_blocks);
+            if (dws[1].x >= 0) nbh1 = min(nbh1, bank_spec<BUCKETS>(p, dws[1].x, 0).h_blocks);
         } else {                                          // (never more blocks than the entry's row - and the stash - holds)
-            if (dws[0].x >= 0) nbh0 = min(nbh0, min(p.stash_nbh, (bank_row(p, dws[0].x, 0).cap + kB - 1) / kB));
-            if (dws[1].x >= 0) nbh1 = min(nbh1, min(p.stash_nbh, (bank_row(p, dws[1].x, 0).cap + kB - 1) / kB));
+            if (dws[0].x >= 0) nbh0 = min(nbh0, min(p.stash_nbh, (bank_row<BUCKETS>(p, dws[0].x, 0).cap + kB - 1) / kB));
+            if (dws[1].x >= 0) nbh1 = min(nbh1, min(p.stash_nbh, (bank_row<BUCKETS>(p, dws[1].x, 0).cap + kB - 1) / kB));
         }
         if (dws[0].x < 0 && dws[1].x < 0) {               // silent unit (simulator.py:610-612): exact zeros, no transforms
             if (part) continue;
@@ -2051,7 +2057,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                     const int term = pr >> 4, i = pr & 15;
                     int ti = tl;
                     SSK_OPAQUE1(ti);                      // per transform: see k_conv
-                    const BankRow br = bank_row(p, term ? dws[1].x : dws[0].x, ch);
+                    const BankRow br = bank_row<BUCKETS>(p, term ? dws[1].x : dws[0].x, ch);
                     if (last_new >= 0 || b0 > 0 || j > 0) lds_barrier();      // (the LDS buffer's previous readers are done)
                     rows_forward(lds, tw, ti, br, i);
                     if (fresh) {                          // not the last one: its spectrum just goes to the stash
@@ -2118,7 +2124,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
                         mp &= mp - 1;
                         const int term = pr >> 4, i = pr & 15;
                         const i32x4 dw = term ? dws[1] : dws[0];
-                        const f32x4* hp = SPECTRAL ? bank_spec(p, dw.x, ch).hp + (size_t)i * blk_f4
+                        const f32x4* hp = SPECTRAL ? bank_spec<BUCKETS>(p, dw.x, ch).hp + (size_t)i * blk_f4
                                                    : stash + (size_t)(term * p.stash_nbh + i) * blk_f4;
                         const f32x4* sp = p.spec + (size_t)(dw.y + (j - i - dw.z)) * blk_f4;
                         rows_product(hp + ti, sp + ti, ti, s, v);

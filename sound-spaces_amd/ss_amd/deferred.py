@@ -905,6 +905,9 @@ class DeferredResolver:
             ticking = hasattr(store, "_batch_of")
             if ticking:                                    # the store's LRU clock: the C lookups stamp the rows they use
                 store.begin_batch()
+            if getattr(self.engine, "spectral_max_units", 0):
+                # (engines that pick the bank form per step: does this step carry distractor terms?  renderer.AudioEngine)
+                self.engine._req_has_distractor = bool((np.frombuffer(buf, np.int64).reshape(n, REC_N)[:, REC_DIS_SOUND] >= 0).any())
             for attempt in range(3):
                 tables = self._request_tables()
                 if ticking:

@@ -362,8 +362,9 @@ class BatchedAudioRenderer:
     # (ss_ctx_set_spectral_policy has the numbers); 0 = the spectral form whenever it exists.  AudioEngine sets it.
     spectral_max_units = 0
 
-    def _spectral_for(self, n_units: int) -> bool:
-        return self.spectral_max_units <= 0 or self.out_len > P.KB or n_units <= self.spectral_max_units
+    def _spectral_for(self, n_units: int, distractor: bool = False) -> bool:
+        """(steps with distractor terms - two forward transforms per row - read the spectral rows at any size)"""
+        return self.spectral_max_units <= 0 or self.out_len > P.KB or n_units <= self.spectral_max_units or distractor
 
     def render(self, plan: Plan, want_audiogoal: bool = False,
                audiogoal_out: Optional[torch.Tensor] = None, spectrogram_out: Optional[torch.Tensor] = None):
@@ -374,7 +375,7 @@ class BatchedAudioRenderer:
         N = len(plan)
         xfade = bool(plan.flags & ops.FLAG_CROSSFADE)
         spectral = (self.rirs.spectra is not None if not isinstance(self.rirs, BucketedRirBank) else bool(self.rirs.spectra)) \
-            and not xfade and self._spectral_for(N)
+            and not xfade and self._spectral_for(N, not (plan.flags & ops.FLAG_NO_DISTRACTOR))
         need_ag = (want_audiogoal or audiogoal_out is not None or
                    (self.out_len > P.KB and not P.wide_one_block(self.out_len, self.n_valid, spectral)
                     and (xfade or self.n_valid <= P.KB or self.out_len > 3 * P.KB)))
@@ -400,10 +401,12 @@ class BatchedAudioRenderer:
         if out is None:
             out = torch.empty((len(plan), 2, self.out_len), dtype=torch.float32, device=self.device)
         if isinstance(self.rirs, BucketedRirBank):
-            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE) and self._spectral_for(len(plan))
+            spectral = bool(self.rirs.spectra) and not (plan.flags & ops.FLAG_CROSSFADE) and \
+                self._spectral_for(len(plan), not (plan.flags & ops.FLAG_NO_DISTRACTOR))
             ops.audio_obs_buckets_into(self._spec, self.rirs.c_array(spectral), len(self.rirs.banks), self.rirs.lengths,
                                        plan.desc, out, None, self.n_valid, self.out_len, self.pad_mode, flags=plan.flags)
-        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE) and self._spectral_for(len(plan)):
+        elif self.rirs.spectra is not None and not (plan.flags & ops.FLAG_CROSSFADE) and \
+                self._spectral_for(len(plan), not (plan.flags & ops.FLAG_NO_DISTRACTOR)):
             ops.fftconv_binaural_spec_into(self._spec, self.rirs.spectra, self.rirs.lengths, plan.desc, out, self.n_valid,
                                            flags=plan.flags)
         else:
@@ -1383,12 +1386,12 @@ class AudioEngine:
             self.store.on_grow = on_grow
         return self._ctx
 
-    def _sync_context_bank(self, n_units: int = 0):
+    def _sync_context_bank(self, n_units: int = 0, distractor: bool = True):
         """n_units: size of the step about to be launched (0 = unknown).  Under the small-step policy (spectral_max_units) the
         block spectra of freshly loaded rows are only built when a launch is going to read them: large steps (which take the
         time-domain rows) skip the transform, the rows stay marked and are transformed before the next small step."""
         ctx = self.context()
-        if n_units <= 0 or self.renderer._spectral_for(n_units):
+        if n_units <= 0 or self.renderer._spectral_for(n_units, distractor):
             n_sync = self.store.sync_spectra()
         else:
             n_sync = 0
@@ -1405,7 +1408,7 @@ class AudioEngine:
     def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None) -> int:
         """One step from the packed request records of ``ss_amd.deferred`` (``ss_ctx_observe_requests``: lookups + planner +
         launch in one C call).  Returns the number of unresolved requests (0: the step is on the stream)."""
-        ctx = self._sync_context_bank(n)
+        ctx = self._sync_context_bank(n, getattr(self, "_req_has_distractor", True))
         if getattr(self, "_req_miss", None) is None or self._req_miss["buf"].shape[0] < n:
             import ctypes
             buf, cnt = np.zeros((max(n, 256),), np.int32), ctypes.c_int(0)
@@ -1422,7 +1425,7 @@ class AudioEngine:
     def observe_columns(self, cols: Dict[str, np.ndarray], spectrogram_out=None, audiogoal_out=None) -> None:
         """One step from unit columns {sound, t0, rir[, dis_sound, dis_rir, last_rir, wrap, last_wrap]} (numpy, one entry
         per env; rir < 0 = silent) through the context: ONE ctypes call, outputs written into the given device tensors."""
-        ctx = self._sync_context_bank(len(cols["sound"]))
+        ctx = self._sync_context_bank(len(cols["sound"]), "dis_rir" in cols)
         ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **cols)
 
     def begin_batch(self) -> None:
@@ -1436,7 +1439,7 @@ class AudioEngine:
 
     def observe(self, units: Sequence[UnitRequest], want_audiogoal: bool = False, want_spectrogram: bool = True,
                 spectrogram_out=None, audiogoal_out=None) -> Dict[str, torch.Tensor]:
-        if self.renderer._spectral_for(len(units)):
+        if self.renderer._spectral_for(len(units), any(u.dis_rir >= 0 for u in units)):
             self.store.sync_spectra()
         else:
             self.store.flush_uploads()
