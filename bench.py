@@ -397,12 +397,12 @@ def dist_of(ms):
 
 
 def measured_traffic(units, sr, kernel):
-    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r5/traffic.json written by
-    scripts/gpu_profile_r5.sh with the hash of the kernel sources): null when the sources have changed since.  Both
+    """HBM bytes per launch from the committed PMC pass of THIS build (profiles/r6/traffic.json written by
+    scripts/gpu_profile_r6.sh with the hash of the kernel sources): null when the sources have changed since.  Both
     counters carry the factor measured in the same pass on a known byte count in the kernel's dominant access pattern
     (scripts/calib_traffic.hip)."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r5", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r6", "traffic.json")))
         have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.kernelhash")).read().strip()
         e = tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
@@ -411,7 +411,7 @@ def measured_traffic(units, sr, kernel):
                     "fetch_correction": fc, "write_bytes_raw": int(e["write_bytes"]), "write_correction": wc,
                     "calibrated_on": {"fetch": e.get("fetch_pattern"), "write": e.get("write_pattern")},
                     "tcc_hit_rate": e.get("tcc_hit_rate"),
-                    "traffic_source": "profiles/r5 rocprofv3 --pmc pass of this build (source hash matches), not measured in this run",
+                    "traffic_source": "profiles/r6 rocprofv3 --pmc pass of this build (source hash matches), not measured in this run",
                     "note": e.get("note", "")}
     except Exception:
         pass
@@ -1089,7 +1089,9 @@ def main():
         b = bytes_per_unit(sr, L, t4)
         kk = "k_conv_spec" if args.spectral else "k_conv"
         if sr > P.KB:
-            kname = f"k_obs_rows<SPECTRAL={'true' if args.spectral else 'false'}>"
+            # rows of 2-3 blocks: small steps (every output block of every row on a CU of its own) take k_obs_blocks
+            small = 2 * N * P.ceil_div(sr, P.KB) <= n_cus and sr <= 3 * P.KB
+            kname = f"{'k_obs_blocks' if small else 'k_obs_rows'}<SPECTRAL={'true' if args.spectral else 'false'}>"
         else:
             kname = f"{kk}<FUSE=true>" if fused else f"{kk}<FUSE=false>+k_spectrogram"
         bpu = (b["fused"] + (2 * sr * 4 if args.with_audiogoal else 0)) if fused else b["conv"] + b["spec"]

@@ -1,23 +1,24 @@
 #!/bin/bash
-# Round-5 final pass: GPU test-suite, the profile pass (scripts/gpu_profile_r5.sh: one bench line WITH its cpu_baseline + one
-# rocprofv3 kernel trace per configuration, PMC for headline / cfg2 / cfg4, counter calibration), then - with that pass's
-# traffic.json in place under profiles/r5/ - the headline lines again so that roofline.traffic is filled in; the RIR miss path
-# (scripts/bench_loader.py), SS2.0 deferred mode, the boundary modes, the eager profile, the feature kernels.  Everything lands
-# in gpurun_out/prof_r5/ (copy to profiles/r5/).  The same-box A/B files of the round (kbench_parts_*.txt, kbench_lanes.txt,
-# ab_sort_*.json, host_profile.txt) come from scripts/gpu_r5_{a,b,c,f}.sh / gpu_host_profile.sh with the -DSS_AB library (prebuilt
-# into gpurun_in/); pmc_cfg1.txt from gpu_pmc_small.sh, miss_breakdown.txt from gpu_r5_i.sh.
+# Round-6 final pass (ONE script; run through gpurun): GPU test-suite, the profile pass (scripts/gpu_profile_r6.sh: one bench line
+# WITH its cpu_baseline + one rocprofv3 kernel trace per configuration, PMC for headline / cfg1 / cfg2 / cfg4 / 10 envs @44.1 kHz,
+# counter calibration), then - with that pass's traffic.json in place under profiles/r6/ - the headline lines again so that
+# roofline.traffic is filled in; the savi pre-training set (scripts/bench_dataset.py), the RIR miss path (scripts/bench_loader.py),
+# SS2.0 deferred mode, the boundary modes, the eager profile, the feature kernels.  Everything lands in gpurun_out/prof_r6/ (copy to
+# profiles/r6/).  The conv-kernel roofline table comes from scripts/gpu_conv_roofline_r6.sh, the same-box A/B files of the round
+# (kbench_blocks_44k.txt) from scripts/gpu_obs_blocks_r6.sh - both build / use what they need themselves.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r5"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r6"
 timeout 1500 python -m pytest tests -m gpu -q > /tmp/pytest_final.log 2>&1; echo "pytest rc=$?"; tail -4 /tmp/pytest_final.log
 timeout 300 python -m pytest tests/test_context.py -m gpu -q -s -k "observe_features_equals" 2>&1 | grep "vs oracle" > /tmp/features_vs_oracle.txt; cat /tmp/features_vs_oracle.txt
-bash scripts/gpu_profile_r5.sh > /tmp/profile_pass.log 2>&1; echo "profile rc=$?"
+bash scripts/gpu_profile_r6.sh > /tmp/profile_pass.log 2>&1; echo "profile rc=$?"
 cp /tmp/pytest_final.log "$OUT/pytest_gpu.log"; cp /tmp/profile_pass.log "$OUT/profile_pass.log"; cp /tmp/features_vs_oracle.txt "$OUT/features_vs_oracle.txt"
-mkdir -p profiles/r5; cp "$OUT/traffic.json" profiles/r5/traffic.json
+mkdir -p profiles/r6; cp "$OUT/traffic.json" profiles/r6/traffic.json
 timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_headline_driver_protocol.json" 2> "$OUT/bench_headline_driver_protocol.err"; echo "driver-protocol rc=$?"
 timeout 900 python bench.py > "$OUT/bench_headline.json" 2> "$OUT/bench_headline.err"; echo "headline rc=$?"
 timeout 900 python bench.py --config cfg2 --steps 40 --warmup 5 --no-plugin-path > "$OUT/bench_cfg2.json" 2> "$OUT/bench_cfg2.err"
 timeout 900 python bench.py --config cfg4 --steps 100 --no-plugin-path > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
+timeout 900 python scripts/bench_dataset.py > "$OUT/dataset.json" 2> "$OUT/dataset.err"; echo "dataset rc=$?"; cat "$OUT/dataset.json"
 timeout 600 python scripts/bench_loader.py --out "$OUT/loader.json" > "$OUT/loader.log" 2>&1; echo "loader rc=$?"
 # SS2.0 deferred: the live-column path and, on the SAME box, round 4's per-request walk (alternating: host speed differs box to box)
 : > "$OUT/bench_deferred_continuous.jsonl"
@@ -33,7 +34,7 @@ timeout 300 python scripts/kbench_features.py > "$OUT/kbench_features.json" 2>/d
 for r in 0.01 0.05 0.25; do timeout 200 python scripts/miss_breakdown.py --rate $r 2>&1 | grep -v amdgpu | tail -12 >> "$OUT/miss_breakdown.txt"; done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/prof_r5/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/prof_r6/bench_*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         print(f.split('/')[-1], 'value',d['value'], 'ms',d['ms_per_step'], 'roofline',d['roofline']['frac'], d['roofline']['avg_launch_ms'], 'traffic', (d['roofline'].get('traffic') or {}).get('bytes') if isinstance(d['roofline'].get('traffic'),dict) else d['roofline'].get('traffic'), 'cpu', d.get('cpu_baseline',{}).get('value'), 'x', d.get('speedup_vs_cpu_all_cores'))

@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-5 profile pass (run through gpurun): for every tracked configuration
+# Round-6 profile pass (run through gpurun): for every tracked configuration
 #   1. the bench line as the driver runs it (default flags of that config; the headline also at --steps 20 --warmup 5)
 #   2. rocprofv3 --kernel-trace --stats of a SINGLE-STREAM run of the same config          -> stats_<cfg>.txt
 # for the headline, cfg2 and cfg4: one --pmc pass per counter group (separate runs, no tracing domains mixed in) -> pmc_<cfg>.txt
 # and the FETCH_SIZE / WRITE_SIZE calibration on known byte counts (scripts/calib_traffic.hip)     -> calibration in traffic.json
-# -> traffic.json (keyed by the hash of the kernel sources).  Copy gpurun_out/prof_r5/* to profiles/r5/.
+# -> traffic.json (keyed by the hash of the kernel sources).  Copy gpurun_out/prof_r6/* to profiles/r6/.
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r5"
+OUT="$GRAFT_REPO_ROOT/gpurun_out/prof_r6"
 rm -rf "$OUT"; mkdir -p "$OUT"
 declare -A CFG
 CFG[headline]=""
@@ -19,14 +19,19 @@ CFG[cfg4]="--config cfg4 --steps 100"
 CFG[cfg4_no_features]="--config cfg4 --steps 100 --features none"
 CFG[replica44k_128]="--sr 44100 --envs 128 --steps 60 --warmup 5"
 CFG[replica44k_10]="--sr 44100 --envs 10 --steps 100 --warmup 10"
+CFG[replica44k_5_spectral]="--sr 44100 --envs 5 --steps 100 --warmup 10 --rir-bank spectral"
+CFG[replica44k_10_spectral]="--sr 44100 --envs 10 --steps 100 --warmup 10 --rir-bank spectral"
+CFG[cfg2_spectral]="--config cfg2 --steps 40 --warmup 5 --rir-bank spectral"
+CFG[cfg1_time]="--config cfg1 --rir-bank time"
+CFG[cfg4_time]="--config cfg4 --steps 100 --rir-bank time"
 # every line carries its cpu_baseline (the oracle at the CONFIG's own rate and shape on the box's cores, ~16 s per line)
-for NAME in headline headline_driver_protocol cfg1 cfg2 cfg3 cfg4 cfg4_no_features replica44k_128 replica44k_10; do
+for NAME in headline headline_driver_protocol cfg1 cfg1_time cfg2 cfg2_spectral cfg3 cfg4 cfg4_time cfg4_no_features replica44k_128 replica44k_10 replica44k_10_spectral replica44k_5_spectral; do
   ARGS=${CFG[$NAME]}
-  EXTRA=""; [ "$NAME" = cfg4_no_features ] && EXTRA="--no-cpu-baseline"
+  EXTRA=""; case "$NAME" in cfg4_no_features|cfg1_time|cfg4_time|cfg2_spectral|replica44k_5_spectral) EXTRA="--no-cpu-baseline";; esac
   [ "$NAME" = headline ] || [ "$NAME" = headline_driver_protocol ] || EXTRA="$EXTRA --no-plugin-path"
   timeout 900 python bench.py $ARGS $EXTRA > "$OUT/bench_$NAME.json" 2> "$OUT/bench_$NAME.err" || echo "bench $NAME failed"
   [ "$NAME" = headline_driver_protocol ] && continue
-  [ "$NAME" = cfg4_no_features ] && continue
+  case "$NAME" in cfg4_no_features|cfg1_time|cfg4_time) continue;; esac
   D="$OUT/trace_$NAME"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o trace -- python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --regions 1 --sustain 0 > "$OUT/bench_under_rocprof_$NAME.json" 2>/dev/null )
   python - "$D" > "$OUT/stats_$NAME.txt" <<'PY'
@@ -39,7 +44,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursi
 PY
   rm -rf "$D"
 done
-for NAME in headline cfg2 cfg4; do
+for NAME in headline cfg1 cfg2 cfg4 replica44k_10; do
   ARGS=${CFG[$NAME]}
   CMD="python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1 --sustain 0"
   D="$OUT/pmc_$NAME"
@@ -84,8 +89,12 @@ for k, (ctr, nbytes) in known.items():
         calib[k]["other_counter_bytes"] = sum(v2) / len(v2) * 1024.0      # (a write kernel that also fetches: read-for-ownership)
 class Names(dict):                       # rocprofv3's template spelling -> bench.py's kernel names
     def _name(self, k):
-        if k.startswith("k_obs_rows<false"):
-            return "k_obs_rows<SPECTRAL=false>"
+        for kk in ("k_obs_rows", "k_obs_blocks"):
+            if k.startswith(kk + "<"):
+                return kk + ("<SPECTRAL=true>" if k.startswith(kk + "<true") else "<SPECTRAL=false>")
+        if k.startswith("k_conv_spec<"):     # <FUSE, SIMPLE, TAB>
+            b = [x.strip() == "true" for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            return "k_conv_spec<FUSE=%s%s>" % ("true" if b[0] else "false", "" if b[1] else ",loop")
         if k.startswith("k_conv<"):          # <FUSE, SIMPLE, XFADE, TAB, WIDE>
             b = [x.strip() == "true" for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
             if len(b) >= 3 and not b[2]:
@@ -103,10 +112,14 @@ names = Names()
 # goes out as 16-B nt stores and comes back as 16-B loads next to 8-B row loads (fetch side mixed: both factors are given)
 dominant = {"k_conv<FUSE=true>": ("rd8_nt", "wr4"), "k_conv<FUSE=true,loop>": ("rd8_nt", "wr8_nt"),
             "k_conv<FUSE=false,loop>": ("rd8_nt", "wr8_nt"), "k_conv<FUSE=false>": ("rd8_nt", "wr8_nt"),
-            "k_obs_rows<SPECTRAL=false>": ("rd16", "wr16_nt"), "k_features<logmel,gccphat>": ("rd16", "wr4"),
+            "k_obs_rows<SPECTRAL=false>": ("rd16", "wr16_nt"), "k_obs_rows<SPECTRAL=true>": ("rd16_nt", "wr4"),
+            "k_obs_blocks<SPECTRAL=false>": ("rd8_nt", "wr4"), "k_obs_blocks<SPECTRAL=true>": ("rd16_nt", "wr4"),
+            "k_conv_spec<FUSE=true>": ("rd16_nt", "wr4"), "k_conv_spec<FUSE=true,loop>": ("rd16_nt", "wr8_nt"),
+            "k_conv_spec<FUSE=false,loop>": ("rd16_nt", "wr8_nt"), "k_conv_spec<FUSE=false>": ("rd16_nt", "wr8_nt"),
+            "k_features<logmel,gccphat>": ("rd16", "wr4"),
             "k_features<spectrogram,logmel,gccphat>": ("rd16", "wr4")}
 kernels = {}
-for cfg in ("headline", "cfg2", "cfg4"):
+for cfg in ("headline", "cfg1", "cfg2", "cfg4", "replica44k_10"):
     d = os.path.join(out, "pmc_" + cfg)
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -146,11 +159,11 @@ json.dump({"source_hash": src_hash, "command": "bench.py [--config cfg2|cfg4] --
            "calibration": calib, "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps({"calibration": calib, "kernels": kernels}, indent=1))
 PY
-rm -rf "$OUT"/pmc_headline "$OUT"/pmc_cfg2 "$OUT"/pmc_cfg4 "$OUT"/pmc_calib
+rm -rf "$OUT"/pmc_headline "$OUT"/pmc_cfg1 "$OUT"/pmc_cfg2 "$OUT"/pmc_cfg4 "$OUT"/pmc_replica44k_10 "$OUT"/pmc_calib
 for f in "$OUT"/stats_*.txt; do echo "== $f"; cat "$f"; done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/prof_r5/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/prof_r6/bench_*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         print(f.split('/')[-1], 'value',d['value'], 'ms',d['ms_per_step'], 'roofline',d['roofline']['frac'], d['roofline']['avg_launch_ms'], 'pipe',d['roofline'].get('pipeline_frac'), {k:v.get('value') for k,v in d.items() if isinstance(v,dict) and 'value' in v and k not in ('roofline','cpu_baseline')})
