@@ -12,15 +12,23 @@ Workload = BASELINE.json's metric shape: 128 envs, 16 kHz, 1-s clips, 2-channel 
       torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1, one rank per GPU over RCCL - the
       reference's own launcher shape, ss_baselines/av_nav/single_node.sh:8-11); under torchrun it checks WORLD_SIZE == N.
 
+`value` (round 6) is the DEPENDENT-step figure: one env group; per step ss_ctx_observe renders into
+rollouts.observations['spectrogram'][step + 1], a one-workgroup kernel on the caller's stream consumes those rows (the policy's
+stand-in, csrc/ss_bench_token.hip) and the next step is ordered behind it - the loop a trainer runs
+(ss_baselines/av_nav/ppo/ppo_trainer.py:133-194).  `pipelined` = the r1-r5 protocol (independent steps on 2-3 internal streams:
+needs that many independent env groups), `dependent.two_groups` = a double-buffered sampler, `dependent.host_sync` = the host also
+waits for every step.
+
 N>1: every rank renders its own 128 envs (weak scaling, units are independent; --scaling strong splits 128 envs over the
-ranks, BASELINE configs[3]) and the per-rank spectrogram slabs are all-gathered over RCCL on a side stream (the exchange
-step BASELINE.json names) in chunks of --gather-every steps; the same run also times the per-step gather and the
-collective-free DD-PPO arrangement and reports them beside the headline.  Rank 0 prints ONE JSON line.
+ranks, BASELINE configs[3]), each rank's consumer reads its own slab (DD-PPO) and the per-rank spectrogram slabs are all-gathered
+over RCCL on a side stream (the exchange step BASELINE.json names) in chunks of --gather-every steps; the same run also times
+`exchange_none` (no collective: the reference's arrangement), `allgather`, `gather` (peer copies to one learner) and the per-step
+gather and reports them beside the headline.  Rank 0 prints ONE JSON line.
 
 The line also carries, measured in the same run: per-step GPU time distribution (HIP events per step), the convolution
-kernel alone (`roofline_conv_only`, the figure BASELINE's >= 40 % target is defined on), the spectral-RIR-bank variant,
-two-stream launch, the PLUGIN PATH (simulator state -> planning -> descriptor upload -> launch -> rollout rows, all
-inside the timed region) and the CPU oracle on the host cores this process may use.
+kernel alone on both bank forms (`roofline_conv_only`, `roofline_conv_only_spectral`: the figure BASELINE's >= 40 % target is
+defined on), the other RIR-bank format, the PLUGIN PATH (simulator state -> planning -> descriptor upload -> launch -> rollout
+rows, all inside the timed region) and the CPU oracle on the host cores this process may use.
 """
 import argparse
 import json
@@ -1026,6 +1034,7 @@ def main():
     # ---- the kernel's own rate: pre-planned descriptors, ONE stream - per-launch durations are separable only without
     # overlap, and this is the average the rocprofv3 kernel trace of the same command reports for the kernel
     per_step = None
+    kernel_pass = "preplanned_single_stream"
     if rank == 0 or world > 1:
         e_k, per_step, _ = run_loop(1, 0, args.spectral, regions=REGIONS)
         side["preplanned_single_stream"] = dict(rate(e_k), note="stateless entry point, descriptors planned outside the timed "
@@ -1034,8 +1043,13 @@ def main():
         _, ps, _ = run_loop(1, 0, args.spectral, per_step_events=True)
         step_dist = dist_of(ps)
         step_dist["note"] = "separate single-stream pass with one HIP event record per step (the records themselves add 2-3 us per step)"
-        e1, _, _ = run_loop(1, 0, args.spectral, lanes=1)
+        e1, ps_ctx, _ = run_loop(1, 0, args.spectral, lanes=1)
         side["ctx_single_stream"] = dict(rate(e1), note="ss_ctx_observe without overlap (a caller that joins every step)")
+        # Short kernels (small steps: 14-16 us): the pre-planned pass goes through the Python op layer (~19 us of host per launch)
+        # and its event average is then the HOST's rate, not the kernel's.  The context pass issues the same kernel from one C
+        # call (~7 us of host): the smaller of the two event averages is the one that is bound by the kernel
+        if per_step and ps_ctx and float(np.mean(ps_ctx)) < float(np.mean(per_step)):
+            per_step, kernel_pass = ps_ctx, "ctx_single_stream"
     if world > 1 and not args.no_secondary:
         #  every exchange arrangement from ONE run of `bench.py --gpus N`, same dependent-step protocol:
         #   exchange_none  no collective (the reference's DD-PPO arrangement: every rank's learner consumes its own slab)
@@ -1148,8 +1162,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": kname,
                          "bytes_per_unit": bpu, "units_per_launch": N, "avg_launch_ms": round(kernel_ms, 5),
-                         "pass": "single-stream pass of the same run over the same steps (preplanned_single_stream): per-launch "
-                                 "durations are only separable without overlap; HIP events around its timed region",
+                         "pass": f"single-stream pass of the same run over the same steps ({kernel_pass}): per-launch durations are only "
+                                 "separable without overlap; HIP events around its timed region (for kernels shorter than the host's "
+                                 "issue rate - small steps - the pass with the leaner host side is taken)",
                          "dependent_achieved": round(bpu * N / (elapsed / args.steps) / 1e9, 1),
                          "dependent_frac": round(bpu * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_achieved": round(bpu * N / (e_p / args.steps) / 1e9, 1),
