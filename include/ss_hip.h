@@ -364,6 +364,47 @@ typedef struct ss_request_tables {
 } ss_request_tables;
 int ss_ctx_observe_requests(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, float* audiogoal,
                             float* spectrogram, int* miss_out, int* n_miss, void* stream);
+/* Round 6: the same call with the miss path INSIDE it.  The reference reads a pose's RIR file on every cache-missing step
+ * (wavfile.read at soundspaces/simulator.py:615-618); with ss_ctx_observe_requests a step that meets a pose whose file is not
+ * resident costs three C calls and the store's Python bookkeeping between them (report -> ss_wav_read_rirs_f32 + scatter -> call
+ * again).  Here the caller lends the library what that bookkeeping needs - the RIR directories, the sorted resident-pair arrays
+ * with spare capacity, a stack of free bank entries, the bank and its length tables, a pinned staging block - and a step whose
+ * only misses are poses that are not resident is served in ONE call: file names built, files read by the library's reader
+ * straight into the staging block, one scatter launch into the free entries, the pair arrays extended in place, the step
+ * launched.  What was loaded is reported (loaded_key / loaded_slot / loaded_frames, n_loaded) so that the caller's own tables
+ * (key -> entry dictionaries, LRU order) follow; n_free and *n_pairs are updated.  Anything the fast path does not cover - an
+ * unknown sound or directory, a stale row, no free entry left (eviction is the caller's policy), a file that is not a plain
+ * float32 stereo wav / is missing / does not fit the rows, a launch that would read the spectral rows - changes NOTHING and is
+ * reported exactly as ss_ctx_observe_requests reports it (miss_out, *n_miss > 0).  Arrays are HOST memory unless said
+ * otherwise; `stage`, `stage_slot`, `stage_len` must be pinned (the scatter kernel reads them over the host link) and stay
+ * untouched by the caller until the stream has run the launch (the library waits for its own previous use of them). */
+typedef struct ss_miss_loader {
+    const char* const* table_dirs;   /* [n_table_dirs]: directory of table id t ("<BINAURAL_RIR_DIR>/<scene>/<azimuth>")      */
+    int n_table_dirs;
+    long long* pair_keys;            /* the arrays ss_request_tables.pair_keys / pair_slots point at, writable, ...            */
+    long long* pair_slots;
+    int pair_cap;                    /* ... with room for pair_cap entries; ss_request_tables.n_pairs is updated                */
+    int* free_slots;                 /* stack of free bank entries: the call pops free_slots[n_free - 1], ...                   */
+    int n_free;                      /* in: entries on the stack; out: entries left                                             */
+    float* bank;                     /* DEVICE: planar time-domain bank [entries][2][cap]                                        */
+    long long bank_unit_stride;      /* floats between entries                                                                   */
+    int bank_chan_stride, cap;
+    int* dev_len;                    /* DEVICE: rir_len table of the bank                                                        */
+    int* host_len;                   /* host mirror of it                                                                        */
+    unsigned char* clipped;          /* [entries]: 1 = the stored row is shorter than its file (keep < frames)                  */
+    unsigned char* spec_stale;       /* optional [entries]: 1 = the row's block spectra must be rebuilt before a spectral launch */
+    int keep;                        /* frames kept per file (1-s clips only ever hear h[0:sr]) or -1 = whole files              */
+    float* stage;                    /* PINNED: stage_rows rows of 2 * cap floats (wav layout)                                   */
+    int* stage_slot;                 /* PINNED [stage_rows]                                                                      */
+    int* stage_len;                  /* PINNED [stage_rows]                                                                      */
+    int stage_rows, threads;
+    long long* loaded_key;           /* report, capacity loaded_cap: pair key, ...                                               */
+    int* loaded_slot;                /* ... the entry it went to, ...                                                            */
+    int* loaded_frames;              /* ... frames in its file (kept = min(frames, keep))                                        */
+    int n_loaded, loaded_cap;
+} ss_miss_loader;
+int ss_ctx_observe_requests_load(ss_ctx* ctx, const long long* recs, int n, ss_request_tables* tables, ss_miss_loader* loader,
+                                 float* audiogoal, float* spectrogram, int* miss_out, int* n_miss, void* stream);
 /* The records -> unit columns step alone (host only, needs no GPU): units_out int32 [5, n] = sound, t0, rir, dis_sound, dis_rir. */
 int ss_ctx_requests_units(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, int* units_out,
                           int* miss_out, int* n_miss);

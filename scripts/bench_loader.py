@@ -85,7 +85,7 @@ def scene_load(dev, root, sr, n, native, workers):
     return {"files": n, "seconds": round(dt, 4), "files_per_s": round(n / dt, 1), "GBps": round(n * sr * 8 / dt / 1e9, 3)}
 
 
-def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources, profile=False, full_store=False):
+def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, sources, profile=False, full_store=False, in_call=True):
     """trainer half of a vector step with round(rate * n_envs) envs on a never-seen pose; full_store: a store that holds the
     resident set and little more, so every miss evicts (the steady state against a data set larger than the HBM set aside)"""
     from ss_amd.deferred import DeferredResolver, attach_deferred
@@ -120,6 +120,7 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
     rollouts = RolloutStorage(16, n_envs, space, ActionSpace(), 8, device=dev)
     if mode == "deferred":
         res = DeferredResolver(eng, rir_reader=reader, fast=True)
+        res.native_miss_path = bool(in_call)                     # False: report -> load_files -> call again (r5's three calls)
         for i, sim in enumerate(sims):
             attach_deferred(sim, env_rank=i)
 
@@ -171,7 +172,9 @@ def miss_steps(dev, root, sr, n_nodes, n_envs, rate, steps, native, mode, source
         pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(30)
         print(st.getvalue()[:7000], flush=True)
     hm = float(np.median(host))
-    return {"mode": mode, "reader": "native" if native else "scipy", "miss_rate": rate, "new_poses_per_step": m,
+    lib_loaded = getattr(res, "library_loaded", 0) if mode == "deferred" else getattr((vobs._rec or {}).get("res"), "library_loaded", 0)
+    return {"mode": mode, "reader": ("native" if in_call else "native, three calls (r5)") if native else "scipy", "miss_rate": rate,
+            "new_poses_per_step": m, "poses_loaded_inside_the_call": int(lib_loaded),
             "store": f"full: {eng.store.slots} slots, every miss evicts" if full_store else "roomy: no evictions",
             "trainer_half_us_per_step_median": round(1e6 * hm, 1), "trainer_half_us_per_step_mean": round(1e6 * float(np.mean(host)), 1),
             "env_steps_per_s_trainer_half": round(n_envs / float(np.mean(host)), 1),
@@ -282,8 +285,10 @@ def main():
     sources = O.synth_sources(rng, sr, k=8)
     for mode in ("deferred", "batched"):
         for rate in (0.01, 0.05, 0.25):
-            for native in (True, False):
-                r = miss_steps(dev, root, sr, n_nodes, a.envs, rate, a.steps, native, mode, sources)
+            for native, in_call in ((True, True), (True, False), (False, True)):
+                if mode == "batched" and not in_call:
+                    continue
+                r = miss_steps(dev, root, sr, n_nodes, a.envs, rate, a.steps, native, mode, sources, in_call=in_call)
                 out["miss_steps"].append(r)
                 print(json.dumps(r), flush=True)
     for rep in range(2):                                        # ... and with a FULL store (every miss evicts an old pose)

@@ -111,6 +111,7 @@ struct Context {
     hipEvent_t ev_xstream = nullptr;              // orders a new stream behind the previous one (pool reads / writes)
     // overlap mode (ss_ctx_set_overlap): consecutive steps alternate between internal streams ("lanes")
     int n_lanes = 1, lane_next = 0;
+    void* miss_ev = nullptr;            // hipEvent_t behind the last scatter of ss_ctx_observe_requests_load (its staging block is reused)
     int spectral_max_units = 0;         // ss_ctx_set_spectral_policy: one-block rows take the spectral bank only for steps of <= this many units (0: always)
     int chip_share = 0;                 // ss_ctx_set_chip_share: launch sources the chip is shared with (0: the lane count)
     hipStream_t lane_stream[kLanes] = {};

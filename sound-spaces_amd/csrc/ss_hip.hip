@@ -9,6 +9,7 @@
 #include <mutex>
 #include <utility>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/ss_hip.h"
@@ -873,6 +874,7 @@ static void ctx_free_device(ssctx::Context& c) {
     if (c.ev_made)
         for (int k = 0; k < ssctx::kRing / ssctx::kGroup; ++k) (void)hipEventDestroy(c.ev_done[k]);
     if (c.ev_xstream) (void)hipEventDestroy(c.ev_xstream);
+    if (c.miss_ev) { (void)hipEventDestroy(static_cast<hipEvent_t>(c.miss_ev)); c.miss_ev = nullptr; }
     c.ev_xstream = nullptr; c.have_last_stream = false;
     if (c.lanes_made) {
         for (int l = 0; l < ssctx::kLanes; ++l) {
@@ -1520,6 +1522,118 @@ int ss_ctx_observe_requests(ss_ctx* h, const long long* recs, int n, const ss_re
     u.sound = w.data(); u.t0 = u.sound + n; u.rir = u.t0 + n;
     bool any_dis = false;
     for (int i = 0; i < n && !any_dis; ++i) any_dis = u.rir[n + n + i] >= 0;     // dis_rir column
+    if (any_dis) { u.dis_sound = u.rir + n; u.dis_rir = u.dis_sound + n; }
+    return ss_ctx_observe(h, &u, n, audiogoal, spectrogram, stream);
+}
+
+// The miss path inside the call (include/ss_hip.h: ss_miss_loader).  Returns 1 = "not for the fast path" (nothing was changed).
+static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, const int* miss,
+                             int n_miss, hipStream_t st) {
+    ssctx::Context& c = h->c;
+    if (!ld || !ld->table_dirs || !ld->pair_keys || !ld->pair_slots || !ld->free_slots || !ld->bank || !ld->dev_len ||
+        !ld->host_len || !ld->clipped || !ld->stage || !ld->stage_slot || !ld->stage_len || !ld->loaded_key || !ld->loaded_slot ||
+        !ld->loaded_frames || ld->cap < 2 || (ld->cap & 1) || tb->pair_keys != ld->pair_keys || tb->pair_slots != ld->pair_slots)
+        return 1;
+    const int n_src = static_cast<int>(c.src_len.size());
+    std::vector<long long> keys;
+    auto want = [&](long long tid, long long recv, long long src) -> bool {      // false: not serviceable here
+        if (recv < 0 || src < 0 || recv >= (1 << 20) || src >= (1 << 20) || tid >= ld->n_table_dirs || !ld->table_dirs[tid]) return false;
+        const long long key = (tid << 40) | (recv << 20) | src;
+        const long long s = find_key(tb->pair_keys, tb->pair_slots, tb->n_pairs, key);
+        if (s >= 0) return !(tb->stale && s < tb->n_slots && tb->stale[s]);      // resident (a stale row is the caller's reload)
+        keys.push_back(key);
+        return true;
+    };
+    for (int k = 0; k < n_miss; ++k) {
+        const long long* r = recs + static_cast<size_t>(miss[k]) * SS_REQ_WORDS;
+        const long long sid = find_key(tb->sound_keys, tb->sound_ids, tb->n_sounds, r[1]);
+        const long long tid = find_key(tb->table_keys, tb->table_ids, tb->n_tables, r[3]);
+        if (sid < 0 || sid >= n_src || tid < 0 || r[2] < 0 || r[2] > 0x7fffffffLL) return 1;
+        if (!want(tid, r[4], r[5])) return 1;
+        if (r[6] >= 0) {
+            const long long did = find_key(tb->sound_keys, tb->sound_ids, tb->n_sounds, r[6]);
+            if (did < 0 || did >= n_src || !want(tid, r[4], r[7])) return 1;
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const int k = static_cast<int>(keys.size());
+    if (k == 0 || k > ld->n_free || k > ld->stage_rows || k > ld->loaded_cap || tb->n_pairs + k > ld->pair_cap) return 1;
+    if (c.miss_ev) {                                           // the staging block's previous scatter has run
+        if (hipEventSynchronize(static_cast<hipEvent_t>(c.miss_ev)) != hipSuccess) return 1;
+    } else {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        c.miss_ev = ev;
+    }
+    std::vector<std::string> paths(k);
+    std::vector<const char*> cp(k);
+    for (int i = 0; i < k; ++i) {
+        const long long key = keys[i];
+        paths[i] = std::string(ld->table_dirs[key >> 40]) + "/" + std::to_string((key >> 20) & 0xFFFFF) + "_" +
+                   std::to_string(key & 0xFFFFF) + ".wav";                       // simulator.py:615-616
+        cp[i] = paths[i].c_str();
+    }
+    std::vector<int> kept(k), frames(k), status(k);
+    sswav::read_many(cp.data(), k, ld->stage, 2LL * ld->cap, ld->cap, ld->keep, false, kept.data(), frames.data(), status.data(),
+                     ld->threads > 0 ? ld->threads : 1);
+    for (int i = 0; i < k; ++i)
+        if (status[i] != sswav::kOk && status[i] != sswav::kEmpty) return 1;     // scipy's semantics are the caller's reader's
+    // ---- commit
+    for (int i = 0; i < k; ++i) {
+        const int slot = ld->free_slots[--ld->n_free];
+        ld->stage_slot[i] = slot;
+        ld->stage_len[i] = kept[i];
+        ld->host_len[slot] = kept[i];
+        ld->clipped[slot] = kept[i] < frames[i];
+        if (ld->spec_stale) ld->spec_stale[slot] = 1;
+        ld->loaded_key[i] = keys[i]; ld->loaded_slot[i] = slot; ld->loaded_frames[i] = frames[i];
+        if (tb->last_used && slot < tb->n_slots) tb->last_used[slot] = tb->tick;
+    }
+    ld->n_loaded = k;
+    int rc = ss_bank_scatter_rows_f32(ld->stage, 2LL * ld->cap, ld->stage_slot, ld->stage_len, k, ld->bank, ld->bank_unit_stride,
+                                      ld->bank_chan_stride, ld->cap, ld->dev_len, st);
+    if (rc == 0) rc = hip_err(hipEventRecord(static_cast<hipEvent_t>(c.miss_ev), st));
+    // the sorted pair arrays, in place (keys ascending: merged from the back)
+    {
+        int i = tb->n_pairs - 1, j = k - 1, o = tb->n_pairs + k - 1;
+        while (j >= 0) {
+            if (i >= 0 && ld->pair_keys[i] > keys[j]) { ld->pair_keys[o] = ld->pair_keys[i]; ld->pair_slots[o] = ld->pair_slots[i]; --i; }
+            else { ld->pair_keys[o] = keys[j]; ld->pair_slots[o] = ld->loaded_slot[j]; --j; }
+            --o;
+        }
+        tb->n_pairs += k;
+    }
+    return rc;                                                 // (< 0: the rows are booked, the launch failed: the caller sees the error)
+}
+
+int ss_ctx_observe_requests_load(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, float* audiogoal,
+                                 float* spectrogram, int* miss_out, int* n_miss, void* stream) {
+    if (!h || n < 0 || !tb) return SS_EINVAL;
+    if (ld) ld->n_loaded = 0;
+    std::vector<int>& w = h->c.sim_scratch;
+    w.resize(static_cast<size_t>(n) * 5 + 1);
+    int rc = requests_to_units(h, recs, n, tb, w.data(), miss_out, n_miss);
+    if (rc != 0 || n == 0) return rc;
+    if (*n_miss) {
+        ssctx::Context& c = h->c;
+        // a launch that reads the SPECTRAL rows needs the new rows' block spectra first: the caller's path
+        bool any_dis = false;
+        for (int i = 0; i < n && !any_dis; ++i) any_dis = recs[static_cast<size_t>(i) * SS_REQ_WORDS] == 0 && recs[static_cast<size_t>(i) * SS_REQ_WORDS + 6] >= 0;
+        const bool spectral = c.hspec && !(c.spectral_max_units > 0 && c.rir && c.out_len <= ssk::kB && n > c.spectral_max_units && !any_dis);
+        if (!ld || !miss_out || spectral || c.rir != ld->bank) return 0;
+        std::vector<int> miss(miss_out, miss_out + (*n_miss < n ? *n_miss : n));
+        rc = serve_pose_misses(h, recs, n, tb, ld, miss.data(), static_cast<int>(miss.size()), static_cast<hipStream_t>(stream));
+        if (rc == 1) return 0;                                 // reported as ss_ctx_observe_requests reports it
+        if (rc) return rc;
+        rc = requests_to_units(h, recs, n, tb, w.data(), miss_out, n_miss);
+        if (rc != 0 || *n_miss) return rc;
+    }
+    ss_units u;
+    std::memset(&u, 0, sizeof u);
+    u.sound = w.data(); u.t0 = u.sound + n; u.rir = u.t0 + n;
+    bool any_dis = false;
+    for (int i = 0; i < n && !any_dis; ++i) any_dis = u.rir[n + n + i] >= 0;
     if (any_dis) { u.dis_sound = u.rir + n; u.dis_rir = u.dis_sound + n; }
     return ss_ctx_observe(h, &u, n, audiogoal, spectrogram, stream);
 }

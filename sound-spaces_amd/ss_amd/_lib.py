@@ -16,13 +16,27 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
            "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
            "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features",
-           "ss_wav_read_rirs_f32", "ss_rows_gather_f32", "ss_bank_scatter_rows_f32", "ss_ctx_set_chip_share", "ss_ctx_set_spectral_policy")
+           "ss_wav_read_rirs_f32", "ss_rows_gather_f32", "ss_bank_scatter_rows_f32", "ss_ctx_set_chip_share", "ss_ctx_set_spectral_policy", "ss_ctx_observe_requests_load")
 
 
 class SsRirBucket(ctypes.Structure):
     """struct ss_rir_bucket of include/ss_hip.h."""
     _fields_ = [("rir", ctypes.c_void_p), ("hspec", ctypes.c_void_p), ("first", ctypes.c_int), ("n_entries", ctypes.c_int),
                 ("cap", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class SsMissLoader(ctypes.Structure):
+    """struct ss_miss_loader of include/ss_hip.h (ss_ctx_observe_requests_load: the miss path inside the call)."""
+    _fields_ = [("table_dirs", ctypes.POINTER(ctypes.c_char_p)), ("n_table_dirs", ctypes.c_int),
+                ("pair_keys", ctypes.c_void_p), ("pair_slots", ctypes.c_void_p), ("pair_cap", ctypes.c_int),
+                ("free_slots", ctypes.c_void_p), ("n_free", ctypes.c_int),
+                ("bank", ctypes.c_void_p), ("bank_unit_stride", ctypes.c_longlong), ("bank_chan_stride", ctypes.c_int),
+                ("cap", ctypes.c_int), ("dev_len", ctypes.c_void_p), ("host_len", ctypes.c_void_p), ("clipped", ctypes.c_void_p),
+                ("spec_stale", ctypes.c_void_p), ("keep", ctypes.c_int),
+                ("stage", ctypes.c_void_p), ("stage_slot", ctypes.c_void_p), ("stage_len", ctypes.c_void_p),
+                ("stage_rows", ctypes.c_int), ("threads", ctypes.c_int),
+                ("loaded_key", ctypes.c_void_p), ("loaded_slot", ctypes.c_void_p), ("loaded_frames", ctypes.c_void_p),
+                ("n_loaded", ctypes.c_int), ("loaded_cap", ctypes.c_int)]
 
 
 class SsSimColumns(ctypes.Structure):
@@ -109,6 +123,7 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe_features.argtypes = [vp, ctypes.POINTER(SsUnits), c_int, vp, vp, ctypes.POINTER(SsFeatures), vp]
     lib.ss_ctx_observe_requests.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp]
     lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
+    lib.ss_ctx_observe_requests_load.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp, vp]
     lib.ss_wav_read_rirs_f32.argtypes = [vp, c_int, vp, c_ll, c_int, c_int, c_int, vp, vp, vp, c_int]
     lib.ss_rows_gather_f32.argtypes = [vp, vp, c_int, vp, c_ll, c_int, c_int]
     lib.ss_bank_scatter_rows_f32.argtypes = [vp, c_ll, vp, vp, c_int, vp, c_ll, c_int, c_int, vp, vp]

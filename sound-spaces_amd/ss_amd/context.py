@@ -337,6 +337,17 @@ class AudioContext:
             _lib.check(rc, "ss_ctx_observe_requests")
         return miss["n"].value
 
+    def observe_requests_load(self, recs: bytes, n: int, tables, loader, spectrogram_ptr, audiogoal_ptr, stream: int, miss) -> int:
+        """``observe_requests`` with the miss path inside the call (``ss_ctx_observe_requests_load``): `loader` = the dict of
+        ``renderer.RirStore.miss_loader`` (struct ss_miss_loader + what keeps its arrays alive).  Poses that are not resident are
+        read, scattered and booked by the library when the fast path covers them (loader['s'].n_loaded says how many); otherwise
+        the call behaves exactly like ``observe_requests``."""
+        rc = self.lib.ss_ctx_observe_requests_load(self._h, recs, n, tables["ref"], loader["ref"], audiogoal_ptr, spectrogram_ptr,
+                                                   miss["ptr"], miss["n_ptr"], stream)
+        if rc != 0:
+            _lib.check(rc, "ss_ctx_observe_requests_load")
+        return miss["n"].value
+
     def requests_units(self, recs: bytes, n: int, tables):
         """Host only: the unit columns ``observe_requests`` would render -> (dict of int32 columns, missing request indices)."""
         out = np.zeros((5, max(n, 1)), np.int32)

@@ -294,6 +294,11 @@ class DeferredResolver:
         self._native_reader = None                          # (rir_reader, stock wav reader?, lenient?), decided on first use
         self.column_steps = self.walk_steps = 0
         # resident RIR files: sorted composite keys (table << 40 | receiver << 20 | source) -> store slot
+        self._pair_buf = None                               # (keys, slots) buffers with spare capacity behind _pk / _ps (_request_tables)
+        self._loader = None                                 # RirStore.miss_loader dict (ss_ctx_observe_requests_load)
+        self._loader_ok = None
+        self.native_miss_path = True                        # False: pose misses always take report -> load_files -> call again
+        self.library_loaded = 0                             # poses the library loaded inside the step's call
         self._pk = np.zeros((0,), np.int64)                 # resident (table, receiver, source) keys, sorted: _pair_keys
         self._ps = np.zeros((0,), np.int64)                 # ... and their store slots: _pair_slots
         self._evq: List[int] = []                           # keys the store has evicted since the arrays were last read
@@ -717,11 +722,54 @@ class DeferredResolver:
         if self._tables is None:
             store = self.engine.store
             ctx = self.engine.context()
-            self._tables = ctx.request_tables(self._sound_keys, self._sound_ids, self._table_keys, self._table_ids,
-                                              self._pair_keys, self._pair_slots,
-                                              stale=store._clipped if store.truncate_to is None else None,
-                                              last_used=getattr(store, "_batch_of", None))
+            pk, ps = self._pair_keys, self._pair_slots
+            if self._use_loader():
+                # the library extends the resident-pair arrays in place when it serves a step's pose misses itself
+                # (ss_ctx_observe_requests_load): they live at the front of buffers with spare capacity
+                n = pk.shape[0]
+                if self._pair_buf is None or pk.base is not self._pair_buf[0] or self._pair_buf[0].shape[0] < n + 128:
+                    cap = max(2 * n, n + 1024)
+                    bk, bs = np.zeros((cap,), np.int64), np.zeros((cap,), np.int64)
+                    bk[:n], bs[:n] = pk, ps
+                    self._pair_buf = (bk, bs)
+                    self._pk, self._ps = bk[:n], bs[:n]
+                pk, ps = self._pair_buf
+            t = ctx.request_tables(self._sound_keys, self._sound_ids, self._table_keys, self._table_ids, pk, ps,
+                                   stale=store._clipped if store.truncate_to is None else None,
+                                   last_used=getattr(store, "_batch_of", None))
+            t["t"].n_pairs = int(self._pk.shape[0])         # (the buffers are longer than what is resident)
+            self._tables = t
         return self._tables
+
+    def _use_loader(self) -> bool:
+        """May the library serve pose misses itself?  (a GPU ``RirStore`` with one row per key behind the stock wav reader)"""
+        if self._loader_ok is None:
+            from .renderer import RirStore, _native_wav
+            import functools
+            store = self.engine.store
+            strict = not (isinstance(self.rir_reader, functools.partial) and self.rir_reader.keywords.get("lenient"))
+            self._loader_ok = bool(self.native_miss_path and type(store) is RirStore and store.group == 1 and
+                                   store.device.type == "cuda" and hasattr(self.engine, "_sync_context_bank") and
+                                   _native_wav(self.rir_reader) and strict)
+        return self._loader_ok
+
+    def _miss_loader(self):
+        """the store's ss_miss_loader over this resolver's directories and pair buffers, refreshed for the coming call"""
+        store = self.engine.store
+        bk, bs = self._pair_buf
+        if self._loader is None:
+            self._loader = store.miss_loader(self._table_dirs, bk, bs, int(self._pk.shape[0]))
+        else:
+            store.refresh_loader(self._loader, self._table_dirs, bk, bs)
+        return self._loader
+
+    def _adopt_loaded(self) -> None:
+        """after a call in which the library loaded poses itself: the store's dictionaries and this resolver's views follow"""
+        k = self.engine.store.adopt_loaded(self._loader, lambda key: ("ix", key))
+        if k:
+            n = int(self._tables["t"].n_pairs)
+            self._pk, self._ps = self._pair_buf[0][:n], self._pair_buf[1][:n]
+            self.library_loaded += k
 
     def _columns(self, requests: Sequence[AudioRequest], buf: Optional[bytes] = None):
         """The N requests of a vector step -> unit columns for ``engine.observe_columns`` in numpy, registering what is new:
@@ -912,7 +960,13 @@ class DeferredResolver:
                 tables = self._request_tables()
                 if ticking:
                     tables["t"].tick = store._batch
-                n_miss = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag)
+                if self._use_loader() and not self._evq:
+                    n_miss = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag,
+                                                          loader=self._miss_loader())
+                    if self._loader["s"].n_loaded:
+                        self._adopt_loaded()
+                else:
+                    n_miss = self.engine.observe_requests(buf, n, tables, spectrogram_out=sg, audiogoal_out=ag)
                 if n_miss == 0:
                     done = True
                     break

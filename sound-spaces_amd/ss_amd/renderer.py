@@ -16,6 +16,7 @@ constructor raises.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -468,6 +469,7 @@ class RirStore:
         self.host_len = np.zeros((slots,), np.int32)          # host mirror of bank.lengths (branch selection, planning)
         self._slot_of: Dict[object, int] = {}      # insertion order == LRU order (oldest first)
         self._free: List[int] = list(range(slots - group, -1, -group))
+        self._free_ver = 0                                     # bumped whenever _free changes (miss_loader's mirror of its top)
         self._batch = 0
         self._batch_of = np.full((slots,), -1, np.int64)      # batch in which the slot was last handed out
         # victim selection without walking the dict (a FULL store is the steady state against an 867-GB data set: every miss
@@ -759,6 +761,7 @@ class RirStore:
         self._key_at[slot] = None
         self._used[slot] = False
         self._free.append(slot)
+        self._free_ver += 1
 
     def _take_slot(self) -> int:
         return self._take_slots(1)[0]
@@ -772,6 +775,7 @@ class RirStore:
         entries of one batch) fall back to the order of use through slot(): oldest first.  All numpy over the slot arrays:
         the first version rebuilt a list of the dict per victim (150 us per miss at 4096 resident poses)."""
         out: List[int] = []
+        self._free_ver += 1
         while self._free and len(out) < k:
             out.append(self._free.pop())
         r = k - len(out)
@@ -806,6 +810,87 @@ class RirStore:
                 self._notify_evict(victim, slot)
             out.append(slot)
         return out
+
+    # ---- the miss path inside the library (ss_ctx_observe_requests_load) ---------------------------------------------------
+    _LOADER_FREE = 64                                            # free entries lent per call (= new poses one call may load)
+
+    def miss_loader(self, table_dirs: Sequence[str], pair_keys: np.ndarray, pair_slots: np.ndarray, n_pairs: int, threads: int = 0):
+        """struct ss_miss_loader over THIS store (GPU stores, group == 1): the library may then serve a step's pose misses itself -
+        files read by its reader into a pinned block of this store, one scatter launch into free entries, `pair_keys` /
+        `pair_slots` (int64 buffers with spare capacity, `n_pairs` entries used) extended in place.  The returned dict is reused
+        from step to step (``refresh_loader`` before a call, ``adopt_loaded`` after one that loaded something)."""
+        import ctypes
+        from . import _lib
+        assert self.device.type == "cuda" and self.group == 1
+        L = _lib.SsMissLoader()
+        pin = dict(dtype=torch.int32, pin_memory=True)
+        rows = self._LOADER_FREE
+        d = dict(s=L, ref=ctypes.byref(L), free=np.zeros((rows,), np.int32), free_ver=-1, free_n=0,
+                 loaded_key=np.zeros((rows,), np.int64), loaded_slot=np.zeros((rows,), np.int32), loaded_frames=np.zeros((rows,), np.int32),
+                 stage_slot=torch.zeros((rows,), **pin), stage_len=torch.zeros((rows,), **pin), stage=None, cap=-1, bank=None,
+                 dirs=None, dirs_arr=None, pk=None)
+        L.free_slots = d["free"].ctypes.data
+        L.loaded_key, L.loaded_slot, L.loaded_frames = (d[k_].ctypes.data for k_ in ("loaded_key", "loaded_slot", "loaded_frames"))
+        L.loaded_cap = L.stage_rows = rows
+        L.stage_slot, L.stage_len = d["stage_slot"].data_ptr(), d["stage_len"].data_ptr()
+        L.threads = int(threads) if threads > 0 else min(8, os.cpu_count() or 1)
+        self.refresh_loader(d, table_dirs, pair_keys, pair_slots)
+        return d
+
+    def refresh_loader(self, d, table_dirs: Sequence[str], pair_keys: np.ndarray, pair_slots: np.ndarray) -> None:
+        """Point the loader at what may have been replaced since its last use (bank after a growth, pair buffers after a merge,
+        a new RIR directory) and refill its stack of free entries when the store's free list changed.  Cheap when nothing did."""
+        import ctypes
+        L = d["s"]
+        bank = self.bank
+        if (d["bank"] is bank.data and d["cap"] == self.cap and d["free_ver"] == self._free_ver and L.n_free == d["free_n"] and
+                d["dirs"] is table_dirs and L.n_table_dirs == len(table_dirs) and d["pk"] is pair_keys and
+                d.get("keep") == self.truncate_to and not (L.n_free < 16 and len(self._free) > L.n_free)):
+            return                                               # nothing changed since the last call (the steady state)
+        d["keep"] = self.truncate_to
+        if d["bank"] is not bank.data or d["cap"] != self.cap:
+            if d["stage"] is None or d["cap"] != self.cap:
+                if d["stage"] is not None:
+                    torch.cuda.synchronize(self.device)          # (a scatter may still be reading the old block)
+                d["stage"] = torch.zeros((L.stage_rows, self.cap, 2), dtype=torch.float32, pin_memory=True)
+                L.stage = d["stage"].data_ptr()
+            d["bank"], d["cap"] = bank.data, self.cap
+            L.bank, L.bank_unit_stride, L.bank_chan_stride, L.cap = bank.data.data_ptr(), bank.data.stride(0), bank.data.stride(1), self.cap
+            L.dev_len = bank.lengths.data_ptr()
+        L.host_len, L.clipped = self.host_len.ctypes.data, self._clipped.ctypes.data
+        L.spec_stale = self._stale.ctypes.data if self.spectral else None
+        L.keep = -1 if self.truncate_to is None else int(self.truncate_to)
+        if d["dirs"] is not table_dirs or len(table_dirs) != L.n_table_dirs:
+            d["dirs"] = table_dirs
+            d["dirs_arr"] = (ctypes.c_char_p * max(1, len(table_dirs)))(*[os.fsencode(p_) for p_ in table_dirs])
+            L.table_dirs, L.n_table_dirs = d["dirs_arr"], len(table_dirs)
+        if d["pk"] is not pair_keys:
+            d["pk"], d["ps"] = pair_keys, pair_slots
+            L.pair_keys, L.pair_slots, L.pair_cap = pair_keys.ctypes.data, pair_slots.ctypes.data, int(pair_keys.shape[0])
+        if d["free_ver"] != self._free_ver or L.n_free != d["free_n"] or (L.n_free < 16 and len(self._free) > L.n_free):
+            top = self._free[-self._LOADER_FREE:]
+            d["free"][:len(top)] = top                           # (stack order: the library pops from the end, as _take_slots does)
+            L.n_free = d["free_n"] = len(top)
+            d["free_ver"] = self._free_ver
+
+    def adopt_loaded(self, d, key_of) -> int:
+        """Book what ``ss_ctx_observe_requests_load`` loaded (loader dict `d`): entries leave the free list and are bound to
+        `key_of(pair_key)` exactly as ``load_files`` binds them.  Returns the number of rows adopted."""
+        L = d["s"]
+        k = int(L.n_loaded)
+        if k == 0:
+            return 0
+        slots = d["loaded_slot"][:k].tolist()
+        assert self._free[-k:][::-1] == slots, "the library pops the free stack from its end"
+        del self._free[-k:]
+        d["free_n"] = int(L.n_free)
+        for key, sl in zip(d["loaded_key"][:k].tolist(), slots):
+            self._bind(key_of(key), sl)
+        sl_np = np.asarray(slots)
+        self._dev_len[sl_np] = self.host_len[sl_np]              # (host_len / _clipped / _stale were written by the library)
+        self.misses += k
+        L.n_loaded = 0
+        return k
 
     def touch_slots(self, slots: np.ndarray) -> None:
         """Column paths (``DeferredResolver``, tables of ``RirIndex``) look slots up without going through ``slot()``: this
@@ -1405,9 +1490,11 @@ class AudioEngine:
             self._ctx_bank = (bank.data, bank.spectra)
         return ctx
 
-    def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None) -> int:
+    def observe_requests(self, recs: bytes, n: int, tables, spectrogram_out=None, audiogoal_out=None, loader=None) -> int:
         """One step from the packed request records of ``ss_amd.deferred`` (``ss_ctx_observe_requests``: lookups + planner +
-        launch in one C call).  Returns the number of unresolved requests (0: the step is on the stream)."""
+        launch in one C call).  Returns the number of unresolved requests (0: the step is on the stream).  `loader` (a
+        ``RirStore.miss_loader`` dict): poses that are not resident are loaded inside the same call when the library's fast
+        path covers them (``ss_ctx_observe_requests_load``); the caller then books them (``RirStore.adopt_loaded``)."""
         ctx = self._sync_context_bank(n, getattr(self, "_req_has_distractor", True))
         if getattr(self, "_req_miss", None) is None or self._req_miss["buf"].shape[0] < n:
             import ctypes
@@ -1417,10 +1504,14 @@ class AudioEngine:
         stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
         sg = None if spectrogram_out is None else spectrogram_out.data_ptr()
         ag = None if audiogoal_out is None else audiogoal_out.data_ptr()
+        if loader is not None:
+            call = lambda: ctx.observe_requests_load(recs, n, tables, loader, sg, ag, stream, self._req_miss)   # noqa: E731
+        else:
+            call = lambda: ctx.observe_requests(recs, n, tables, sg, ag, stream, self._req_miss)                # noqa: E731
         if torch.cuda.current_device() == (dev.index or 0):
-            return ctx.observe_requests(recs, n, tables, sg, ag, stream, self._req_miss)
+            return call()
         with torch.cuda.device(dev):
-            return ctx.observe_requests(recs, n, tables, sg, ag, stream, self._req_miss)
+            return call()
 
     def observe_columns(self, cols: Dict[str, np.ndarray], spectrogram_out=None, audiogoal_out=None) -> None:
         """One step from unit columns {sound, t0, rir[, dis_sound, dis_rir, last_rir, wrap, last_wrap]} (numpy, one entry

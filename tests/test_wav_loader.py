@@ -298,3 +298,93 @@ def test_the_reader_pool_survives_fork(wavs):
     assert not pr.is_alive(), "the forked child hung in the reader pool"
     kept, status, diff = q.get(timeout=5)
     assert status == [_lib.WAV_OK] * 4 and diff == 0.0 and kept[0] == 16000
+
+
+@pytest.mark.gpu
+def test_pose_misses_are_served_inside_the_step_s_call(tmp_path):
+    """Round 6 (ss_ctx_observe_requests_load): a deferred-mode step that meets poses whose RIR file is not resident is ONE C call -
+    file names built, files read by the library's reader into the store's pinned block, one scatter launch into free entries, the
+    resident-pair arrays extended in place, the step launched - and the store's / resolver's own tables follow from the report.
+    Against the three-call path (report -> load_files -> call again) and the oracle: same observations; what the fast path does
+    not cover (a full store: eviction is the store's policy; an int16 file: scipy's semantics) falls back and still agrees."""
+    import pickle
+    import types
+    import torch
+    from oracle import ss_oracle as O
+    from ss_amd.deferred import DeferredResolver, attach_deferred
+    from ss_amd.renderer import AudioEngine
+    NS = types.SimpleNamespace
+    sr, n_nodes, n_env = 16000, 6, 8
+    rng = np.random.default_rng(11)
+    root = tmp_path / "rirs"
+    rirs = {}
+    for az in (0, 90):
+        (root / str(az)).mkdir(parents=True)
+        for r in range(n_nodes):
+            for s_ in range(n_nodes):
+                L = int(rng.integers(2000, 16001))
+                h = O.synth_rir(np.random.default_rng(100 * az + 10 * r + s_), sr, length=L, n=1)[0]
+                p = str(root / str(az) / f"{r}_{s_}.wav")
+                if (az, r, s_) == (90, 5, 5):                    # one file scipy reads but the library's reader hands back
+                    wavfile.write(p, sr, (h.T * 20000).astype(np.int16))
+                    rirs[p] = (h.T * 20000).astype(np.int16).astype(np.float32)
+                else:
+                    wavfile.write(p, sr, np.ascontiguousarray(h.T))
+                    rirs[p] = np.ascontiguousarray(h.T)
+    clip = O.synth_sources(np.random.default_rng(5), sr, k=1)[0]
+
+    class Sim:
+        config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, HAS_DISTRACTOR_SOUND=False), USE_RENDERED_OBSERVATIONS=True)
+        binaural_rir_dir = str(root)
+        _source_sound_dict = {"s.wav": clip}
+        _current_sound, _audio_index, _episode_step_count, _duration = "s.wav", 0, 0, 500
+        _receiver_position_index = _source_position_index = 0
+        azimuth_angle = 0
+        current_source_sound = property(lambda self: clip)
+        _audio_length = 1
+
+    def run(in_call, slots):
+        sims = [Sim() for _ in range(n_env)]
+        for i, sm in enumerate(sims):
+            attach_deferred(sm, env_rank=i)
+        res = DeferredResolver(AudioEngine(sr, device="cuda:0", rir_slots=slots), fast=True, prefetch_azimuths=False)
+        res.native_miss_path = in_call
+        outs = []
+        walk = np.random.default_rng(3)
+        for k in range(6):
+            for sm in sims:
+                sm._receiver_position_index, sm._source_position_index = int(walk.integers(0, n_nodes)), int(walk.integers(0, n_nodes))
+                sm.azimuth_angle = int(walk.choice([0, 90]))
+                sm._episode_step_count += 1
+            if k == 4:
+                sims[0]._receiver_position_index = sims[0]._source_position_index = 5
+                sims[0].azimuth_angle = 90                       # the int16 file
+            reqs = [pickle.loads(pickle.dumps(sm.get_current_spectrogram_observation(None))) for sm in sims]
+            out = res.resolve(reqs, want_audiogoal=True)
+            torch.cuda.synchronize()
+            outs.append((out["audiogoal"].cpu().numpy(), out["spectrogram"].cpu().numpy(),
+                         [os.path.join(str(root), str(sm.azimuth_angle), f"{sm._receiver_position_index}_{sm._source_position_index}.wav") for sm in sims]))
+        return res, outs
+
+    res_a, a = run(True, 256)
+    res_b, b = run(False, 256)
+    assert res_a.library_loaded >= 20 and res_b.library_loaded == 0
+    store = res_a.engine.store
+    assert len(store._slot_of) == store.misses and len(store._free) == store.slots - len(store._slot_of)
+    for (key, slot) in store._slot_of.items():                   # the store's books agree with what the library wrote
+        assert key[0] == "ix" and store._key_at[slot] == key and store._used[slot]
+        k = key[1]
+        path = os.path.join(res_a._table_dirs[k >> 40], f"{(k >> 20) & 0xFFFFF}_{k & 0xFFFFF}.wav")
+        assert int(store.host_len[slot]) == min(rirs[path].shape[0], 16000)
+        assert int(res_a._pair_slots[np.searchsorted(res_a._pair_keys, k)]) == slot
+    assert np.all(np.diff(res_a._pair_keys) > 0)
+    for (ag1, sg1, paths), (ag2, sg2, _) in zip(a, b):
+        np.testing.assert_array_equal(ag1, ag2)
+        np.testing.assert_array_equal(sg1, sg2)
+        for i, pth in enumerate(paths):
+            ref = O.compute_audiogoal(clip, rirs[pth], sr)
+            assert O.relerr(ag1[i], ref) < 1e-4 and O.relerr(sg1[i], O.compute_spectrogram(ref.astype(np.float32))) < 1e-4
+    res_c, c = run(True, 10)                                     # 10 entries for up to 8 new poses per step: evictions -> the store's own path
+    assert res_c.engine.store.misses > 10
+    for (ag1, sg1, _), (ag3, sg3, _) in zip(a, c):
+        np.testing.assert_array_equal(ag1, ag3)
