@@ -374,7 +374,7 @@ int ss_ctx_observe_requests(ss_ctx* ctx, const long long* recs, int n, const ss_
  * launched.  What was loaded is reported (loaded_key / loaded_slot / loaded_frames, n_loaded) so that the caller's own tables
  * (key -> entry dictionaries, LRU order) follow; n_free and *n_pairs are updated.  Anything the fast path does not cover - an
  * unknown sound or directory, a stale row, no free entry left (eviction is the caller's policy), a file that is not a plain
- * float32 stereo wav / is missing / does not fit the rows, a launch that would read the spectral rows - changes NOTHING and is
+ * float32 stereo wav / is missing / does not fit the rows, a launch that reads the spectral rows without `stage_desc` - changes NOTHING and is
  * reported exactly as ss_ctx_observe_requests reports it (miss_out, *n_miss > 0).  Arrays are HOST memory unless said
  * otherwise; `stage`, `stage_slot`, `stage_len` must be pinned (the scatter kernel reads them over the host link) and stay
  * untouched by the caller until the stream has run the launch (the library waits for its own previous use of them). */
@@ -397,6 +397,9 @@ typedef struct ss_miss_loader {
     float* stage;                    /* PINNED: stage_rows rows of 2 * cap floats (wav layout)                                   */
     int* stage_slot;                 /* PINNED [stage_rows]                                                                      */
     int* stage_len;                  /* PINNED [stage_rows]                                                                      */
+    int* stage_desc;                 /* optional, PINNED [stage_rows * 2 * ceil(cap / kB) * 5]: window descriptors of the new rows'
+                                      * block spectra - with it, steps that read the SPECTRAL rows (ss_ctx_set_rir_spectra) are
+                                      * served too: the new rows are transformed right behind the scatter                        */
     int stage_rows, threads;
     long long* loaded_key;           /* report, capacity loaded_cap: pair key, ...                                               */
     int* loaded_slot;                /* ... the entry it went to, ...                                                            */

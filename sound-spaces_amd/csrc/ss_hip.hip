@@ -1528,8 +1528,10 @@ int ss_ctx_observe_requests(ss_ctx* h, const long long* recs, int n, const ss_re
 
 // The miss path inside the call (include/ss_hip.h: ss_miss_loader).  Returns 1 = "not for the fast path" (nothing was changed).
 static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, const int* miss,
-                             int n_miss, hipStream_t st) {
+                             int n_miss, hipStream_t st, bool spectral) {
     ssctx::Context& c = h->c;
+    const int hb = (ld && ld->cap > 0) ? (ld->cap + ssk::kB - 1) / ssk::kB : 1;
+    if (spectral && (!ld || !ld->stage_desc || c.h_blocks != hb)) return 1;
     if (!ld || !ld->table_dirs || !ld->pair_keys || !ld->pair_slots || !ld->free_slots || !ld->bank || !ld->dev_len ||
         !ld->host_len || !ld->clipped || !ld->stage || !ld->stage_slot || !ld->stage_len || !ld->loaded_key || !ld->loaded_slot ||
         !ld->loaded_frames || ld->cap < 2 || (ld->cap & 1) || tb->pair_keys != ld->pair_keys || tb->pair_slots != ld->pair_slots)
@@ -1559,6 +1561,10 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     const int k = static_cast<int>(keys.size());
     if (k == 0 || k > ld->n_free || k > ld->stage_rows || k > ld->loaded_cap || tb->n_pairs + k > ld->pair_cap) return 1;
+    if (spectral) {                                            // (window offsets are int32 words from the bank's base)
+        for (int i = 0; i < k; ++i)
+            if ((static_cast<long long>(ld->free_slots[ld->n_free - 1 - i]) + 1) * ld->bank_unit_stride >= (1LL << 31)) return 1;
+    }
     if (c.miss_ev) {                                           // the staging block's previous scatter has run
         if (hipEventSynchronize(static_cast<hipEvent_t>(c.miss_ev)) != hipSuccess) return 1;
     } else {
@@ -1593,6 +1599,34 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
     ld->n_loaded = k;
     int rc = ss_bank_scatter_rows_f32(ld->stage, 2LL * ld->cap, ld->stage_slot, ld->stage_len, k, ld->bank, ld->bank_unit_stride,
                                       ld->bank_chan_stride, ld->cap, ld->dev_len, st);
+    if (rc == 0 && spectral) {
+        // the new rows' block spectra H'_i = 2 rFFT(block i), straight into the spectral bank (scatter form of k_source_windows;
+        // the descriptors are read from the pinned block in place)
+        int w = 0;
+        for (int i = 0; i < k; ++i)
+            for (int ch = 0; ch < 2; ++ch)
+                for (int b = 0; b < hb; ++b, ++w) {
+                    const int slot = ld->stage_slot[i], left = ld->cap - b * ssk::kB;
+                    int* d = ld->stage_desc + 5 * w;
+                    d[0] = static_cast<int>(slot * ld->bank_unit_stride + static_cast<long long>(ch) * ld->bank_chan_stride + static_cast<long long>(b) * ssk::kB);
+                    d[1] = left < ssk::kB ? left : ssk::kB;
+                    d[2] = 0; d[3] = 0;
+                    d[4] = (slot * 2 + ch) * hb + b;
+                }
+        ssk::SrcParams sp;
+        rc = get_tables(&sp.tb);
+        if (rc == 0) {
+            sp.src = ld->bank;
+            sp.desc = ld->stage_desc;
+            sp.spec = reinterpret_cast<ssk::f32x4*>(const_cast<float*>(c.hspec));
+            sp.desc_stride = 5;
+            sp.scale = 1.0f;
+            hipLaunchKernelGGL(ssk::k_source_windows, dim3(w), dim3(ssk::kT), 0, st, sp);
+            rc = hip_err(hipGetLastError());
+        }
+        if (rc == 0 && ld->spec_stale)
+            for (int i = 0; i < k; ++i) ld->spec_stale[ld->stage_slot[i]] = 0;
+    }
     if (rc == 0) rc = hip_err(hipEventRecord(static_cast<hipEvent_t>(c.miss_ev), st));
     // the sorted pair arrays, in place (keys ascending: merged from the back)
     {
@@ -1617,13 +1651,13 @@ int ss_ctx_observe_requests_load(ss_ctx* h, const long long* recs, int n, ss_req
     if (rc != 0 || n == 0) return rc;
     if (*n_miss) {
         ssctx::Context& c = h->c;
-        // a launch that reads the SPECTRAL rows needs the new rows' block spectra first: the caller's path
+        // a launch that reads the SPECTRAL rows needs the new rows' block spectra first (built behind the scatter)
         bool any_dis = false;
         for (int i = 0; i < n && !any_dis; ++i) any_dis = recs[static_cast<size_t>(i) * SS_REQ_WORDS] == 0 && recs[static_cast<size_t>(i) * SS_REQ_WORDS + 6] >= 0;
         const bool spectral = c.hspec && !(c.spectral_max_units > 0 && c.rir && c.out_len <= ssk::kB && n > c.spectral_max_units && !any_dis);
-        if (!ld || !miss_out || spectral || c.rir != ld->bank) return 0;
+        if (!ld || !miss_out || c.rir != ld->bank) return 0;
         std::vector<int> miss(miss_out, miss_out + (*n_miss < n ? *n_miss : n));
-        rc = serve_pose_misses(h, recs, n, tb, ld, miss.data(), static_cast<int>(miss.size()), static_cast<hipStream_t>(stream));
+        rc = serve_pose_misses(h, recs, n, tb, ld, miss.data(), static_cast<int>(miss.size()), static_cast<hipStream_t>(stream), spectral);
         if (rc == 1) return 0;                                 // reported as ss_ctx_observe_requests reports it
         if (rc) return rc;
         rc = requests_to_units(h, recs, n, tb, w.data(), miss_out, n_miss);

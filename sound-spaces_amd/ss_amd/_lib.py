@@ -34,7 +34,7 @@ class SsMissLoader(ctypes.Structure):
                 ("cap", ctypes.c_int), ("dev_len", ctypes.c_void_p), ("host_len", ctypes.c_void_p), ("clipped", ctypes.c_void_p),
                 ("spec_stale", ctypes.c_void_p), ("keep", ctypes.c_int),
                 ("stage", ctypes.c_void_p), ("stage_slot", ctypes.c_void_p), ("stage_len", ctypes.c_void_p),
-                ("stage_rows", ctypes.c_int), ("threads", ctypes.c_int),
+                ("stage_desc", ctypes.c_void_p), ("stage_rows", ctypes.c_int), ("threads", ctypes.c_int),
                 ("loaded_key", ctypes.c_void_p), ("loaded_slot", ctypes.c_void_p), ("loaded_frames", ctypes.c_void_p),
                 ("n_loaded", ctypes.c_int), ("loaded_cap", ctypes.c_int)]
 

@@ -854,6 +854,8 @@ class RirStore:
                     torch.cuda.synchronize(self.device)          # (a scatter may still be reading the old block)
                 d["stage"] = torch.zeros((L.stage_rows, self.cap, 2), dtype=torch.float32, pin_memory=True)
                 L.stage = d["stage"].data_ptr()
+                d["stage_desc"] = torch.zeros((L.stage_rows * 2 * P.ceil_div(self.cap, P.KB) * 5,), dtype=torch.int32, pin_memory=True)
+                L.stage_desc = d["stage_desc"].data_ptr() if self.spectral else None
             d["bank"], d["cap"] = bank.data, self.cap
             L.bank, L.bank_unit_stride, L.bank_chan_stride, L.cap = bank.data.data_ptr(), bank.data.stride(0), bank.data.stride(1), self.cap
             L.dev_len = bank.lengths.data_ptr()
