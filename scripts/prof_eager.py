@@ -98,3 +98,39 @@ for _ in range(2000):
     call()
 pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28); print(s.getvalue()[:6000])
+
+
+# ---- an agent that MOVES: every call meets a pose whose RIR file is not resident (simulator.py:615-618 reads the file on every
+# cache-missing step).  Real float32 wav files on tmpfs, the stock reader: the library's reader against scipy (a wrapper is not
+# "the stock reader"), same box, alternating.
+import shutil, tempfile
+from scipy.io import wavfile
+from ss_amd.sim_audio import wav_rir_reader
+td = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+n_nodes = 24
+for az in (0, 90, 180, 270):
+    os.makedirs(os.path.join(td, str(az)))
+    for r in range(n_nodes):
+        for s_ in range(n_nodes):
+            wavfile.write(os.path.join(td, str(az), "%d_%d.wav" % (r, s_)), sr, rng.standard_normal((sr, 2)).astype(np.float32) * 0.05)
+for rep in range(2):
+    for name, reader in (("library reader", wav_rir_reader), ("scipy", lambda p_: wav_rir_reader(p_))):
+        eng3 = AudioEngine(sr, device="cuda:0", rir_slots=4 * n_nodes * n_nodes)
+        sim3 = Sim()
+        sim3.binaural_rir_dir = td
+        sim_audio.attach(sim3, eng3, rir_reader=reader)
+        sen3 = sensors.SpectrogramSensor(sim=sim3, config=NS())
+        poses = [(r, s_, az) for az in (0, 90, 180, 270) for r in range(n_nodes) for s_ in range(n_nodes)]
+        rng.shuffle(poses)
+
+        def call3(pose):
+            sim3._receiver_position_index, sim3._source_position_index, sim3.azimuth_angle = pose
+            sim3._spectrogram_cache.clear(); sim3._audiogoal_cache.clear()
+            return sen3.get_observation(observations=None, episode=None)
+        for pose in poses[:200]:
+            call3(pose)
+        t0 = time.perf_counter()
+        for pose in poses[200:2200]:
+            call3(pose)
+        print("eager, every call a NEW pose (file -> HBM -> observation), %s: %.1f us per call" % (name, 1e6 * (time.perf_counter() - t0) / 2000))
+shutil.rmtree(td, ignore_errors=True)

@@ -1405,6 +1405,7 @@ class AudioEngine:
         units read the time-domain rows, whose forward FFT hides under the rows' loads there (+-2 us per 128 envs at half the
         bytes).  An explicit rir_spectral=True keeps r5's meaning: the spectral rows for every launch."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
+        self._native_readers: Dict[int, tuple] = {}              # rir_file_slot: id(reader) -> (stock wav reader?, lenient?, reader)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
         self.spectral_max_units = 0
         if rir_spectral is None:
@@ -1526,6 +1527,24 @@ class AudioEngine:
 
     def rir_slot(self, key, loader, refresh: bool = False) -> int:
         return self.store.slot(key, loader, refresh)
+
+    def rir_file_slot(self, path: str, reader) -> int:
+        """Bank entry of the RIR FILE `path` (keyed by the path, as ``rir_slot(path, ...)``).  A file that is not resident is read by
+        the library's own reader when `reader` is the stock wav reader (``RirStore.load_files``: header parsed in C++, the frames
+        read() straight into a pinned block, one scatter launch; anything unusual goes through `reader`, i.e. scipy with the
+        reference's ValueError -> zero-RIR fallback, simulator.py:617-624) instead of scipy + a host transpose + a row upload: what
+        an eager call pays on EVERY step of an agent that moves (simulator.py:615-618 reads the file on every cache-missing step)."""
+        store = self.store
+        if path in store._slot_of or getattr(store, "group", 1) != 1 or not hasattr(store, "load_files"):
+            return store.slot(path, lambda: reader(path))
+        native = self._native_readers.get(id(reader))
+        if native is None:
+            import functools
+            native = self._native_readers[id(reader)] = (_native_wav(reader), isinstance(reader, functools.partial) and
+                                                         bool(reader.keywords.get("lenient")), reader)
+        if not native[0]:
+            return store.slot(path, lambda: reader(path))
+        return store.load_files([path], [path], reader=reader, missing_ok=native[1], new_batch=False)[0]
 
     def rir_len(self, slot: int) -> int:
         return int(self.store.host_len[slot])

@@ -157,6 +157,9 @@ class HipSimAudio:
                     self._paths.clear()
                 path = self._paths[key] = os.path.join(key[0], str(key[1]), "{}_{}.wav".format(key[2], source_index))  # :615-616, :650-651
             self._refs.append(path)
+            file_slot = getattr(self.engine, "rir_file_slot", None)
+            if file_slot is not None:                        # (misses of the stock reader: the library's own wav reader)
+                return file_slot(path, self.rir_reader)
             return self.engine.rir_slot(path, lambda: self.rir_reader(path))
         # habitat_sim audio sensor: a fresh RIR every step (:626) -> this env's live slot, re-uploaded.  The key is a
         # counter drawn at attach time: id(sim) can be handed to another simulator once this one is collected
@@ -170,7 +173,8 @@ class HipSimAudio:
         RIRs again from what they WERE: the file paths / the live RIR array of the step the request was made in."""
         def slot(ref):
             if isinstance(ref, str):
-                return self.engine.rir_slot(ref, lambda: self.rir_reader(ref))
+                file_slot = getattr(self.engine, "rir_file_slot", None)
+                return file_slot(ref, self.rir_reader) if file_slot is not None else self.engine.rir_slot(ref, lambda: self.rir_reader(ref))
             return self.engine.rir_slot(("live", self._env_id), lambda: ref, refresh=True)
         if refs:
             req.rir = slot(refs[0])

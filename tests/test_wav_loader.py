@@ -388,3 +388,50 @@ def test_pose_misses_are_served_inside_the_step_s_call(tmp_path):
     assert res_c.engine.store.misses > 10
     for (ag1, sg1, _), (ag3, sg3, _) in zip(a, c):
         np.testing.assert_array_equal(ag1, ag3)
+
+
+@pytest.mark.gpu
+def test_eager_calls_read_new_poses_with_the_library_s_reader(wavs, tmp_path):
+    """``attach()`` with the stock reader: a pose whose file is not resident goes through ``AudioEngine.rir_file_slot`` ->
+    ``RirStore.load_files`` (the library's reader + one scatter launch) instead of scipy + a row upload; reference semantics file by
+    file (simulator.py:615-624): float32 files as they are, an int16 file through scipy, an empty / a junk file = the zero RIR."""
+    import shutil
+    import types
+    from oracle import ss_oracle as O
+    from ss_amd import sensors, sim_audio
+    from ss_amd.renderer import AudioEngine
+    NS = types.SimpleNamespace
+    sr = 16000
+    root = tmp_path / "scene"
+    names = {(0, 1, 2): "a", (0, 3, 4): "ragged", (90, 1, 2): "i16", (90, 3, 4): "empty", (180, 1, 2): "junk", (180, 3, 4): "tiny"}
+    for (az, r, s_), n in names.items():
+        os.makedirs(root / str(az), exist_ok=True)
+        shutil.copy(wavs[n], root / str(az) / f"{r}_{s_}.wav")
+    clip = O.synth_sources(np.random.default_rng(2), sr, k=1)[0]
+
+    class Sim:
+        config = NS(AUDIO=NS(RIR_SAMPLING_RATE=sr, HAS_DISTRACTOR_SOUND=False), USE_RENDERED_OBSERVATIONS=True)
+        binaural_rir_dir = str(root)
+        _source_sound_dict = {"s.wav": clip}
+        _current_sound, _audio_index, _episode_step_count, _duration = "s.wav", 0, 0, 500
+        current_source_sound = property(lambda self: clip)
+        _audio_length = 1
+    sim = Sim()
+    eng = AudioEngine(sr, device="cuda:0", rir_slots=16)
+    sim_audio.attach(sim, eng, lazy_audiogoal=False)
+    ag_s, sg_s = sensors.AudioGoalSensor(sim=sim, config=NS()), sensors.SpectrogramSensor(sim=sim, config=NS())
+    for (az, r, s_), n in names.items():
+        sim.azimuth_angle, sim._receiver_position_index, sim._source_position_index = az, r, s_
+        sg = sg_s.get_observation(observations=None, episode=None)
+        ag = ag_s.get_observation(observations=None, episode=None)
+        h = wav_rir_reader(wavs[n])
+        if h is None or not np.size(h):
+            assert not ag.any() and not sg.any(), n
+            continue
+        ref = O.compute_audiogoal(clip, np.asarray(h, np.float32), sr)
+        assert O.relerr(ag, ref) < 1e-4 and O.relerr(sg, O.compute_spectrogram(ref.astype(np.float32))) < 1e-4, n
+    assert eng.store.misses == len(names) and len(eng.store._slot_of) == len(names)
+    sim.azimuth_angle, sim._receiver_position_index, sim._source_position_index = 0, 1, 2      # a pose seen before: a hit
+    sim._spectrogram_cache.clear(); sim._audiogoal_cache.clear()
+    sg_s.get_observation(observations=None, episode=None)
+    assert eng.store.misses == len(names)
