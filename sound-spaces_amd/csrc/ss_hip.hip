@@ -724,12 +724,67 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
 
 
 // ---- spectral RIR bank ---------------------------------------------------------------------------------------------
+}  // extern "C"
+// ss_rir_spectra_f32 for a handful of rows: pinned descriptor blocks (per device), reused behind an event
+constexpr int kSmallSpectraWindows = 256;
+struct SmallSpectraRing {
+    static constexpr int kSlots = 8;
+    struct Slot { int* desc = nullptr; hipEvent_t ev = nullptr; } slot[kSlots];
+    unsigned next = 0;
+};
+static std::mutex g_small_mu;
+static std::map<int, SmallSpectraRing> g_small_ring;
+extern "C" {
+
 int ss_rir_spectra_f32(const float* rir, float* hspec_out, int n_entries, long long rir_unit_stride, int rir_chan_stride,
                        int rir_cap, void* stream) {
     if (n_entries == 0) return 0;
     if (!rir || !hspec_out || n_entries < 0 || rir_cap <= 0 || rir_unit_stride < 0 || rir_chan_stride < 0) return SS_EINVAL;
     const int hb = (rir_cap + ssk::kB - 1) / ssk::kB;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // A HANDFUL of rows (a step's new poses, an eager call's one): descriptors in a small ring of pinned blocks the kernel reads
+    // in place - no allocation, no copy, no synchronisation (the general path below does all three per call: ~60 us for one row,
+    // which is what an eager call at a new pose paid on top of its file read).  A block is reused after its event has passed.
+    if (static_cast<long long>(n_entries) * 2 * hb <= kSmallSpectraWindows &&
+        static_cast<long long>(n_entries) * rir_unit_stride < (1LL << 31)) {
+        int dev = 0;
+        hipError_t e0 = hipGetDevice(&dev);
+        if (e0 != hipSuccess) return hip_err(e0);
+        std::lock_guard<std::mutex> lk(g_small_mu);
+        SmallSpectraRing& ring = g_small_ring[dev];
+        SmallSpectraRing::Slot& sl = ring.slot[ring.next++ % SmallSpectraRing::kSlots];
+        if (!sl.desc) {
+            e0 = hipHostMalloc(reinterpret_cast<void**>(&sl.desc), sizeof(int) * 4 * kSmallSpectraWindows, hipHostMallocDefault);
+            if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+            if (e0 != hipSuccess) { sl.desc = nullptr; (void)hipGetLastError(); }
+        } else {
+            e0 = hipEventSynchronize(sl.ev);
+        }
+        if (sl.desc && e0 == hipSuccess) {
+            int w = 0;
+            for (int r = 0; r < n_entries; ++r)
+                for (int c = 0; c < 2; ++c)
+                    for (int i = 0; i < hb; ++i, ++w) {
+                        const int left = rir_cap - i * ssk::kB;
+                        sl.desc[4 * w + 0] = static_cast<int>(r * rir_unit_stride + (long long)c * rir_chan_stride + (long long)i * ssk::kB);
+                        sl.desc[4 * w + 1] = left < ssk::kB ? left : ssk::kB;
+                        sl.desc[4 * w + 2] = 0;
+                        sl.desc[4 * w + 3] = 0;
+                    }
+            ssk::SrcParams p;
+            int rc = get_tables(&p.tb);
+            if (rc) return rc;
+            p.src = rir;
+            p.desc = sl.desc;
+            p.spec = reinterpret_cast<ssk::f32x4*>(hspec_out);
+            p.desc_stride = 4;
+            p.scale = 1.0f;
+            hipLaunchKernelGGL(ssk::k_source_windows, dim3(w), dim3(ssk::kT), 0, st, p);
+            rc = hip_err(hipGetLastError());
+            if (rc == 0) rc = hip_err(hipEventRecord(sl.ev, st));
+            return rc;
+        }
+    }
     // window offsets are int32 words relative to a base pointer: walk the bank in chunks that keep them below 2^31
     long long per = (rir_unit_stride > 0) ? ((1LL << 30) / rir_unit_stride) : n_entries;
     if (per < 1) return SS_EINVAL;
