@@ -373,7 +373,8 @@ int ss_ctx_observe_requests(ss_ctx* ctx, const long long* recs, int n, const ss_
  * straight into the staging block, one scatter launch into the free entries, the pair arrays extended in place, the step
  * launched.  What was loaded is reported (loaded_key / loaded_slot / loaded_frames, n_loaded) so that the caller's own tables
  * (key -> entry dictionaries, LRU order) follow; n_free and *n_pairs are updated.  Anything the fast path does not cover - an
- * unknown sound or directory, a stale row, no free entry left (eviction is the caller's policy), a file that is not a plain
+ * unknown sound or directory, a stale row, no entry to be had (stack empty and no eviction arrays lent, or every occupied entry
+ * in use by this very step), a file that is not a plain
  * float32 stereo wav / is missing / does not fit the rows, a launch that reads the spectral rows without `stage_desc` - changes NOTHING and is
  * reported exactly as ss_ctx_observe_requests reports it (miss_out, *n_miss > 0).  Arrays are HOST memory unless said
  * otherwise; `stage`, `stage_slot`, `stage_len` must be pinned (the scatter kernel reads them over the host link) and stay
@@ -401,6 +402,14 @@ typedef struct ss_miss_loader {
                                       * block spectra - with it, steps that read the SPECTRAL rows (ss_ctx_set_rir_spectra) are
                                       * served too: the new rows are transformed right behind the scatter                        */
     int stage_rows, threads;
+    /* optional: eviction inside the call.  When the step needs more entries than the stack holds, the least recently used
+     * occupied entries are reused - recency = ss_request_tables.last_used (entries stamped with the step's own tick are never
+     * taken), ties by use_seq, oldest first: the policy of RirStore._take_slots.  Their pairs leave pair_keys / pair_slots in
+     * the call; evicted_slot names them so that the caller drops its own records of the keys they held.  NULL: no eviction. */
+    const unsigned char* used;       /* [n_slots of ss_request_tables]: 1 = the entry is occupied                                */
+    const long long* use_seq;        /* [n_slots]: order of last use through the caller's own lookups                            */
+    int* evicted_slot;               /* report, capacity evict_cap                                                               */
+    int n_evicted, evict_cap;
     long long* loaded_key;           /* report, capacity loaded_cap: pair key, ...                                               */
     int* loaded_slot;                /* ... the entry it went to, ...                                                            */
     int* loaded_frames;              /* ... frames in its file (kept = min(frames, keep))                                        */

@@ -1615,10 +1615,28 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
     std::sort(keys.begin(), keys.end());
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     const int k = static_cast<int>(keys.size());
-    if (k == 0 || k > ld->n_free || k > ld->stage_rows || k > ld->loaded_cap || tb->n_pairs + k > ld->pair_cap) return 1;
+    if (k == 0 || k > ld->stage_rows || k > ld->loaded_cap || tb->n_pairs + k > ld->pair_cap) return 1;
+    // entries: free ones first, then - if the caller lent its recency arrays - the least recently used occupied ones
+    std::vector<int> victims;
+    if (k > ld->n_free) {
+        const int r = k - ld->n_free;
+        if (!ld->used || !ld->use_seq || !ld->evicted_slot || !tb->last_used || r > ld->evict_cap) return 1;
+        std::vector<int> cand;
+        for (int sl = 0; sl < tb->n_slots; ++sl)
+            if (ld->used[sl] && tb->last_used[sl] < tb->tick) cand.push_back(sl);     // (never a row this step resolves to)
+        if (static_cast<int>(cand.size()) < r) return 1;       // the caller's own path raises its "store too small" there
+        auto older = [&](int a, int b) {
+            return tb->last_used[a] != tb->last_used[b] ? tb->last_used[a] < tb->last_used[b] : ld->use_seq[a] < ld->use_seq[b];
+        };
+        std::partial_sort(cand.begin(), cand.begin() + r, cand.end(), older);
+        victims.assign(cand.begin(), cand.begin() + r);
+    }
+    std::vector<int> take(k);                                  // the entries the k new rows go to, in order
+    for (int i = 0; i < k; ++i)
+        take[i] = i < ld->n_free ? ld->free_slots[ld->n_free - 1 - i] : victims[i - ld->n_free];
     if (spectral) {                                            // (window offsets are int32 words from the bank's base)
         for (int i = 0; i < k; ++i)
-            if ((static_cast<long long>(ld->free_slots[ld->n_free - 1 - i]) + 1) * ld->bank_unit_stride >= (1LL << 31)) return 1;
+            if ((static_cast<long long>(take[i]) + 1) * ld->bank_unit_stride >= (1LL << 31)) return 1;
     }
     if (c.miss_ev) {                                           // the staging block's previous scatter has run
         if (hipEventSynchronize(static_cast<hipEvent_t>(c.miss_ev)) != hipSuccess) return 1;
@@ -1641,8 +1659,23 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
     for (int i = 0; i < k; ++i)
         if (status[i] != sswav::kOk && status[i] != sswav::kEmpty) return 1;     // scipy's semantics are the caller's reader's
     // ---- commit
+    if (!victims.empty()) {                                    // their pairs leave the sorted arrays (one compacting pass)
+        std::vector<char> gone(static_cast<size_t>(tb->n_slots), 0);
+        for (int v : victims) gone[v] = 1;
+        int o = 0;
+        for (int i = 0; i < tb->n_pairs; ++i) {
+            const long long sl = ld->pair_slots[i];
+            if (sl >= 0 && sl < tb->n_slots && gone[sl]) continue;
+            ld->pair_keys[o] = ld->pair_keys[i]; ld->pair_slots[o] = ld->pair_slots[i]; ++o;
+        }
+        tb->n_pairs = o;
+        for (size_t i = 0; i < victims.size(); ++i) ld->evicted_slot[i] = victims[i];
+        ld->n_evicted = static_cast<int>(victims.size());
+    }
+    const int from_free = k < ld->n_free ? k : ld->n_free;
+    ld->n_free -= from_free;
     for (int i = 0; i < k; ++i) {
-        const int slot = ld->free_slots[--ld->n_free];
+        const int slot = take[i];
         ld->stage_slot[i] = slot;
         ld->stage_len[i] = kept[i];
         ld->host_len[slot] = kept[i];
@@ -1699,7 +1732,7 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
 int ss_ctx_observe_requests_load(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, float* audiogoal,
                                  float* spectrogram, int* miss_out, int* n_miss, void* stream) {
     if (!h || n < 0 || !tb) return SS_EINVAL;
-    if (ld) ld->n_loaded = 0;
+    if (ld) { ld->n_loaded = 0; ld->n_evicted = 0; }
     std::vector<int>& w = h->c.sim_scratch;
     w.resize(static_cast<size_t>(n) * 5 + 1);
     int rc = requests_to_units(h, recs, n, tb, w.data(), miss_out, n_miss);

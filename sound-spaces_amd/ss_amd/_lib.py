@@ -35,6 +35,8 @@ class SsMissLoader(ctypes.Structure):
                 ("spec_stale", ctypes.c_void_p), ("keep", ctypes.c_int),
                 ("stage", ctypes.c_void_p), ("stage_slot", ctypes.c_void_p), ("stage_len", ctypes.c_void_p),
                 ("stage_desc", ctypes.c_void_p), ("stage_rows", ctypes.c_int), ("threads", ctypes.c_int),
+                ("used", ctypes.c_void_p), ("use_seq", ctypes.c_void_p), ("evicted_slot", ctypes.c_void_p),
+                ("n_evicted", ctypes.c_int), ("evict_cap", ctypes.c_int),
                 ("loaded_key", ctypes.c_void_p), ("loaded_slot", ctypes.c_void_p), ("loaded_frames", ctypes.c_void_p),
                 ("n_loaded", ctypes.c_int), ("loaded_cap", ctypes.c_int)]
 

@@ -765,9 +765,14 @@ class DeferredResolver:
 
     def _adopt_loaded(self) -> None:
         """after a call in which the library loaded poses itself: the store's dictionaries and this resolver's views follow"""
+        tables = self._tables
         k = self.engine.store.adopt_loaded(self._loader, lambda key: ("ix", key))
         if k:
-            n = int(self._tables["t"].n_pairs)
+            # entries the library evicted went through the store's hooks (_evicted: queued + tables dropped) like any other
+            # eviction - but their pairs have ALREADY left the sorted arrays inside the call: nothing to drop, the tables stand
+            self._evq = []
+            self._tables = tables
+            n = int(tables["t"].n_pairs)
             self._pk, self._ps = self._pair_buf[0][:n], self._pair_buf[1][:n]
             self.library_loaded += k
 

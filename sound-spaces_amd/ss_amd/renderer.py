@@ -827,11 +827,13 @@ class RirStore:
         rows = self._LOADER_FREE
         d = dict(s=L, ref=ctypes.byref(L), free=np.zeros((rows,), np.int32), free_ver=-1, free_n=0,
                  loaded_key=np.zeros((rows,), np.int64), loaded_slot=np.zeros((rows,), np.int32), loaded_frames=np.zeros((rows,), np.int32),
+                 evicted=np.zeros((rows,), np.int32),
                  stage_slot=torch.zeros((rows,), **pin), stage_len=torch.zeros((rows,), **pin), stage=None, cap=-1, bank=None,
                  dirs=None, dirs_arr=None, pk=None)
         L.free_slots = d["free"].ctypes.data
         L.loaded_key, L.loaded_slot, L.loaded_frames = (d[k_].ctypes.data for k_ in ("loaded_key", "loaded_slot", "loaded_frames"))
-        L.loaded_cap = L.stage_rows = rows
+        L.loaded_cap = L.stage_rows = L.evict_cap = rows
+        L.evicted_slot = d["evicted"].ctypes.data
         L.stage_slot, L.stage_len = d["stage_slot"].data_ptr(), d["stage_len"].data_ptr()
         L.threads = int(threads) if threads > 0 else min(8, os.cpu_count() or 1)
         self.refresh_loader(d, table_dirs, pair_keys, pair_slots)
@@ -860,6 +862,7 @@ class RirStore:
             L.bank, L.bank_unit_stride, L.bank_chan_stride, L.cap = bank.data.data_ptr(), bank.data.stride(0), bank.data.stride(1), self.cap
             L.dev_len = bank.lengths.data_ptr()
         L.host_len, L.clipped = self.host_len.ctypes.data, self._clipped.ctypes.data
+        L.used, L.use_seq = self._used.ctypes.data, self._use_seq.ctypes.data      # (eviction inside the call: _take_slots' policy)
         L.spec_stale = self._stale.ctypes.data if self.spectral else None
         L.keep = -1 if self.truncate_to is None else int(self.truncate_to)
         if d["dirs"] is not table_dirs or len(table_dirs) != L.n_table_dirs:
@@ -883,8 +886,22 @@ class RirStore:
         if k == 0:
             return 0
         slots = d["loaded_slot"][:k].tolist()
-        assert self._free[-k:][::-1] == slots, "the library pops the free stack from its end"
-        del self._free[-k:]
+        ke = int(L.n_evicted)
+        if ke:                                                   # entries the library reused: their keys leave the store's books
+            tell = self.on_evict is not None or bool(self._evict_hooks)
+            for slot in d["evicted"][:ke].tolist():
+                victim = self._key_at[slot]
+                del self._slot_of[victim]
+                self._key_at[slot] = None
+                self._used[slot] = False
+                self._pending.pop(slot, None)
+                if tell:
+                    self._notify_evict(victim, slot)
+            L.n_evicted = 0
+        kf = k - ke                                              # ... the others came off the free stack
+        if kf:
+            assert self._free[-kf:][::-1] == slots[:kf], "the library pops the free stack from its end"
+            del self._free[-kf:]
         d["free_n"] = int(L.n_free)
         for key, sl in zip(d["loaded_key"][:k].tolist(), slots):
             self._bind(key_of(key), sl)

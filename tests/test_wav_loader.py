@@ -306,7 +306,7 @@ def test_pose_misses_are_served_inside_the_step_s_call(tmp_path):
     file names built, files read by the library's reader into the store's pinned block, one scatter launch into free entries, the
     resident-pair arrays extended in place, the step launched - and the store's / resolver's own tables follow from the report.
     Against the three-call path (report -> load_files -> call again) and the oracle: same observations; what the fast path does
-    not cover (a full store: eviction is the store's policy; an int16 file: scipy's semantics) falls back and still agrees."""
+    not cover (an int16 file: scipy's semantics) falls back and still agrees; a store smaller than the walk evicts inside the call."""
     import pickle
     import types
     import torch
@@ -384,10 +384,16 @@ def test_pose_misses_are_served_inside_the_step_s_call(tmp_path):
         for i, pth in enumerate(paths):
             ref = O.compute_audiogoal(clip, rirs[pth], sr)
             assert O.relerr(ag1[i], ref) < 1e-4 and O.relerr(sg1[i], O.compute_spectrogram(ref.astype(np.float32))) < 1e-4
-    res_c, c = run(True, 10)                                     # 10 entries for up to 8 new poses per step: evictions -> the store's own path
-    assert res_c.engine.store.misses > 10
+    res_c, c = run(True, 10)                                     # 10 entries for up to 8 new poses per step: the library evicts
+    st_c = res_c.engine.store                                    # (least recently used entries that this step does not resolve to)
+    assert st_c.misses > 10 and res_c.library_loaded > 10 and len(st_c._slot_of) <= 10
+    assert sorted(st_c._slot_of.values()) == sorted(np.flatnonzero(st_c._used).tolist())
+    assert sorted(int(v) for v in res_c._pair_slots) == sorted(st_c._slot_of[k_] for k_ in st_c._slot_of if k_[0] == "ix")
     for (ag1, sg1, _), (ag3, sg3, _) in zip(a, c):
         np.testing.assert_array_equal(ag1, ag3)
+    res_d, d = run(False, 10)                                    # ... exactly like the store's own eviction path
+    for (ag1, _, _), (ag4, _, _) in zip(a, d):
+        np.testing.assert_array_equal(ag1, ag4)
 
 
 @pytest.mark.gpu
