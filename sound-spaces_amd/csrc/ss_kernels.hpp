@@ -1884,6 +1884,20 @@ __device__ __forceinline__ float ld_agent(const float* q) {
 #endif
 }
 
+// L2 warm-up: one 4-byte load per 128-byte line of [ptr, ptr + bytes), fire and forget - the data goes to a 256-byte dummy in LDS
+// (global_load_lds: no destination register, nothing ever waits for it), the LINES stay in this XCD's L2.  Issued in front of an
+// STFT phase (microseconds of pure LDS / VALU work) for what the NEXT output block will load cold from HBM: its RIR block or
+// (k_obs_rows; -DSS_ROWS_NO_L2_WARM is the A/B switch)
+__device__ __forceinline__ void l2_touch(const void* ptr, int bytes, int t, int* s_dummy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const char* c = static_cast<const char*>(ptr);
+    for (int off = t * 128; off < bytes; off += kT * 128)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const int*>(c + off), s_dummy, 4, 0, 0);
+#else
+    (void)ptr; (void)bytes; (void)t; (void)s_dummy;
+#endif
+}
+
 // STFT of the pooled blocks [b0, b1) that output block j completes (see the kernel comment).  y = the block's kB samples
 // (packed pairs t + 1024 a).  `last`: j is the row's last block (right centre padding, frames up to n_frames - 1).
 // tail_in: the previous block's last samples (k_obs_rows: the workgroup's own LDS; GLOBAL_TAIL, k_obs_blocks: global memory
@@ -1982,6 +1996,7 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
         const c32 wq0 = p.tb.twM[64 * (t & 15)];
         if (t < 16) s_wq[t] = wq0;
     }
+    __shared__ int s_dummy[64];                           // sink of the L2 warm-up loads (l2_touch)
     // nothing the compiler tracks may be pending when the row loop starts (see k_conv_rows)
     SSK_OPAQUE2(tw.p1); SSK_OPAQUE2(tw.p2); SSK_OPAQUE2(tw.i0); SSK_OPAQUE2(tw.i1);
     const int G = (int)gridDim.x;
@@ -2174,6 +2189,16 @@ __global__ __launch_bounds__(1024) void k_obs_rows(ConvParams p, int n_rows) {
             // computed (at 44.1 kHz a 0.25-s step has 18 live pooled blocks of 69; the other 51 were three quarters of the STFT work).
             const int b_zero = live_blocks(p.n_valid, p.out_len, p.t4);
             const int b1c = min(b1, max(b0, b_zero));     // [b0, b1c) computed, [b1c, b1) zero
+#if !defined(SS_ROWS_NO_L2_WARM)
+            // what block j + 1 will load cold from HBM - term 0's RIR block j + 1 (1-s clips: exactly its new pair), or that
+            // block's spectrum on the spectral bank - is pulled into L2 under this block's STFT phase
+            // (time-domain bank: -1.3 ... -1.7 % in three alternating runs at 64 / 128 / 512 units; the same for the spectral
+            // bank's block spectra measured +2.5 % at 128 / 512 units and is not done: profiles/r6/kbench_l2warm_44k.txt)
+            if (!SPECTRAL && !XFADE && j + 1 < p.nb_y && dws[0].x >= 0 && j + 1 < nbh0) {
+                const BankRow br = bank_row<BUCKETS>(p, dws[0].x, ch);
+                if (br.es == 1) l2_touch(br.h + (size_t)(j + 1) * kB, min(kB, br.cap - (j + 1) * kB) * 4, tl, s_dummy);
+            }
+#endif
             if (kRowsAbl & 1) {
                 if (y[0].x == 123.456f) p.sgram[0] = y[7].y;      // keeps the convolution alive
                 lds_barrier();
