@@ -417,6 +417,14 @@ typedef struct ss_miss_loader {
 } ss_miss_loader;
 int ss_ctx_observe_requests_load(ss_ctx* ctx, const long long* recs, int n, ss_request_tables* tables, ss_miss_loader* loader,
                                  float* audiogoal, float* spectrogram, int* miss_out, int* n_miss, void* stream);
+/* The loader alone, for callers that name FILES (the eager call of an agent that has moved: simulator.py:615-618 reads the pose's
+ * file on every cache-missing step): k wav files -> k bank entries of the lent store (free stack first, then the least recently
+ * used occupied entries whose last_used is below `tick`; last_used / n_slots as in ss_request_tables, NULL = no eviction), one
+ * scatter launch on `stream`, block spectra of the new rows when the context holds the spectral form; report in loaded_slot /
+ * loaded_frames / evicted_slot.  pair_keys / pair_slots / table_dirs / loaded_key are not used.  Returns 0 = loaded, 1 = not for
+ * this path (nothing changed: unusual file, no entry to be had, rows too short, the bank is not the context's), < 0 = error. */
+int ss_ctx_load_rir_files(ss_ctx* ctx, ss_miss_loader* loader, const char* const* paths, int k, long long* last_used,
+                          long long tick, int n_slots, void* stream);
 /* The records -> unit columns step alone (host only, needs no GPU): units_out int32 [5, n] = sound, t0, rir, dis_sound, dis_rir. */
 int ss_ctx_requests_units(ss_ctx* ctx, const long long* recs, int n, const ss_request_tables* tables, int* units_out,
                           int* miss_out, int* n_miss);

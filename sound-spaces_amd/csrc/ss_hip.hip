@@ -1581,6 +1581,98 @@ int ss_ctx_observe_requests(ss_ctx* h, const long long* recs, int n, const ss_re
     return ss_ctx_observe(h, &u, n, audiogoal, spectrogram, stream);
 }
 
+// k files -> k bank entries of the lent store (ss_miss_loader): entries off the free stack, then - with the recency arrays lent -
+// the least recently used occupied ones (never one stamped with `tick`); files read into the pinned block, ONE scatter launch,
+// the new rows' block spectra when `spectral`; loaded_slot / loaded_frames / evicted_slot report.  1 = not served, nothing changed.
+static int loader_load_paths(ssctx::Context& c, ss_miss_loader* ld, const char* const* cp, int k, long long* last_used, long long tick,
+                             int n_slots, bool spectral, hipStream_t st) {
+    const int hb = (ld->cap + ssk::kB - 1) / ssk::kB;
+    if (k <= 0 || k > ld->stage_rows || k > ld->loaded_cap) return 1;
+    if (spectral && (!ld->stage_desc || c.h_blocks != hb || !c.hspec)) return 1;
+    // entries: free ones first, then - if the caller lent its recency arrays - the least recently used occupied ones
+    std::vector<int> victims;
+    if (k > ld->n_free) {
+        const int r = k - ld->n_free;
+        if (!ld->used || !ld->use_seq || !ld->evicted_slot || !last_used || r > ld->evict_cap) return 1;
+        std::vector<int> cand;
+        for (int sl = 0; sl < n_slots; ++sl)
+            if (ld->used[sl] && last_used[sl] < tick) cand.push_back(sl);     // (never a row this step resolves to)
+        if (static_cast<int>(cand.size()) < r) return 1;       // the caller's own path raises its "store too small" there
+        auto older = [&](int a, int b) {
+            return last_used[a] != last_used[b] ? last_used[a] < last_used[b] : ld->use_seq[a] < ld->use_seq[b];
+        };
+        std::partial_sort(cand.begin(), cand.begin() + r, cand.end(), older);
+        victims.assign(cand.begin(), cand.begin() + r);
+    }
+    std::vector<int> take(k);                                  // the entries the k new rows go to, in order
+    for (int i = 0; i < k; ++i)
+        take[i] = i < ld->n_free ? ld->free_slots[ld->n_free - 1 - i] : victims[i - ld->n_free];
+    if (spectral) {                                            // (window offsets are int32 words from the bank's base)
+        for (int i = 0; i < k; ++i)
+            if ((static_cast<long long>(take[i]) + 1) * ld->bank_unit_stride >= (1LL << 31)) return 1;
+    }
+    if (c.miss_ev) {                                           // the staging block's previous scatter has run
+        if (hipEventSynchronize(static_cast<hipEvent_t>(c.miss_ev)) != hipSuccess) return 1;
+    } else {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        c.miss_ev = ev;
+    }
+    std::vector<int> kept(k), frames(k), status(k);
+    sswav::read_many(cp, k, ld->stage, 2LL * ld->cap, ld->cap, ld->keep, false, kept.data(), frames.data(), status.data(),
+                     ld->threads > 0 ? ld->threads : 1);
+    for (int i = 0; i < k; ++i)
+        if (status[i] != sswav::kOk && status[i] != sswav::kEmpty) return 1;     // scipy's semantics are the caller's reader's
+    // ---- commit
+    for (size_t i = 0; i < victims.size(); ++i) ld->evicted_slot[i] = victims[i];
+    ld->n_evicted = static_cast<int>(victims.size());
+    const int from_free = k < ld->n_free ? k : ld->n_free;
+    ld->n_free -= from_free;
+    for (int i = 0; i < k; ++i) {
+        const int slot = take[i];
+        ld->stage_slot[i] = slot;
+        ld->stage_len[i] = kept[i];
+        ld->host_len[slot] = kept[i];
+        ld->clipped[slot] = kept[i] < frames[i];
+        if (ld->spec_stale) ld->spec_stale[slot] = 1;
+        ld->loaded_slot[i] = slot; ld->loaded_frames[i] = frames[i];
+        if (last_used && slot < n_slots) last_used[slot] = tick;
+    }
+    ld->n_loaded = k;
+    int rc = ss_bank_scatter_rows_f32(ld->stage, 2LL * ld->cap, ld->stage_slot, ld->stage_len, k, ld->bank, ld->bank_unit_stride,
+                                      ld->bank_chan_stride, ld->cap, ld->dev_len, st);
+    if (rc == 0 && spectral) {
+        // the new rows' block spectra H'_i = 2 rFFT(block i), straight into the spectral bank (scatter form of k_source_windows;
+        // the descriptors are read from the pinned block in place)
+        int w = 0;
+        for (int i = 0; i < k; ++i)
+            for (int ch = 0; ch < 2; ++ch)
+                for (int b = 0; b < hb; ++b, ++w) {
+                    const int slot = ld->stage_slot[i], left = ld->cap - b * ssk::kB;
+                    int* d = ld->stage_desc + 5 * w;
+                    d[0] = static_cast<int>(slot * ld->bank_unit_stride + static_cast<long long>(ch) * ld->bank_chan_stride + static_cast<long long>(b) * ssk::kB);
+                    d[1] = left < ssk::kB ? left : ssk::kB;
+                    d[2] = 0; d[3] = 0;
+                    d[4] = (slot * 2 + ch) * hb + b;
+                }
+        ssk::SrcParams sp;
+        rc = get_tables(&sp.tb);
+        if (rc == 0) {
+            sp.src = ld->bank;
+            sp.desc = ld->stage_desc;
+            sp.spec = reinterpret_cast<ssk::f32x4*>(const_cast<float*>(c.hspec));
+            sp.desc_stride = 5;
+            sp.scale = 1.0f;
+            hipLaunchKernelGGL(ssk::k_source_windows, dim3(w), dim3(ssk::kT), 0, st, sp);
+            rc = hip_err(hipGetLastError());
+        }
+        if (rc == 0 && ld->spec_stale)
+            for (int i = 0; i < k; ++i) ld->spec_stale[ld->stage_slot[i]] = 0;
+    }
+    if (rc == 0) rc = hip_err(hipEventRecord(static_cast<hipEvent_t>(c.miss_ev), st));
+    return rc;
+}
+
 // The miss path inside the call (include/ss_hip.h: ss_miss_loader).  Returns 1 = "not for the fast path" (nothing was changed).
 static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, const int* miss,
                              int n_miss, hipStream_t st, bool spectral) {
@@ -1616,106 +1708,32 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
     keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
     const int k = static_cast<int>(keys.size());
     if (k == 0 || k > ld->stage_rows || k > ld->loaded_cap || tb->n_pairs + k > ld->pair_cap) return 1;
-    // entries: free ones first, then - if the caller lent its recency arrays - the least recently used occupied ones
-    std::vector<int> victims;
-    if (k > ld->n_free) {
-        const int r = k - ld->n_free;
-        if (!ld->used || !ld->use_seq || !ld->evicted_slot || !tb->last_used || r > ld->evict_cap) return 1;
-        std::vector<int> cand;
-        for (int sl = 0; sl < tb->n_slots; ++sl)
-            if (ld->used[sl] && tb->last_used[sl] < tb->tick) cand.push_back(sl);     // (never a row this step resolves to)
-        if (static_cast<int>(cand.size()) < r) return 1;       // the caller's own path raises its "store too small" there
-        auto older = [&](int a, int b) {
-            return tb->last_used[a] != tb->last_used[b] ? tb->last_used[a] < tb->last_used[b] : ld->use_seq[a] < ld->use_seq[b];
-        };
-        std::partial_sort(cand.begin(), cand.begin() + r, cand.end(), older);
-        victims.assign(cand.begin(), cand.begin() + r);
-    }
-    std::vector<int> take(k);                                  // the entries the k new rows go to, in order
-    for (int i = 0; i < k; ++i)
-        take[i] = i < ld->n_free ? ld->free_slots[ld->n_free - 1 - i] : victims[i - ld->n_free];
-    if (spectral) {                                            // (window offsets are int32 words from the bank's base)
-        for (int i = 0; i < k; ++i)
-            if ((static_cast<long long>(take[i]) + 1) * ld->bank_unit_stride >= (1LL << 31)) return 1;
-    }
-    if (c.miss_ev) {                                           // the staging block's previous scatter has run
-        if (hipEventSynchronize(static_cast<hipEvent_t>(c.miss_ev)) != hipSuccess) return 1;
-    } else {
-        hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return 1; }
-        c.miss_ev = ev;
-    }
-    std::vector<std::string> paths(k);
-    std::vector<const char*> cp(k);
-    for (int i = 0; i < k; ++i) {
-        const long long key = keys[i];
-        paths[i] = std::string(ld->table_dirs[key >> 40]) + "/" + std::to_string((key >> 20) & 0xFFFFF) + "_" +
-                   std::to_string(key & 0xFFFFF) + ".wav";                       // simulator.py:615-616
-        cp[i] = paths[i].c_str();
-    }
-    std::vector<int> kept(k), frames(k), status(k);
-    sswav::read_many(cp.data(), k, ld->stage, 2LL * ld->cap, ld->cap, ld->keep, false, kept.data(), frames.data(), status.data(),
-                     ld->threads > 0 ? ld->threads : 1);
-    for (int i = 0; i < k; ++i)
-        if (status[i] != sswav::kOk && status[i] != sswav::kEmpty) return 1;     // scipy's semantics are the caller's reader's
-    // ---- commit
-    if (!victims.empty()) {                                    // their pairs leave the sorted arrays (one compacting pass)
-        std::vector<char> gone(static_cast<size_t>(tb->n_slots), 0);
-        for (int v : victims) gone[v] = 1;
-        int o = 0;
-        for (int i = 0; i < tb->n_pairs; ++i) {
-            const long long sl = ld->pair_slots[i];
-            if (sl >= 0 && sl < tb->n_slots && gone[sl]) continue;
-            ld->pair_keys[o] = ld->pair_keys[i]; ld->pair_slots[o] = ld->pair_slots[i]; ++o;
+    int rc = 0;
+    {
+        std::vector<std::string> paths(k);
+        std::vector<const char*> cp(k);
+        for (int i = 0; i < k; ++i) {
+            const long long key = keys[i];
+            paths[i] = std::string(ld->table_dirs[key >> 40]) + "/" + std::to_string((key >> 20) & 0xFFFFF) + "_" +
+                       std::to_string(key & 0xFFFFF) + ".wav";                   // simulator.py:615-616
+            cp[i] = paths[i].c_str();
         }
-        tb->n_pairs = o;
-        for (size_t i = 0; i < victims.size(); ++i) ld->evicted_slot[i] = victims[i];
-        ld->n_evicted = static_cast<int>(victims.size());
-    }
-    const int from_free = k < ld->n_free ? k : ld->n_free;
-    ld->n_free -= from_free;
-    for (int i = 0; i < k; ++i) {
-        const int slot = take[i];
-        ld->stage_slot[i] = slot;
-        ld->stage_len[i] = kept[i];
-        ld->host_len[slot] = kept[i];
-        ld->clipped[slot] = kept[i] < frames[i];
-        if (ld->spec_stale) ld->spec_stale[slot] = 1;
-        ld->loaded_key[i] = keys[i]; ld->loaded_slot[i] = slot; ld->loaded_frames[i] = frames[i];
-        if (tb->last_used && slot < tb->n_slots) tb->last_used[slot] = tb->tick;
-    }
-    ld->n_loaded = k;
-    int rc = ss_bank_scatter_rows_f32(ld->stage, 2LL * ld->cap, ld->stage_slot, ld->stage_len, k, ld->bank, ld->bank_unit_stride,
-                                      ld->bank_chan_stride, ld->cap, ld->dev_len, st);
-    if (rc == 0 && spectral) {
-        // the new rows' block spectra H'_i = 2 rFFT(block i), straight into the spectral bank (scatter form of k_source_windows;
-        // the descriptors are read from the pinned block in place)
-        int w = 0;
-        for (int i = 0; i < k; ++i)
-            for (int ch = 0; ch < 2; ++ch)
-                for (int b = 0; b < hb; ++b, ++w) {
-                    const int slot = ld->stage_slot[i], left = ld->cap - b * ssk::kB;
-                    int* d = ld->stage_desc + 5 * w;
-                    d[0] = static_cast<int>(slot * ld->bank_unit_stride + static_cast<long long>(ch) * ld->bank_chan_stride + static_cast<long long>(b) * ssk::kB);
-                    d[1] = left < ssk::kB ? left : ssk::kB;
-                    d[2] = 0; d[3] = 0;
-                    d[4] = (slot * 2 + ch) * hb + b;
-                }
-        ssk::SrcParams sp;
-        rc = get_tables(&sp.tb);
-        if (rc == 0) {
-            sp.src = ld->bank;
-            sp.desc = ld->stage_desc;
-            sp.spec = reinterpret_cast<ssk::f32x4*>(const_cast<float*>(c.hspec));
-            sp.desc_stride = 5;
-            sp.scale = 1.0f;
-            hipLaunchKernelGGL(ssk::k_source_windows, dim3(w), dim3(ssk::kT), 0, st, sp);
-            rc = hip_err(hipGetLastError());
+        const int rc_l = loader_load_paths(c, ld, cp.data(), k, tb->last_used, tb->tick, tb->n_slots, spectral, st);
+        if (rc_l == 1) return 1;
+        for (int i = 0; i < k; ++i) ld->loaded_key[i] = keys[i];
+        if (ld->n_evicted) {                                   // the evicted entries' pairs leave the sorted arrays (one compacting pass)
+            std::vector<char> gone(static_cast<size_t>(tb->n_slots), 0);
+            for (int i = 0; i < ld->n_evicted; ++i) gone[ld->evicted_slot[i]] = 1;
+            int o = 0;
+            for (int i = 0; i < tb->n_pairs; ++i) {
+                const long long sl = ld->pair_slots[i];
+                if (sl >= 0 && sl < tb->n_slots && gone[sl]) continue;
+                ld->pair_keys[o] = ld->pair_keys[i]; ld->pair_slots[o] = ld->pair_slots[i]; ++o;
+            }
+            tb->n_pairs = o;
         }
-        if (rc == 0 && ld->spec_stale)
-            for (int i = 0; i < k; ++i) ld->spec_stale[ld->stage_slot[i]] = 0;
+        rc = rc_l;
     }
-    if (rc == 0) rc = hip_err(hipEventRecord(static_cast<hipEvent_t>(c.miss_ev), st));
     // the sorted pair arrays, in place (keys ascending: merged from the back)
     {
         int i = tb->n_pairs - 1, j = k - 1, o = tb->n_pairs + k - 1;
@@ -1727,6 +1745,19 @@ static int serve_pose_misses(ss_ctx* h, const long long* recs, int n, ss_request
         tb->n_pairs += k;
     }
     return rc;                                                 // (< 0: the rows are booked, the launch failed: the caller sees the error)
+}
+
+int ss_ctx_load_rir_files(ss_ctx* h, ss_miss_loader* ld, const char* const* paths, int k, long long* last_used, long long tick,
+                          int n_slots, void* stream) {
+    if (!h || !ld || !paths || k < 0) return SS_EINVAL;
+    ld->n_loaded = 0; ld->n_evicted = 0;
+    if (k == 0) return 0;
+    ssctx::Context& c = h->c;
+    if (!ld->free_slots || !ld->bank || !ld->dev_len || !ld->host_len || !ld->clipped || !ld->stage || !ld->stage_slot ||
+        !ld->stage_len || !ld->loaded_slot || !ld->loaded_frames || ld->cap < 2 || (ld->cap & 1) || c.rir != ld->bank)
+        return 1;
+    // (rows of a store that keeps the spectral form get their block spectra right away: whichever form the next launch reads)
+    return loader_load_paths(c, ld, paths, k, last_used, tick, n_slots, c.hspec != nullptr, static_cast<hipStream_t>(stream));
 }
 
 int ss_ctx_observe_requests_load(ss_ctx* h, const long long* recs, int n, ss_request_tables* tb, ss_miss_loader* ld, float* audiogoal,

@@ -16,7 +16,7 @@ EXPORTS = ("ss_block_len", "ss_spec_floats", "ss_version", "ss_init", "ss_source
            "ss_ctx_sims_units", "ss_ctx_set_overlap", "ss_ctx_join", "ss_fftconv_binaural_buckets_f32",
            "ss_audio_obs_buckets_f32", "ss_ctx_set_rir_buckets", "ss_release_scratch",
            "ss_source_windows32_f32", "ss_audio_obs32_f32", "ss_ctx_observe_requests", "ss_ctx_requests_units", "ss_audio_features_f32", "ss_ctx_observe_features",
-           "ss_wav_read_rirs_f32", "ss_rows_gather_f32", "ss_bank_scatter_rows_f32", "ss_ctx_set_chip_share", "ss_ctx_set_spectral_policy", "ss_ctx_observe_requests_load")
+           "ss_wav_read_rirs_f32", "ss_rows_gather_f32", "ss_bank_scatter_rows_f32", "ss_ctx_set_chip_share", "ss_ctx_set_spectral_policy", "ss_ctx_observe_requests_load", "ss_ctx_load_rir_files")
 
 
 class SsRirBucket(ctypes.Structure):
@@ -126,6 +126,7 @@ def load() -> ctypes.CDLL:
     lib.ss_ctx_observe_requests.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp]
     lib.ss_ctx_requests_units.argtypes = [vp, vp, c_int, vp, vp, vp, vp]
     lib.ss_ctx_observe_requests_load.argtypes = [vp, vp, c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.ss_ctx_load_rir_files.argtypes = [vp, vp, vp, c_int, vp, c_ll, c_int, vp]
     lib.ss_wav_read_rirs_f32.argtypes = [vp, c_int, vp, c_ll, c_int, c_int, c_int, vp, vp, vp, c_int]
     lib.ss_rows_gather_f32.argtypes = [vp, vp, c_int, vp, c_ll, c_int, c_int]
     lib.ss_bank_scatter_rows_f32.argtypes = [vp, c_ll, vp, vp, c_int, vp, c_ll, c_int, c_int, vp, vp]

@@ -878,9 +878,10 @@ class RirStore:
             L.n_free = d["free_n"] = len(top)
             d["free_ver"] = self._free_ver
 
-    def adopt_loaded(self, d, key_of) -> int:
-        """Book what ``ss_ctx_observe_requests_load`` loaded (loader dict `d`): entries leave the free list and are bound to
-        `key_of(pair_key)` exactly as ``load_files`` binds them.  Returns the number of rows adopted."""
+    def adopt_loaded(self, d, key_of=None, keys=None) -> int:
+        """Book what ``ss_ctx_observe_requests_load`` / ``ss_ctx_load_rir_files`` loaded (loader dict `d`): entries leave the free
+        list and are bound to `key_of(pair_key)` (or to `keys[i]`: the file form) exactly as ``load_files`` binds them.  Returns
+        the number of rows adopted."""
         L = d["s"]
         k = int(L.n_loaded)
         if k == 0:
@@ -903,8 +904,8 @@ class RirStore:
             assert self._free[-kf:][::-1] == slots[:kf], "the library pops the free stack from its end"
             del self._free[-kf:]
         d["free_n"] = int(L.n_free)
-        for key, sl in zip(d["loaded_key"][:k].tolist(), slots):
-            self._bind(key_of(key), sl)
+        for key, sl in zip(keys if keys is not None else map(key_of, d["loaded_key"][:k].tolist()), slots):
+            self._bind(key, sl)
         sl_np = np.asarray(slots)
         self._dev_len[sl_np] = self.host_len[sl_np]              # (host_len / _clipped / _stale were written by the library)
         self.misses += k
@@ -1423,6 +1424,7 @@ class AudioEngine:
         bytes).  An explicit rir_spectral=True keeps r5's meaning: the spectral rows for every launch."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         self._native_readers: Dict[int, tuple] = {}              # rir_file_slot: id(reader) -> (stock wav reader?, lenient?, reader)
+        self._file_loader = None                                 # RirStore.miss_loader dict of rir_file_slot (ss_ctx_load_rir_files)
         full = self.renderer.n_valid != self.renderer.sr or self.renderer.wrap
         self.spectral_max_units = 0
         if rir_spectral is None:
@@ -1561,6 +1563,26 @@ class AudioEngine:
                                                          bool(reader.keywords.get("lenient")), reader)
         if not native[0]:
             return store.slot(path, lambda: reader(path))
+        if type(store) is RirStore and store.device.type == "cuda" and not native[1] and hasattr(store, "_batch_of"):
+            # ONE C call (ss_ctx_load_rir_files): entry off the free stack (or the least recently used one), file read into the
+            # store's pinned block, scatter launch, block spectra - the store's dictionaries follow from the report
+            import ctypes
+            ctx = self._sync_context_bank(1)
+            d = self._file_loader
+            if d is None:
+                z = np.zeros((1,), np.int64)
+                d = self._file_loader = store.miss_loader([], z, z.copy(), 0)
+            else:
+                store.refresh_loader(d, d["dirs"], d["pk"], d["ps"])
+            dev = self.renderer.device
+            stream = torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+            rc = ctx.lib.ss_ctx_load_rir_files(ctx._h, d["ref"], (ctypes.c_char_p * 1)(os.fsencode(path)), 1,
+                                               store._batch_of.ctypes.data, int(store._batch), int(store.slots), stream)
+            if rc == 0:
+                store.adopt_loaded(d, keys=[path])
+                return store._slot_of[path]
+            if rc < 0:
+                ops._lib.check(rc, "ss_ctx_load_rir_files")
         return store.load_files([path], [path], reader=reader, missing_ok=native[1], new_batch=False)[0]
 
     def rir_len(self, slot: int) -> int:
