@@ -100,7 +100,11 @@ int ss_spectrogram_f32(const float* x, float* out, int n_units, int len, int pad
  * buffer, cross-faded rows with more than one rendered block take two launches (convolution, spectrogram), which is 20 %
  * faster than their one-launch form.  Pooled blocks that lie behind the rendered samples of a short step are exact zeros
  * and are written, not computed.  For rows longer than kB the library keeps a per-(device, stream) scratch for the block spectra of
- * the rows in flight (<= 2 x ceil(rir_cap/kB) x 128 KiB per CU), allocated on the stream's first such call. */
+ * the rows in flight (<= 2 x ceil(rir_cap/kB) x 128 KiB per CU), allocated on the stream's first such call.
+ * Small steps of such rows (rows x output blocks <= the launch's share of the CUs: <= 42 units at 44.1 kHz) are rendered by one
+ * workgroup per OUTPUT BLOCK (k_obs_blocks): the samples in front of a block boundary are handed to the next block's workgroup
+ * through a per-(device, stream) area of 1.3 MB whose flags carry a launch counter - such a launch must not be replayed from a
+ * captured hipGraph (the counter would repeat; the library itself never captures). */
 int ss_audio_obs_f32(const float* spec, const float* rir, const int* rir_len, const int* unit_desc,
                      float* audiogoal, float* spectrogram, int n_units,
                      long long rir_unit_stride, int rir_chan_stride, int rir_elem_stride,

@@ -1876,6 +1876,11 @@ __device__ __forceinline__ bool flag_acquire(const int* f, int v) {
     return *f == v;                                       // (host build: workgroups run one after the other, producers first)
 #endif
 }
+__device__ __forceinline__ void wait_global_stores() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) alone (expcnt 7, lgkmcnt 15: untouched): this wave's loads AND stores
+#endif
+}
 __device__ __forceinline__ float ld_agent(const float* q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1935,6 +1940,9 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     if (!last && tail_out) {                              // context of the next block: samples [640 b1 - 256, base + kB)
         const int s0n = kHop * kPool * b1 - kNfft / 2;
         if (t < kTailFloats && s0n + t < base + kB) tail_out[t] = yl[s0n - base + t];
+        // GLOBAL_TAIL: the stores of EVERY thread must have reached L2 before thread 0 releases the flag - lds_barrier() only
+        // waits for LDS operations (lgkmcnt), and the agent-scope release below only for thread 0's own wave
+        if (GLOBAL_TAIL) wait_global_stores();
     }
     lds_barrier();
     if (GLOBAL_TAIL && sync.flag_out && t == 0) flag_release(sync.flag_out, sync.epoch);      // (behind the barrier: every

@@ -527,6 +527,7 @@ class RirStore:
         self._used[:] = False
         self._pending = {}
         self._free = list(range(self.slots - self.group, -1, -self.group))
+        self._free_ver += 1
         self.host_len[:] = 0
         self.bank.lengths.zero_()
         self._dev_len[:] = -1
@@ -901,8 +902,12 @@ class RirStore:
             L.n_evicted = 0
         kf = k - ke                                              # ... the others came off the free stack
         if kf:
-            assert self._free[-kf:][::-1] == slots[:kf], "the library pops the free stack from its end"
-            del self._free[-kf:]
+            if self._free[-kf:][::-1] == slots[:kf]:             # the library pops the free stack from its end, as _take_slots does
+                del self._free[-kf:]
+            else:                                                # (the list changed under the loader's mirror: take them out one by one)
+                gone = set(slots[:kf])
+                self._free = [f for f in self._free if f not in gone]
+                self._free_ver += 1
         d["free_n"] = int(L.n_free)
         for key, sl in zip(keys if keys is not None else map(key_of, d["loaded_key"][:k].tolist()), slots):
             self._bind(key, sl)
