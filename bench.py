@@ -412,7 +412,7 @@ def measured_traffic(units, sr, kernel):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r6", "traffic.json")))
         have = open(os.path.join(ROOT, "sound-spaces_amd", "csrc", ".libss_hip.kernelhash")).read().strip()
-        e = tj["kernels"][kernel]
+        e = tj["kernels"].get("%s@%d" % (kernel, units)) or tj["kernels"][kernel]
         if tj["source_hash"] == have and e["units_per_launch"] == units and e["sampling_rate"] == sr:
             fc, wc = float(e.get("fetch_correction", 1.0)), float(e.get("write_correction", 1.0))
             return {"bytes": int(fc * e["fetch_bytes"] + wc * e["write_bytes"]), "fetch_bytes_raw": int(e["fetch_bytes"]),
@@ -516,10 +516,10 @@ def main():
                          "samples (the format SURVEY 8(d) defines the metric and its algorithmic bytes on); 'spectral' = block "
                          "spectra computed once at bank load (ss_rir_spectra_f32), no forward FFT per step, 2x the bytes per "
                          "RIR.  The other format is timed in the same run and reported beside it.  'auto' (default) = what "
-                         "AudioEngine(rir_spectral=None) does with both forms resident: 16-kHz steps of <= 64 units read the "
-                         "spectral rows (cfg1, cfg3, the reference's 5-10 envs per GPU) and so do 16-kHz steps with distractor "
-                         "terms (cfg4: two forward transforms per row), everything else the time-domain rows "
-                         "(44.1 kHz: the metric's declared format; the engine itself prefers the spectral rows there)")
+                         "AudioEngine(rir_spectral=None) does: both forms resident (when they fit its HBM share), every launch "
+                         "reads the spectral rows - measured faster at every step size and rate (profiles/r6/"
+                         "kbench_bank_form_16k.txt).  SURVEY 8(d) defines the metric's ALGORITHMIC bytes on the time-domain rows: "
+                         "`roofline` keeps that definition whatever the launch reads (`actual_bytes_per_unit` says what it reads)")
     ap.add_argument("--config", choices=["headline", "cfg1", "cfg2", "cfg3", "cfg4"], default="headline",
                     help="BASELINE.json configs[] presets: cfg1 = 32 envs @16 kHz; cfg2 = 128 envs x 4 rotations @44.1 kHz "
                          "(512 units / launch); cfg4 = savi: 256 envs, 21 sounds of 1-20 s, distractor, audiogoal + "
@@ -557,9 +557,8 @@ def main():
         args.envs, args.sr, args.rotations, args.workload = 256, 16000, 1, "savi"
 
     # (after the presets: 'auto' needs the step's size)
-    units_per_step = (args.envs // args.gpus if args.scaling == "strong" else args.envs) * args.rotations
-    args.spectral = args.rir_bank == "spectral" or (args.rir_bank == "auto" and args.sr <= 16384 and
-                                                    (units_per_step <= 64 or args.workload == "savi"))   # (savi: distractor terms)
+    args.spectral = args.rir_bank in ("spectral", "auto")        # auto = AudioEngine(rir_spectral=None): both forms resident, the
+                                                              # launches read the spectral rows (faster at every size: kbench_bank_form_16k.txt)
     feats = args.features if args.features is not None else ("logmel,gccphat" if args.workload == "savi" else "none")
     feats = [f for f in feats.split(",") if f and f != "none"]
     assert all(f in ("logmel", "gccphat") for f in feats), "--features: logmel, gccphat"
@@ -1066,12 +1065,16 @@ def main():
             except Exception as ex_:                               # one arrangement failing must not take the line down
                 side[key] = {"value": None, "note": f"{type(ex_).__name__}: {ex_}"}
     if world == 1 and not args.no_secondary:
-        eo, _, _ = run_loop(1, 0, not args.spectral, lanes=LANES)  # the other RIR bank format, same protocol as the headline
+        eo, _, _ = run_loop(1, 0, not args.spectral, lanes=LANES)  # the other RIR bank format: pipelined, dependent, kernel rate
+        ed, _, _ = run_loop(1, 0, not args.spectral, regions=REGIONS, dependent=1)
         _, ps_o, _ = run_loop(1, 0, not args.spectral)
         side["spectral_bank" if not args.spectral else "time_domain_bank"] = dict(
-            rate(eo), avg_launch_ms=round(float(np.mean(ps_o)), 5),
-            note=("RIR bank stored as block spectra (ss_rir_spectra_f32): no forward FFT per step, 2x the bytes per RIR "
-                  "(actual reads per unit: 2*2*L*4 + window spectrum from L2)" if not args.spectral else "time-domain bank"))
+            rate(eo), dependent=rate(ed), avg_launch_ms=round(float(np.mean(ps_o)), 5),
+            note=("`value` = pipelined (as `pipelined` of the line), `dependent` = the line's own protocol.  " +
+                  ("RIR bank stored as block spectra (ss_rir_spectra_f32): no forward FFT per step, 2x the bytes per RIR "
+                   "(actual reads per unit: 2*2*L*4 + window spectrum from L2)" if not args.spectral else
+                   "launches read the time-domain rows: the format SURVEY 8(d) defines the algorithmic bytes on, and what "
+                   "rounds 1-5 reported the headline on")))
     r.rirs.spectra = spectra if args.spectral else None
 
     # ---- secondary measurement: the convolution kernel alone (audiogoal written), same inputs -------------

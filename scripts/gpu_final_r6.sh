@@ -16,6 +16,7 @@ cp /tmp/pytest_final.log "$OUT/pytest_gpu.log"; cp /tmp/profile_pass.log "$OUT/p
 mkdir -p profiles/r6; cp "$OUT/traffic.json" profiles/r6/traffic.json
 timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_headline_driver_protocol.json" 2> "$OUT/bench_headline_driver_protocol.err"; echo "driver-protocol rc=$?"
 timeout 900 python bench.py > "$OUT/bench_headline.json" 2> "$OUT/bench_headline.err"; echo "headline rc=$?"
+timeout 900 python bench.py --rir-bank time --no-plugin-path > "$OUT/bench_headline_time.json" 2> "$OUT/bench_headline_time.err"
 timeout 900 python bench.py --config cfg2 --steps 40 --warmup 5 --no-plugin-path > "$OUT/bench_cfg2.json" 2> "$OUT/bench_cfg2.err"
 timeout 900 python bench.py --config cfg4 --steps 100 --no-plugin-path > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
 timeout 900 python scripts/bench_dataset.py > "$OUT/dataset.json" 2> "$OUT/dataset.err"; echo "dataset rc=$?"; cat "$OUT/dataset.json"

@@ -19,15 +19,16 @@ CFG[cfg4]="--config cfg4 --steps 100"
 CFG[cfg4_no_features]="--config cfg4 --steps 100 --features none"
 CFG[replica44k_128]="--sr 44100 --envs 128 --steps 60 --warmup 5"
 CFG[replica44k_10]="--sr 44100 --envs 10 --steps 100 --warmup 10"
-CFG[replica44k_5_spectral]="--sr 44100 --envs 5 --steps 100 --warmup 10 --rir-bank spectral"
-CFG[replica44k_10_spectral]="--sr 44100 --envs 10 --steps 100 --warmup 10 --rir-bank spectral"
-CFG[cfg2_spectral]="--config cfg2 --steps 40 --warmup 5 --rir-bank spectral"
+CFG[replica44k_5]="--sr 44100 --envs 5 --steps 100 --warmup 10"
+CFG[replica44k_10_time]="--sr 44100 --envs 10 --steps 100 --warmup 10 --rir-bank time"
+CFG[cfg2_time]="--config cfg2 --steps 40 --warmup 5 --rir-bank time"
+CFG[headline_time]="--rir-bank time --no-plugin-path"
 CFG[cfg1_time]="--config cfg1 --rir-bank time"
 CFG[cfg4_time]="--config cfg4 --steps 100 --rir-bank time"
 # every line carries its cpu_baseline (the oracle at the CONFIG's own rate and shape on the box's cores, ~16 s per line)
-for NAME in headline headline_driver_protocol cfg1 cfg1_time cfg2 cfg2_spectral cfg3 cfg4 cfg4_time cfg4_no_features replica44k_128 replica44k_10 replica44k_10_spectral replica44k_5_spectral; do
+for NAME in headline headline_driver_protocol headline_time cfg1 cfg1_time cfg2 cfg2_time cfg3 cfg4 cfg4_time cfg4_no_features replica44k_128 replica44k_10 replica44k_10_time replica44k_5; do
   ARGS=${CFG[$NAME]}
-  EXTRA=""; case "$NAME" in cfg4_no_features|cfg1_time|cfg4_time|cfg2_spectral|replica44k_5_spectral) EXTRA="--no-cpu-baseline";; esac
+  EXTRA=""; case "$NAME" in cfg4_no_features|headline_time|cfg1_time|cfg4_time|cfg2_time|replica44k_5|replica44k_10_time) EXTRA="--no-cpu-baseline";; esac
   [ "$NAME" = headline ] || [ "$NAME" = headline_driver_protocol ] || EXTRA="$EXTRA --no-plugin-path"
   timeout 900 python bench.py $ARGS $EXTRA > "$OUT/bench_$NAME.json" 2> "$OUT/bench_$NAME.err" || echo "bench $NAME failed"
   [ "$NAME" = headline_driver_protocol ] && continue
@@ -44,7 +45,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_stats.csv"), recursi
 PY
   rm -rf "$D"
 done
-for NAME in headline cfg1 cfg2 cfg4 replica44k_10; do
+for NAME in headline headline_time cfg1 cfg2 cfg2_time cfg4 replica44k_10; do
   ARGS=${CFG[$NAME]}
   CMD="python $GRAFT_REPO_ROOT/bench.py $ARGS --no-cpu-baseline --no-plugin-path --no-secondary --streams 1 --spinup-steps 0 --regions 1 --sustain 0"
   D="$OUT/pmc_$NAME"
@@ -119,7 +120,7 @@ dominant = {"k_conv<FUSE=true>": ("rd8_nt", "wr4"), "k_conv<FUSE=true,loop>": ("
             "k_features<logmel,gccphat>": ("rd16", "wr4"),
             "k_features<spectrogram,logmel,gccphat>": ("rd16", "wr4")}
 kernels = {}
-for cfg in ("headline", "cfg1", "cfg2", "cfg4", "replica44k_10"):
+for cfg in ("headline", "headline_time", "cfg1", "cfg2", "cfg2_time", "cfg4", "replica44k_10"):
     d = os.path.join(out, "pmc_" + cfg)
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -145,7 +146,7 @@ for cfg in ("headline", "cfg1", "cfg2", "cfg4", "replica44k_10"):
                 wc = 1.0        # WRITE_SIZE counts the bytes that MOVE: 4-byte stores to every other float of a line are written
                                 # as whole sectors (calibration: 2x the bytes stored) - that IS the traffic; the factor 0.5 would
                                 # turn it back into bytes stored
-            kernels[nm] = {
+            kernels["%s@%d" % (nm, bench["config"]["units_per_gpu"])] = {
                 "units_per_launch": bench["config"]["units_per_gpu"], "sampling_rate": bench["config"]["sampling_rate"],
                 "fetch_bytes": f_kib * 1024, "write_bytes": w_kib * 1024,
                 "fetch_correction": fc, "write_correction": wc,
@@ -159,7 +160,7 @@ json.dump({"source_hash": src_hash, "command": "bench.py [--config cfg2|cfg4] --
            "calibration": calib, "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps({"calibration": calib, "kernels": kernels}, indent=1))
 PY
-rm -rf "$OUT"/pmc_headline "$OUT"/pmc_cfg1 "$OUT"/pmc_cfg2 "$OUT"/pmc_cfg4 "$OUT"/pmc_replica44k_10 "$OUT"/pmc_calib
+rm -rf "$OUT"/pmc_headline "$OUT"/pmc_headline_time "$OUT"/pmc_cfg1 "$OUT"/pmc_cfg2 "$OUT"/pmc_cfg2_time "$OUT"/pmc_cfg4 "$OUT"/pmc_replica44k_10 "$OUT"/pmc_calib
 for f in "$OUT"/stats_*.txt; do echo "== $f"; cat "$f"; done
 python - <<'PY'
 import json,glob

@@ -1414,19 +1414,20 @@ class AudioEngine:
     def __init__(self, sampling_rate: int, device="cuda", rir_slots: int = 4096, rir_cap: Optional[int] = None,
                  rir_max_cap: int = 1 << 18, rir_group: int = 1, rir_spectral: Optional[bool] = None,
                  rir_buckets: Optional[Sequence[Tuple[int, int]]] = None, spectral_hbm_fraction: float = 0.5,
-                 spectral_max_units: int = 64, **renderer_kwargs):
+                 spectral_max_units: int = 0, **renderer_kwargs):
         """rir_spectral: keep the RIR rows' block spectra in HBM as well (2x the bytes per row) and run k_conv_spec /
         k_obs_rows<SPECTRAL> (no forward FFT per step): for STATIC banks (SoundSpaces 1.0 RIR files); live SS2.0 RIRs change
         every step and stay on the time-domain kernels.  None (default) = decided here: ON for file-backed stores at rates
         whose rows span several partition blocks (44.1 / 48 kHz - the reference's Replica rate,
         configs/audionav/av_nav/replica/audiogoal.yaml:18: every observation is three forward FFTs per ear and a stash round
         trip there; cfg[2]: 271 vs 334 us per 512 units) when rows + spectra fit `spectral_hbm_fraction` of the device's free
-        memory.  Round 6: at 16 kHz too, under the same condition - but there only SMALL steps read the spectral rows
-        (<= `spectral_max_units` = 64 units per launch, chosen per launch: the reference steps 5-10 envs per GPU,
-        ss_baselines/av_nav/config/audionav/{replica,mp3d}/train_telephone/audiogoal_depth_ddppo.yaml:3, an eager call renders 1 -
-        no forward FFT on a mostly idle chip: 12.9 / 15.6 us against 17.1 / 19.0 us per step of 1 / 32 envs); steps of more
-        units read the time-domain rows, whose forward FFT hides under the rows' loads there (+-2 us per 128 envs at half the
-        bytes).  An explicit rir_spectral=True keeps r5's meaning: the spectral rows for every launch."""
+        memory.  Round 6: at 16 kHz too, under the same condition, for EVERY launch: the fused kernel is faster from the spectral
+        rows at every size (same box, alternating, profiles/r6/kbench_bank_form_16k.txt: 1 / 32 / 64 / 128 / 256 / 512 / 2048 units
+        17.1 / 19.0 / 20.3 / 25.0 / 48.5 / 96.2 / 365 us from the time-domain rows, 12.9 / 15.6 / 17.4 / 23.2 / 44.8 / 86.3 / 325 us
+        from the spectral rows) - what it costs is HBM (rows + spectra = 3 x the rows) and one transform per loaded row, which is why
+        it is tied to `spectral_hbm_fraction`.  `spectral_max_units` > 0 restores a per-launch choice: launches of more units than
+        that (without distractor terms) read the time-domain rows, and the block spectra of freshly loaded rows are only built
+        when a launch needs them."""
         self.renderer = BatchedAudioRenderer(sampling_rate, device=device, **renderer_kwargs)
         self._native_readers: Dict[int, tuple] = {}              # rir_file_slot: id(reader) -> (stock wav reader?, lenient?, reader)
         self._file_loader = None                                 # RirStore.miss_loader dict of rir_file_slot (ss_ctx_load_rir_files)

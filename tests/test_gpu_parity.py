@@ -1631,16 +1631,17 @@ def test_split_rows_small_steps_vs_reference_run_vectors(n_units, group):
 
 @pytest.mark.parametrize("n_units", [1, 2, 16, 32, 64, 65, 128])
 def test_engine_default_small_16k_steps_read_the_spectral_rows(n_units):
-    """AudioEngine(rir_spectral=None) at 16 kHz keeps both bank forms; launches of <= 64 units (the reference
-    steps 5-10 envs per GPU) read the spectral rows (no forward FFT: k_conv_spec, split rows), larger ones the time-domain rows -
-    chosen per launch in the Python planner path (engine.observe), in the C++ context (observe_columns: ss_ctx_set_spectral_policy)
-    and for the eager call.  Every unit is a reference-run case; rows loaded before a LARGE step get their block spectra only when a
-    small step needs them."""
+    """AudioEngine(rir_spectral=None) at 16 kHz keeps both bank forms.  With a per-launch threshold
+    (spectral_max_units=64; the default since the same-box sweep of profiles/r6/kbench_bank_form_16k.txt is 0 = the spectral rows for
+    every launch) launches of <= 64 units read the spectral rows (no forward FFT: k_conv_spec, split rows), larger ones the
+    time-domain rows - chosen per launch in the Python planner path (engine.observe), in the C++ context (observe_columns:
+    ss_ctx_set_spectral_policy) and for the eager call.  Every unit is a reference-run case; rows loaded before a LARGE step get
+    their block spectra only when a small step needs them."""
     from ss_amd.renderer import AudioEngine, UnitRequest
     names = [c for c in SIM_CASES if case_inputs(c)["rir"].shape[0] <= 16000 and len(case_inputs(c)["source"]) == 16000]
     assert len(names) >= 3
     ins = [case_inputs(c) for c in names]
-    eng = AudioEngine(16000, device=DEV, rir_slots=32)
+    eng = AudioEngine(16000, device=DEV, rir_slots=32, spectral_max_units=64)
     assert eng.rir_spectral and eng.store.spectral and eng.renderer._spectral_for(64) and not eng.renderer._spectral_for(65)
     sids = [eng.source_id(f"s{k}", d["source"]) for k, d in enumerate(ins)]
     slots = [eng.rir_slot(f"r{k}.wav", (lambda d=d: d["rir"])) for k, d in enumerate(ins)]
@@ -1672,8 +1673,9 @@ def test_engine_keeps_the_spectral_form_by_default_at_the_replica_rate():
     engines (live RIRs) and stores that would not fit stay on the time-domain kernels.  Same observation either way."""
     from ss_amd.renderer import AudioEngine, UnitRequest
     assert AudioEngine(44100, device=DEV, rir_slots=16).rir_spectral
-    e16 = AudioEngine(16000, device=DEV, rir_slots=16)          # round 6: kept at 16 kHz too, for SMALL steps only (next test)
-    assert e16.rir_spectral and e16.spectral_max_units == 64 and AudioEngine(44100, device=DEV, rir_slots=16).spectral_max_units == 0
+    e16 = AudioEngine(16000, device=DEV, rir_slots=16)          # round 6: kept at 16 kHz too (faster at every step size)
+    assert e16.rir_spectral and e16.spectral_max_units == 0 and AudioEngine(44100, device=DEV, rir_slots=16).spectral_max_units == 0
+    assert AudioEngine(16000, device=DEV, rir_slots=16, spectral_max_units=64).spectral_max_units == 64
     assert not AudioEngine(16000, device=DEV, rir_slots=16, rir_spectral=False).rir_spectral
     assert not AudioEngine(44100, device=DEV, rir_slots=16, step_time=0.25, wrap=True).rir_spectral
     assert not AudioEngine(44100, device=DEV, rir_slots=16, spectral_hbm_fraction=1e-9).rir_spectral
