@@ -1131,7 +1131,7 @@ def main():
                     f"{n_env} envs/GPU x {rot} rotation(s) = {N} units/launch, sr={sr}, " +
                     ("" if savi else f"1-s source clips ({args.sounds} sounds), ") +
                     f"2-ch RIR L={L}, RIR bank {R} entries ({R * 2 * L * 4 >> 20} MiB/GPU, HBM-resident"
-                    f"{', stored as block spectra: ' + str(R * 2 * 2 * P.SPEC_FLOATS * 4 >> 20) + ' MiB' if args.spectral else ''}), "
+                    f"{', stored as block spectra: ' + str(R * 2 * P.ceil_div(L, P.KB) * P.SPEC_FLOATS * 4 >> 20) + ' MiB' if args.spectral else ''}), "
                     "cache-miss path, spectrogram [65,%d,2] f32 out" % t4)
         out = {
             "metric": "audio env-steps/sec (RIR-convolve+spectrogram) per node, 128 envs Replica 16 kHz",
