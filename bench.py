@@ -1054,8 +1054,9 @@ def main():
         #   exchange_none  no collective (the reference's DD-PPO arrangement: every rank's learner consumes its own slab)
         #   allgather      RCCL all_gather_into_tensor of the step slabs, a chunk of --gather-every steps at a time
         #   gather         peer copies to ONE learner rank (PeerCopyExchange(learners=[0]): xGMI writes, no collective)
+        # (the peer-copy arrangement last: everything that only needs RCCL is measured before the IPC transport is set up)
         for key, mode, ge in (("exchange_none", "none", 0), ("allgather", "allgather", args.gather_every),
-                              ("gather", "gather", args.gather_every), ("exchange_per_step_gather", args.exchange, 1)):
+                              ("exchange_per_step_gather", args.exchange, 1), ("gather", "gather", args.gather_every)):
             if mode == args.exchange and ge == G_head:
                 side[key] = dict(rate(elapsed), note="= the headline of this run")
                 continue
