@@ -185,7 +185,15 @@ class AudioGoalDataset(_TorchDataset):
         eng = self.engine
         if out is None:
             out = torch.empty((len(items),) + P.spectrogram_shape(self.rir_sampling_rate), dtype=torch.float32, device=self.device)
-        eng.observe_columns(self.unit_columns(items, indices), spectrogram_out=out)     # (load_files opens the store's batch)
+        room = int(getattr(eng.store, "slots", len(items)))
+        lo = 0
+        while lo < len(items):                                    # (a mini-batch with more distinct RIR files than the store has
+            seen, hi = set(), lo                                  #  entries is rendered in as many launches as it takes)
+            while hi < len(items) and (len(seen) < room or self.files[items[hi]][0] in seen):
+                seen.add(self.files[items[hi]][0])
+                hi += 1
+            eng.observe_columns(self.unit_columns(items[lo:hi], indices[lo:hi]), spectrogram_out=out[lo:hi])   # (load_files opens the store's batch)
+            lo = hi
         return out
 
     def __getitem__(self, item):

@@ -148,6 +148,12 @@ def test_unit_columns_and_the_oracle_against_the_reference_run_audiogoals(tree):
     # in for the kernels: every item of the seeded loader against the reference-run spectrograms
     got = torch.cat([inputs[0] for inputs, _ in ds.loader(batch_size=9, seed=11)]).numpy()
     assert max(O.relerr(got[i], GOLD["items/spectrogram"][i]) for i in range(26)) < 1e-5
+    # a store of 8 entries under a mini-batch of 26 items (24 distinct files): rendered in several steps, same numbers
+    random.seed(7)
+    small = OracleColumnEngine(16000, slots=8)
+    ds_s = make(tree, engine=small)
+    got_s = torch.cat([inputs[0] for inputs, _ in ds_s.loader(batch_size=26, seed=11)]).numpy()
+    assert small.column_calls >= 3 and max(O.relerr(got_s[i], GOLD["items/spectrogram"][i]) for i in range(26)) < 1e-5
 
 
 def test_missing_labels_and_one_second_clips_fail_like_the_reference(tree):
@@ -186,3 +192,8 @@ def test_items_and_batches_on_the_gpu_equal_the_reference_run(tree):
     ds3 = make(tree, device="cuda:0", rir_slots=8)
     got3 = torch.cat([inputs[0] for inputs, _ in ds3.loader(batch_size=5, seed=11)]).cpu().numpy()
     assert np.array_equal(got3, got) or max(O.relerr(got3[i], ref[i]) for i in range(26)) < 1e-4
+    # ... and a mini-batch with more distinct files than the store has entries: several launches, same numbers
+    random.seed(7)
+    ds4 = make(tree, device="cuda:0", rir_slots=8)
+    got4 = torch.cat([inputs[0] for inputs, _ in ds4.loader(batch_size=26, seed=11)]).cpu().numpy()
+    assert max(O.relerr(got4[i], ref[i]) for i in range(26)) < 1e-4
