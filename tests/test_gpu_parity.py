@@ -1689,3 +1689,28 @@ def test_engine_keeps_the_spectral_form_by_default_at_the_replica_rate():
         out = eng.observe([UnitRequest(sid, 0, slot)], want_audiogoal=True)
         check(out["audiogoal"][0].cpu().numpy()[:, ::stride], ref_a)
         check(out["spectrogram"][0].cpu().numpy(), ref_s)
+
+
+@pytest.mark.parametrize("sr", [22050, 32000])
+@pytest.mark.parametrize("n_units", [1, 7])
+def test_rows_of_two_blocks_at_other_rates_small_steps(sr, n_units):
+    """Rows of two partition blocks (22.05 / 32 kHz: not rates the reference ships configs for, but `RIR_SAMPLING_RATE` is a config
+    key) through the small-step kernel (k_obs_blocks: one workgroup per output block) on both bank forms, with and without the
+    waveform: every unit against the oracle (simulator.py:629-632 + nav.py:86-100)."""
+    from ss_amd.renderer import UnitRequest
+    rng = np.random.default_rng(sr + n_units)
+    srcs = O.synth_sources(rng, sr, k=2)
+    h = O.synth_rir(rng, sr, n=3)
+    for spectral in (False, True):
+        r = make_renderer(sr, list(srcs), [np.ascontiguousarray(x.T) for x in h])
+        if spectral:
+            r.rirs.build_spectra()
+        units = [UnitRequest(n % 2, 0, n % 3) for n in range(n_units)]
+        ag, sg = r.render(r.plan(units), want_audiogoal=True)
+        sg_only = r.render(r.plan(units))[1]
+        ag, sg, sg_only = ag.cpu().numpy(), sg.cpu().numpy(), sg_only.cpu().numpy()
+        for n in range(n_units):
+            ref = O.compute_audiogoal(srcs[n % 2], np.ascontiguousarray(h[n % 3].T), sr)
+            check(ag[n], ref)
+            check(sg[n], O.compute_spectrogram(ref.astype(np.float32)))
+            check(sg_only[n], O.compute_spectrogram(ref.astype(np.float32)))

@@ -826,3 +826,23 @@ def test_one_workgroup_per_output_block_equals_the_row_kernel(parts_log2, varian
     check(s2[0], ref_s)
     check(a2[0][:, ::stride], ref_a)
     assert not s2[1].any() and not a2[1].any()
+
+
+@pytest.mark.parametrize("sr", [22050, 32000, 48000])
+def test_one_workgroup_per_output_block_at_other_rates(sr):
+    """k_obs_blocks on rows of two blocks (22.05 kHz), of exactly two blocks' worth of pooled columns (32 kHz: the last block
+    completes a single pooled block more than the first) and of three blocks at 48 kHz: against the oracle (simulator.py:629-632
+    + nav.py:86-100) and against k_obs_rows."""
+    rng = np.random.default_rng(sr)
+    src = O.synth_sources(rng, sr, k=1)[0]
+    h = O.synth_rir(rng, sr, n=2)
+    bank = np.ascontiguousarray(h)
+    units = [dict(sound=0, t0=0, rir=0), dict(sound=0, t0=0, rir=1)]
+    kw = dict(fuse=True, row_wgs=64)
+    a1, s1 = hs.run([src], bank, [sr, sr], units, sr, sr, **kw)
+    a2, s2 = hs.run([src], bank, [sr, sr], units, sr, sr, row_blocks=True, parts_log2=1, **kw)
+    for n in range(2):
+        ref = O.compute_audiogoal(src, np.ascontiguousarray(h[n].T), sr)
+        check(a2[n], ref)
+        check(s2[n], O.compute_spectrogram(ref.astype(np.float32)))
+        assert O.relerr(s2[n], s1[n]) < 2e-6 and O.relerr(a2[n], a1[n]) < 2e-6
