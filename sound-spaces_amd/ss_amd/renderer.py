@@ -80,15 +80,16 @@ class RirBank:
 
     @staticmethod
     def from_arrays(rirs: Sequence[Optional[np.ndarray]], device, cap: Optional[int] = None) -> "RirBank":
-        """rirs[i]: float array [L, 2] (wav layout, what scipy.io.wavfile.read returns) or [2, L];
-        None or an empty array = unreadable / empty file -> zero RIR (simulator.py:619-624)."""
+        """rirs[i]: float array [L, 2] (wav layout, what scipy.io.wavfile.read returns) or [2, L] (a [2, 2] array is read
+        as the wav layout: a file of two samples); None or an empty array = unreadable / empty file -> zero RIR
+        (simulator.py:619-624)."""
         norm = []
         for r in rirs:
             if r is None or np.size(r) == 0:
                 norm.append(np.zeros((2, 0), np.float32))
                 continue
             r = np.asarray(r, dtype=np.float32)
-            norm.append(np.ascontiguousarray(r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r))
+            norm.append(np.ascontiguousarray(r.T if (r.ndim == 2 and r.shape[1] == 2) else r))
         longest = max([a.shape[1] for a in norm] + [2])
         cap = cap or longest
         cap += cap & 1                       # even capacity: 8-byte aligned rows for the float2 loads
@@ -424,11 +425,11 @@ class BatchedAudioRenderer:
 
 
 def _planar(rir) -> np.ndarray:
-    """float32 [2, L] from a wav-layout [L, 2] / planar [2, L] array; None / empty -> [2, 0]."""
+    """float32 [2, L] from a wav-layout [L, 2] / planar [2, L] array ([2, 2] = wav layout); None / empty -> [2, 0]."""
     if rir is None or not np.size(rir):
         return np.zeros((2, 0), np.float32)
     r = np.asarray(rir, dtype=np.float32)
-    return r.T if (r.ndim == 2 and r.shape[1] == 2 and r.shape[0] != 2) else r
+    return r.T if (r.ndim == 2 and r.shape[1] == 2) else r
 
 
 class RirStore:

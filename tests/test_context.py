@@ -525,3 +525,17 @@ def test_observe_features_equals_observe_then_feature_kernels(overlap):
     assert torch.equal(sg, want[0][1])
     with pytest.raises(Exception):                                             # the features read the waveform: no audiogoal, no call
         ctx.observe_prepared_features(ctx.prepare(**cols[0]), sg.data_ptr(), None, stream, got[0][4])
+
+
+def test_two_sample_rir_is_read_as_wav_layout():
+    """A [2, 2] array is ambiguous between the wav layout [L, 2] and the planar [2, L]; `wavfile.read` (simulator.py:615)
+    returns the wav layout, so that is what a 2 x 2 array means (found by scripts/gpu_fuzz.py: a two-tap RIR came out
+    transposed)."""
+    from ss_amd.renderer import RirBank, _planar
+    h = np.array([[1.0, 2.0], [3.0, 4.0]], np.float32)               # sample 0 = (L 1, R 2), sample 1 = (L 3, R 4)
+    bank = RirBank.from_arrays([h, np.arange(6, dtype=np.float32).reshape(3, 2), np.arange(6, dtype=np.float32).reshape(2, 3)], "cpu")
+    assert bank.data[0, :, :2].tolist() == [[1.0, 3.0], [2.0, 4.0]]
+    assert bank.data[1, :, :3].tolist() == [[0.0, 2.0, 4.0], [1.0, 3.0, 5.0]]
+    assert bank.data[2, :, :3].tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]
+    assert bank.lengths.tolist() == [2, 3, 3]
+    assert _planar(h).tolist() == [[1.0, 3.0], [2.0, 4.0]]
