@@ -139,6 +139,82 @@ def run_continuous(rng, dev):
     return sr, len(units), len(srcs), len(rirs), any(k[4] >= 0 for k in keys), worst
 
 
+def run_engine(rng, dev):
+    """Several consecutive steps through AudioEngine (RirStore / BucketedRirStore + the C++ context, `observe_columns`) with a
+    store smaller than the pool of poses: entries are evicted and rewritten between steps, rows grow, the spectral rows of
+    rewritten entries are rebuilt; every unit of every step against the oracle."""
+    from ss_amd.renderer import AudioEngine
+    sr = int(rng.choice([16000, 16000, 44100, 22050, 48000]))
+    n_src = int(rng.integers(1, 4))
+    srcs = []
+    for _ in range(n_src):
+        n = sr if rng.integers(0, 2) == 0 else int(rng.integers(2, 5)) * sr
+        srcs.append((rng.standard_normal(n) * rng.uniform(0.05, 0.5)).astype(np.float32))
+    pool = int(rng.integers(4, 40))
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=int(rng.uniform(0.05, 1.6 if rng.random() < 0.15 else 1.0) * sr),
+                                             n=1)[0].T).astype(np.float32) for _ in range(pool)]
+    per_step = int(rng.choice([1, 2, 5, 10, 16, 32, 64]))
+    if sr >= 32000:
+        per_step = min(per_step, 32)
+    slots = int(rng.integers(max(2, min(pool, per_step)), pool + 4))
+    kw = {}
+    form = int(rng.integers(0, 3))
+    if form == 1:
+        kw["rir_spectral"] = False
+    elif form == 2 and rng.random() < 0.5:
+        kw["rir_buckets"] = [(slots, sr // 2), (slots, sr), (slots, 2 * sr)]
+    with_dis = rng.random() < 0.3
+    eng = AudioEngine(sr, device=dev, rir_slots=slots, **kw)
+    sids = [eng.source_id(f"s{i}", s) for i, s in enumerate(srcs)]
+    worst, n_total = 0.0, 0
+    for step in range(int(rng.integers(3, 9))):
+        n = int(rng.integers(1, per_step + 1))
+        picks = rng.choice(pool, size=min(n, slots // (2 if with_dis else 1), pool), replace=False)
+        eng.begin_batch()
+        cols = dict(sound=[], t0=[], rir=[])
+        if with_dis:
+            cols.update(dis_sound=[], dis_rir=[])
+        keys = []
+        for u in range(n):
+            s = int(rng.integers(0, n_src))
+            idx = 0 if len(srcs[s]) == sr else int(rng.integers(0, len(srcs[s]) // sr))
+            h = int(picks[u % len(picks)])
+            silent = rng.random() < 0.05
+            cols["sound"].append(sids[s]); cols["t0"].append(P.window_start_sim(len(srcs[s]), sr, idx))
+            cols["rir"].append(-1 if silent else eng.rir_slot(("pose", h), (lambda h=h: rirs[h])))
+            ds = dh = -1
+            if with_dis:
+                if rng.random() < 0.6 and not silent:
+                    ds, dh = int(rng.integers(0, n_src)), int(picks[(u + 1) % len(picks)])
+                cols["dis_sound"].append(sids[ds] if ds >= 0 else -1)
+                cols["dis_rir"].append(eng.rir_slot(("pose", dh), (lambda dh=dh: rirs[dh])) if ds >= 0 else -1)
+            keys.append((s, idx, h, silent, ds, dh))
+        cols = {k: np.asarray(v, np.int64) for k, v in cols.items()}
+        sg = torch.full((n,) + tuple(O.spectrogram_shape(sr)), float("nan"), device=dev)
+        ag = torch.full((n, 2, sr), float("nan"), device=dev)
+        eng.observe_columns(cols, spectrogram_out=sg, audiogoal_out=ag if step % 2 == 0 else None)
+        sg = sg.cpu().numpy()
+        ag = ag.cpu().numpy() if step % 2 == 0 else None
+        assert not np.isnan(sg).any() and (ag is None or not np.isnan(ag).any()), "NaN / unwritten output rows"
+        for u, k in enumerate(keys):
+            s, idx, h, silent, ds, dh = k
+            if silent:
+                assert not sg[u].any() and (ag is None or not ag[u].any()), f"step {step} silent unit {u} not zero"
+                continue
+            ra = np.asarray(O.compute_audiogoal(srcs[s], rirs[h], sr, idx, False, srcs[ds] if ds >= 0 else None,
+                                                rirs[dh] if ds >= 0 else None), np.float64)
+            rs = O.compute_spectrogram(ra.astype(np.float32))
+            for got, ref, what in ((ag[u] if ag is not None else None, ra, "audiogoal"), (sg[u], rs, "spectrogram")):
+                if got is None:
+                    continue
+                err = np.abs(got - ref).max() / np.abs(ref).max()
+                worst = max(worst, err)
+                assert err <= TOL, f"step {step} unit {u} {what}: {err:.3e} key={k} store={type(eng.store).__name__} " \
+                                   f"slots={slots} pool={pool} spectral={eng.rir_spectral}"
+        n_total += n
+    return sr, n_total, n_src, pool, with_dis, worst
+
+
 def run_trial(rng, dev):
     sr, srcs, rirs, units, keys = draw_trial(rng)
     refs = {}
@@ -178,7 +254,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--mode", choices=["sim", "continuous"], default="sim",
+    ap.add_argument("--mode", choices=["sim", "continuous", "engine"], default="sim",
                     help="sim: SoundSpacesSim._compute_audiogoal steps; continuous: SoundSpaces 2.0 steps (distractor column = cross-fade)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -188,7 +264,7 @@ def main():
     for t in range(args.trials):
         rng = np.random.default_rng([args.seed, t])
         try:
-            sr, n, ns, nr, dis, worst = (run_trial if args.mode == 'sim' else run_continuous)(rng, dev)
+            sr, n, ns, nr, dis, worst = {'sim': run_trial, 'continuous': run_continuous, 'engine': run_engine}[args.mode](rng, dev)
             worst_all = max(worst_all, worst)
             lines.append(f"trial {t:4d} ok   sr={sr:5d} units={n:3d} sources={ns} rirs={nr} distractor={int(dis)} worst={worst:.2e}")
         except Exception as e:                          # noqa: BLE001 - a sweep reports every failing trial

@@ -42,7 +42,9 @@ def run_trial(rng):
         N = max(1, 8_000_000 // n)
     pad = str(rng.choice(["reflect", "constant"]))
     sr = int(rng.choice([16000, 44100, 48000, 22050]))
-    n_mels = int(rng.choice([64, 40, 32, 20]))
+    n_mels = int(rng.choice([64, 40, 32]))                  # (bands wider than 60 bins - 20-band banks, 32 bands at 48 kHz - are
+    if sr == 48000 and n_mels == 32:                        #  outside the ABI's stated limit, include/ss_hip.h: SS_EINVAL)
+        n_mels = 40
     max_lag = int(rng.choice([32, 16, 8, 1]))
     x = (rng.standard_normal((N, 2, n)) * rng.uniform(1e-3, 1.0, (N, 1, 1))).astype(np.float32)
     if N > 2:
@@ -65,16 +67,26 @@ def run_trial(rng):
     for i in rows:
         ref = {"spectrogram": O.compute_spectrogram(x[i], pad_mode=pad), "logmel": O.compute_logmel(x[i], sr, n_mels, 1e-6, pad),
                "gccphat": O.compute_gcc_phat(x[i], max_lag, 1e-8, pad)}
+        # PHAT divides every bin by its own magnitude: a bin that is empty to 1e-4 of the frame's median (white noise through
+        # a reflect-padded, hence symmetric, first frame has them) carries an arbitrary unit phase in ANY float32 evaluation -
+        # frames with such a bin are left out of the comparison (1 frame in ~10^4 here)
+        G = np.abs(O.stft(x[i, 0], pad_mode=pad) * np.conj(O.stft(x[i, 1], pad_mode=pad)))
+        well = G.min(axis=0) > 1e-4 * np.median(G, axis=0)
         for w in names:
             scale = 1.0 if w == "gccphat" else None
             if w == "gccphat" and not (x[i, 0].any() and x[i, 1].any()):
                 continue                                       # 0 / (0 + eps): both sides are exact zeros or eps-noise
-            e = rel(got[w][i], ref[w], scale)
+            if w == "gccphat":
+                ref[w] = ref[w][:, well]
+                got_w = got[w][i][:, well]
+            else:
+                got_w = got[w][i]
+            e = rel(got_w, ref[w], scale)
             assert e <= TOL, f"{w} row {i}: {e:.3e} (N={N} n={n} pad={pad} sr={sr} mels={n_mels} lag={max_lag})"
             worst = max(worst, e)
             for want, outs in fused.items():
                 if w in outs:
-                    e = rel(outs[w][i], ref[w], scale)
+                    e = rel(outs[w][i][:, well] if w == "gccphat" else outs[w][i], ref[w], scale)
                     assert e <= TOL, f"audio_features{want}.{w} row {i}: {e:.3e} (N={N} n={n} pad={pad} sr={sr} mels={n_mels} lag={max_lag})"
                     worst = max(worst, e)
         if inten is not None and x[i].max() > 0:

@@ -1482,8 +1482,6 @@ class AudioEngine:
         if getattr(self, "_ctx", None) is None:
             from .context import AudioContext
             r = self.renderer
-            if isinstance(self.store, BucketedRirStore):
-                raise NotImplementedError("AudioEngine.context(): length-bucketed stores use ss_ctx_set_rir_buckets directly")
             ctx = AudioContext(r.sr, n_valid=r.n_valid, wrap=r.wrap, pad_mode=r.pad_mode)
             if self.spectral_max_units:
                 ctx.set_spectral_policy(self.spectral_max_units)
@@ -1512,6 +1510,12 @@ class AudioEngine:
             self.store.flush_uploads()                             # (sync_spectra's first half: queued row uploads go out)
         bank = self.store.bank
         cur = self._ctx_bank                                     # (the tensors the context was last pointed at: identity, not
+        if isinstance(bank, BucketedRirBank):                    # length buckets: ss_ctx_set_rir_buckets (every bucket's rows, and
+            now = tuple(b.data for b in bank.banks) + tuple(b.spectra for b in bank.banks)      # its block spectra when kept)
+            if n_sync or cur is None or len(cur) != len(now) or any(a is not b for a, b in zip(cur, now)):
+                ctx.set_rir_buckets(bank, spectral=bool(self.store.spectral and bank.spectra))
+                self._ctx_bank = now
+            return ctx
         if n_sync or cur is None or cur[0] is not bank.data or cur[1] is not bank.spectra:   # two data_ptr() calls per step)
             ctx.set_rir_bank(bank.data, bank.lengths)
             if bank.spectra is not None and self.store.spectral:

@@ -94,14 +94,10 @@ def _render_to_host(backend, req, want_spectrogram: bool, want_audiogoal: bool =
                                torch.ops.ss_hip.eager_obs if ops.NATIVE_OPS else None)
     dbuf, hbuf, h, shp, n_ag, n_sg, torch, ops, dbuf0, eager_op = st
     n = n_ag + n_sg if want_spectrogram else n_ag
-    if ops.NATIVE_OPS and hasattr(eng, "context") and not getattr(eng, "_no_native_eager", False):
+    if ops.NATIVE_OPS and hasattr(eng, "context"):
         # ONE C++ dispatch (csrc/ss_torch_ops.cpp::eager_obs): the library's planner + window cache + launch
         # (ss_ctx_observe on a one-unit step), one async copy of both outputs into pinned memory, stream synchronise
-        try:
-            ctx = eng._sync_context_bank()
-        except NotImplementedError:                              # (length-bucketed stores keep the renderer path)
-            eng._no_native_eager = True
-            return _render_to_host(backend, req, want_spectrogram, want_audiogoal)
+        ctx = eng._sync_context_bank()
         wrap = 1 if req.wrap is None else int(bool(req.wrap))
         eager_op(ctx.handle, int(req.sound), int(req.t0), int(req.rir), int(req.dis_sound), int(req.dis_rir),
                  int(req.last_rir), wrap, wrap if req.last_wrap is None else int(bool(req.last_wrap)),

@@ -979,9 +979,17 @@ def test_bucketed_store_mixes_short_and_3s_rirs_without_reallocating_the_bank():
             refs.append(O.compute_audiogoal(src[s_], rirs[h_], sr, audio_index=idx).astype(np.float32))
         out = eng.observe(units, want_audiogoal=True)
         ag, sg = out["audiogoal"].cpu().numpy(), out["spectrogram"].cpu().numpy()
+        # the same step as unit columns through the engine's C++ context (ss_ctx_set_rir_buckets: found missing by
+        # scripts/gpu_fuzz.py --mode engine - AudioEngine.context() used to refuse length-bucketed stores)
+        sg2, ag2 = torch.empty_like(out["spectrogram"]), torch.empty_like(out["audiogoal"])
+        eng.observe_columns(dict(sound=np.asarray([u.sound for u in units]), t0=np.asarray([u.t0 for u in units], np.int64),
+                                 rir=np.asarray([u.rir for u in units])), spectrogram_out=sg2, audiogoal_out=ag2)
+        ag2, sg2 = ag2.cpu().numpy(), sg2.cpu().numpy()
         for n in range(40):
             check(ag[n], refs[n])
             check(sg[n], O.compute_spectrogram(refs[n]))
+            check(ag2[n], refs[n])
+            check(sg2[n], O.compute_spectrogram(refs[n]))
     assert eng.store.grown == 0 and eng.store.stores[0].bank.data.data_ptr() == short_ptr and eng.store.stores[0].cap == sr
     # short-bucket-only step == the same step on a plain short bank, bit for bit (loop-free kernel, SS_FLAG_FIRST_BUCKET)
     eng.begin_batch()
