@@ -287,8 +287,12 @@ int ss_ctx_observe_features(ss_ctx* ctx, const ss_units* units, int n, float* au
  * overlaps the tail of step k (STFT: no memory traffic) - what the reference's serial per-env loop
  * (ss_baselines/common/sync_vector_env.py:397-410) cannot do.  Results become visible to a stream through
  * ss_ctx_join(ctx, stream) (the stream waits for every step issued so far); a caller that needs step k before it issues
- * step k+1 joins every step and gets the single-stream behaviour.  n_streams = 1 switches back (synchronises the device).
- * Steps must write disjoint output rows while they are in flight (rollout rows are).
+ * step k+1 joins every step and gets the single-stream behaviour (joins from several streams each wait).  n_streams = 1
+ * switches back (synchronises the device).
+ * Steps must write disjoint output rows while they are in flight (rollout rows are), and a caller that REWRITES bank rows
+ * (eviction: a new pose's RIR over an old entry) while steps are in flight joins first on the stream that carries the
+ * rewrite - a step still running on a lane may read the old entry.  The library's own loaders (ss_ctx_observe_requests_load,
+ * ss_ctx_load_rir_files) order their scatter behind every step issued so far themselves.
  * Threading: the ordering behind the caller's stream is elided when that stream is IDLE at the time of the call (one
  * hipStreamQuery instead of an event record + a stream wait).  That test is only sound for a single-threaded user of `stream`:
  * a second host thread that enqueues work on the same stream between the query and the lane's launch is NOT ordered in front

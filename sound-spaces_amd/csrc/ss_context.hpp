@@ -115,7 +115,10 @@ struct Context {
     int spectral_max_units = 0;         // ss_ctx_set_spectral_policy: one-block rows take the spectral bank only for steps of <= this many units (0: always)
     int chip_share = 0;                 // ss_ctx_set_chip_share: launch sources the chip is shared with (0: the lane count)
     hipStream_t lane_stream[kLanes] = {};
-    bool lane_dirty[kLanes] = {};                 // work issued on the lane since the last ss_ctx_join
+    bool lane_dirty[kLanes] = {};                 // work issued on the lane since ev_lane was last recorded
+    bool lane_joined[kLanes] = {};                // ev_lane holds a record ("everything issued on the lane so far")
+    bool lane_join_valid[kLanes] = {};            // ... and lane_join_stream is the stream that waited for that record last
+    hipStream_t lane_join_stream[kLanes] = {};
     hipEvent_t ev_lane[kLanes] = {};              // join: "everything issued on the lane so far"
     hipEvent_t ev_in = nullptr;                   // the caller's stream at the time of the call
     hipEvent_t ev_win[kLanes] = {};               // after the lane's latest k_source_windows launch

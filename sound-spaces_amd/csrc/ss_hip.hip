@@ -1315,7 +1315,7 @@ int ss_ctx_set_overlap(ss_ctx* h, int n_streams) {
     c.ring_k = 0;                                              // groups start afresh (everything has completed)
     c.group_open = false;
     c.have_last_stream = false;
-    for (int l = 0; l < ssctx::kLanes; ++l) { c.lane_dirty[l] = false; for (int o = 0; o < ssctx::kLanes; ++o) c.win_seen[l][o] = c.win_seq[o]; }
+    for (int l = 0; l < ssctx::kLanes; ++l) { c.lane_dirty[l] = false; c.lane_joined[l] = false; c.lane_join_valid[l] = false; for (int o = 0; o < ssctx::kLanes; ++o) c.win_seen[l][o] = c.win_seq[o]; }
     return 0;
 }
 
@@ -1337,11 +1337,34 @@ int ss_ctx_join(ss_ctx* h, void* stream) {
     if (c.n_lanes <= 1) return 0;                              // single-stream mode: the caller's stream IS the work's stream
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int l = 0; l < c.n_lanes; ++l) {
-        if (!c.lane_dirty[l]) continue;
-        hipError_t e = hipEventRecord(c.ev_lane[l], c.lane_stream[l]);
+        // a lane with nothing issued since its last join: its event still stands for "everything on the lane" - a join from
+        // ANOTHER stream waits for that record, the stream that joined last has nothing left to wait for
+        if (!c.lane_dirty[l] && (!c.lane_joined[l] || (c.lane_join_valid[l] && c.lane_join_stream[l] == st))) continue;
+        hipError_t e = c.lane_dirty[l] ? hipEventRecord(c.ev_lane[l], c.lane_stream[l]) : hipSuccess;
         if (e == hipSuccess) e = hipStreamWaitEvent(st, c.ev_lane[l], 0);
         if (e != hipSuccess) return hip_err(e);
         c.lane_dirty[l] = false;
+        c.lane_joined[l] = true;
+        c.lane_join_valid[l] = true;
+        c.lane_join_stream[l] = st;
+    }
+    return 0;
+}
+
+// Overlap mode: work on `st` that REWRITES bank rows (the in-call loaders' scatter) goes behind every step issued so far - steps
+// in flight on the lanes may still read the entries (write after read).  The lanes' join state is left alone.
+static int order_behind_lanes(ssctx::Context& c, hipStream_t st) {
+    if (c.n_lanes <= 1) return 0;
+    for (int l = 0; l < c.n_lanes; ++l) {
+        if (!c.lane_dirty[l] && !c.lane_joined[l]) continue;
+        hipError_t e = c.lane_dirty[l] ? hipEventRecord(c.ev_lane[l], c.lane_stream[l]) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c.ev_lane[l], 0);
+        if (e != hipSuccess) return hip_err(e);
+        if (c.lane_dirty[l]) {                                 // the record now covers the lane's work: a later join re-uses it
+            c.lane_dirty[l] = false;
+            c.lane_joined[l] = true;
+            c.lane_join_valid[l] = false;                      // (no stream has JOINED: every join still waits)
+        }
     }
     return 0;
 }
@@ -1623,6 +1646,9 @@ static int loader_load_paths(ssctx::Context& c, ss_miss_loader* ld, const char* 
                      ld->threads > 0 ? ld->threads : 1);
     for (int i = 0; i < k; ++i)
         if (status[i] != sswav::kOk && status[i] != sswav::kEmpty) return 1;     // scipy's semantics are the caller's reader's
+#if !defined(SS_AB_NO_LOADER_LANE_ORDER)                       // (A/B builds: tests/test_wav_loader.py's write-after-read case fails without)
+    if (order_behind_lanes(c, st)) return 1;                   // (overlap mode: steps in flight may read the entries rewritten below)
+#endif
     // ---- commit
     for (size_t i = 0; i < victims.size(); ++i) ld->evicted_slot[i] = victims[i];
     ld->n_evicted = static_cast<int>(victims.size());

@@ -441,3 +441,52 @@ def test_eager_calls_read_new_poses_with_the_library_s_reader(wavs, tmp_path):
     sim._spectrogram_cache.clear(); sim._audiogoal_cache.clear()
     sg_s.get_observation(observations=None, episode=None)
     assert eng.store.misses == len(names)
+
+
+@pytest.mark.gpu
+def test_in_call_loader_orders_its_scatter_behind_steps_in_flight(tmp_path):
+    """Overlap mode (ss_ctx_set_overlap) + a store of three entries: thirty large steps that read entry A are queued on the lanes,
+    then a new pose is loaded by the library's own loader (ss_ctx_load_rir_files through ``AudioEngine.rir_file_slot``), which
+    evicts the least recently used entry - A - while those steps are still in flight.  The scatter goes on the caller's stream:
+    it has to wait for the lanes (write after read), or the queued steps render the NEW pose's RIR."""
+    import torch
+    from oracle import ss_oracle as O
+    from ss_amd.renderer import AudioEngine
+    from ss_amd.sim_audio import wav_rir_reader
+    sr, n_units, n_steps = 16000, 512, 30
+    rng = np.random.default_rng(21)
+    paths = []
+    for k in range(4):
+        p = str(tmp_path / f"{k}_0.wav")
+        wavfile.write(p, sr, np.ascontiguousarray(O.synth_rir(rng, sr, length=16000, n=1)[0].T))
+        paths.append(p)
+    clip = O.synth_sources(rng, sr, k=1)[0]
+    eng = AudioEngine(sr, device="cuda:0", rir_slots=3)
+    sid = eng.source_id("s", clip)
+    slots = []
+    for p in paths[:3]:
+        eng.begin_batch()
+        slots.append(eng.rir_file_slot(p, wav_rir_reader))
+    ctx = eng.context()
+    cols = dict(sound=np.full(n_units, sid), t0=np.zeros(n_units, np.int64), rir=np.full(n_units, slots[0]))
+    ref = torch.empty((n_units, 65, 26, 2), device="cuda:0")
+    eng.observe_columns(cols, spectrogram_out=ref)
+    torch.cuda.synchronize()
+    ctx.set_overlap(2)
+    out = torch.zeros((n_steps, n_units, 65, 26, 2), device="cuda:0")
+    torch.cuda.synchronize()
+    for k in range(n_steps):
+        eng.observe_columns(cols, spectrogram_out=out[k])
+    eng.begin_batch()
+    new = eng.rir_file_slot(paths[3], wav_rir_reader)               # evicts A (= slots[0]) inside ONE C call, steps still queued
+    assert new == slots[0] and eng.store.misses == 4
+    ctx.join()
+    torch.cuda.synchronize()
+    for k in range(n_steps):
+        assert torch.equal(out[k], ref), k
+    sg = torch.empty((1, 65, 26, 2), device="cuda:0")               # ... and the new pose renders from the rewritten entry
+    eng.observe_columns(dict(sound=np.array([sid]), t0=np.zeros(1, np.int64), rir=np.array([new])), spectrogram_out=sg)
+    ctx.join()
+    torch.cuda.synchronize()
+    a = O.compute_audiogoal(clip, wav_rir_reader(paths[3]), sr)
+    assert O.relerr(sg[0].cpu().numpy(), O.compute_spectrogram(a.astype(np.float32))) < 1e-4
