@@ -167,7 +167,16 @@ def run_engine(rng, dev):
     eng = AudioEngine(sr, device=dev, rir_slots=slots, **kw)
     sids = [eng.source_id(f"s{i}", s) for i, s in enumerate(srcs)]
     worst, n_total = 0.0, 0
+    # overlap mode (ss_ctx_set_overlap): the steps alternate between 2-3 internal streams and NOTHING is read back before the last
+    # step was issued; the store uploads rows on the caller's stream, so - as include/ss_hip.h asks - the caller joins before a
+    # step that may rewrite entries (the lanes' fences, the shared window-spectra pool and the descriptor ring are what this covers)
+    lanes = int(rng.choice([2, 3])) if rng.random() < 0.4 else 1
+    if lanes > 1:
+        eng.context().set_overlap(lanes)
+    pending = []
     for step in range(int(rng.integers(3, 9))):
+        if lanes > 1:
+            eng.context().join()
         n = int(rng.integers(1, per_step + 1))
         picks = rng.choice(pool, size=min(n, slots // (2 if with_dis else 1), pool), replace=False)
         eng.begin_batch()
@@ -193,8 +202,13 @@ def run_engine(rng, dev):
         sg = torch.full((n,) + tuple(O.spectrogram_shape(sr)), float("nan"), device=dev)
         ag = torch.full((n, 2, sr), float("nan"), device=dev)
         eng.observe_columns(cols, spectrogram_out=sg, audiogoal_out=ag if step % 2 == 0 else None)
+        pending.append((step, n, keys, sg, ag if step % 2 == 0 else None))
+    if lanes > 1:
+        eng.context().join()
+    torch.cuda.synchronize()
+    for step, n, keys, sg, ag in pending:
         sg = sg.cpu().numpy()
-        ag = ag.cpu().numpy() if step % 2 == 0 else None
+        ag = ag.cpu().numpy() if ag is not None else None
         assert not np.isnan(sg).any() and (ag is None or not np.isnan(ag).any()), "NaN / unwritten output rows"
         for u, k in enumerate(keys):
             s, idx, h, silent, ds, dh = k
@@ -210,7 +224,7 @@ def run_engine(rng, dev):
                 err = np.abs(got - ref).max() / np.abs(ref).max()
                 worst = max(worst, err)
                 assert err <= TOL, f"step {step} unit {u} {what}: {err:.3e} key={k} store={type(eng.store).__name__} " \
-                                   f"slots={slots} pool={pool} spectral={eng.rir_spectral}"
+                                   f"slots={slots} pool={pool} spectral={eng.rir_spectral} lanes={lanes}"
         n_total += n
     return sr, n_total, n_src, pool, with_dis, worst
 
@@ -275,6 +289,7 @@ def main():
            f"(tolerance {TOL:.0e}), {time.time() - t_start:.0f} s"
     print(tail)
     if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
             f.write("\n".join(lines + [tail]) + "\n")
     sys.exit(1 if fails else 0)

@@ -119,6 +119,7 @@ def main():
            f"(tolerance {TOL:.0e}), {time.time() - t_start:.0f} s"
     print(tail)
     if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
             f.write("\n".join(lines + [tail]) + "\n")
     sys.exit(1 if fails else 0)
