@@ -1919,6 +1919,7 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
     float* yl = buf + ctx;                                // sample `base`
     const int len = p.out_len;
     lds_barrier();                                        // every earlier use of the buffer (pass 1', previous STFT) is over
+    bool tail_ok = true;
     {
         c32* yl2 = reinterpret_cast<c32*>(yl) + t;        // one ds_write_b64 per packed pair
 #pragma unroll
@@ -1927,11 +1928,13 @@ __device__ __forceinline__ void rows_stft_phase(c32* lds, const ConvParams& p, i
             yl2[1024 * a] = mk2(n < p.n_valid ? y[a].x : 0.f, n + 1 < p.n_valid ? y[a].y : 0.f);   // zeros beyond n_valid
         }
         if (GLOBAL_TAIL) {
-            if (j > 0 && t == 0) (void)flag_acquire(sync.flag_in, sync.epoch);     // block j - 1 has left its last samples
+            if (j > 0 && t == 0) tail_ok = flag_acquire(sync.flag_in, sync.epoch); // block j - 1 has left its last samples
         } else if (j > 0 && t < ctx) buf[t] = tail_in[t]; // the previous block's last samples
     }
     lds_barrier();
-    if (GLOBAL_TAIL && j > 0 && t < ctx) buf[t] = ld_agent(tail_in + t);
+    // (a wait that ran out - the producer never came: not reachable under the launcher's "grid fits the chip" rule - poisons the
+    //  block's first frames instead of rendering them from stale samples: NaN in the observation, not a plausible wrong value)
+    if (GLOBAL_TAIL && j > 0 && t < ctx) buf[t] = tail_ok ? ld_agent(tail_in + t) : __builtin_nanf("");
     if (j == 0 && t < kNfft / 2) yl[-1 - t] = p.pad_mode == 0 ? yl[1 + t] : 0.f;              // left centre padding
     if (last && t >= 256 && t < 256 + kNfft / 2) {        // right centre padding: sample len + k = sample len - 2 - k
         const int k = t - 256;

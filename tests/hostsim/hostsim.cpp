@@ -350,6 +350,7 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
     g_parts_log2 = 0;
     const int n_rows = 2 * n_units;
     if (g_obs_blocks) {
+        const bool reversed = g_obs_blocks == 2;        // consumers BEFORE producers: every hand-off wait runs out (poisoned frames)
         g_obs_blocks = 0;
         if (crossfade || n_valid != out_len) return -3;
         const int nb = (out_len + ssk::kB - 1) / ssk::kB, grid_b = (n_rows * nb) << p.parts_log2;
@@ -359,7 +360,8 @@ int hs_obs_rows(const float* spec, const float* rir, const float* hspec, const i
         std::vector<float> tails(static_cast<size_t>(n_rows) * 2 * ssk::kTailFloats, 12345.0f);
         std::vector<int> fl(static_cast<size_t>(n_rows) * 2, 0);
         gridDim = dim3{(unsigned)grid_b, 1, 1};
-        for (int b = 0; b < grid_b; ++b) {
+        for (int bb = 0; bb < grid_b; ++bb) {
+            const int b = reversed ? grid_b - 1 - bb : bb;
             blockIdx = dim3{(unsigned)b, 0, 0};
             int rc = run_block(ssk::kT, [&] {
                 if (hspec) ssk::k_obs_blocks<true>(p, n_rows, tails.data(), fl.data(), 7);

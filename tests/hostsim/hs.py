@@ -123,7 +123,7 @@ def run(sources, rir_bank, rir_len, units, n_valid, out_len, fuse=False, want_sp
             rc = L.hs_rir_spectra(_p(rir_bank, ctypes.c_float), _p(hspec, ctypes.c_float), R, ctypes.c_longlong(2 * cap), cap, cap)
             assert rc == 0, rc
         if row_blocks:                                   # k_obs_blocks: one workgroup per output block of a row
-            L.hs_set_obs_blocks(1)
+            L.hs_set_obs_blocks(int(row_blocks))         # (2: the workgroups run in REVERSE order - no hand-off ever arrives)
         rc = L.hs_obs_rows(_p(spec, ctypes.c_float), _p(bank, ctypes.c_float), _p(hspec, ctypes.c_float) if spectral else None,
                            _p(rl, ctypes.c_int), _p(desc, ctypes.c_int), _p(out, ctypes.c_float) if want_audiogoal else None,
                            _p(sg, ctypes.c_float), int(N), ctypes.c_longlong(us), int(cs), int(es), int(cap), int(hb), int(n_valid),

@@ -846,3 +846,25 @@ def test_one_workgroup_per_output_block_at_other_rates(sr):
         check(a2[n], ref)
         check(s2[n], O.compute_spectrogram(ref.astype(np.float32)))
         assert O.relerr(s2[n], s1[n]) < 2e-6 and O.relerr(a2[n], a1[n]) < 2e-6
+
+
+def test_a_hand_off_that_never_arrives_poisons_the_block_s_first_column():
+    """k_obs_blocks waits (bounded) for the previous block's workgroup to leave the samples behind the block boundary.  The launcher
+    only takes the kernel when every workgroup is resident, so the wait cannot run out - if it ever did, the block's first frame
+    is rendered from NaN, not from stale samples: a loud observation instead of a plausible wrong one.  Host build, workgroups in
+    REVERSE order (no hand-off has been written when its reader runs): one NaN pooled column per hand-off, everything else -
+    the waveform, the other columns - as in the ordered run."""
+    sr = 44100
+    rng = np.random.default_rng(3)
+    src = O.synth_sources(rng, sr, k=1)[0]
+    bank = np.ascontiguousarray(O.synth_rir(rng, sr, n=1))
+    units = [dict(sound=0, t0=0, rir=0)]
+    kw = dict(fuse=True, row_wgs=64)
+    for spectral in (False, True):
+        a1, s1 = hs.run([src], bank, [sr], units, sr, sr, row_blocks=True, spectral=spectral, **kw)
+        a2, s2 = hs.run([src], bank, [sr], units, sr, sr, row_blocks=2, spectral=spectral, **kw)
+        assert not np.isnan(s1).any() and np.array_equal(a1, a2)
+        bad = np.isnan(s2[0])                                     # [65, T4, 2]
+        cols = np.flatnonzero(bad.any(axis=(0, 2)))
+        assert len(cols) == 2 and bad[:, cols, :].all()           # three output blocks: two hand-offs, whole columns, both ears
+        assert np.array_equal(s2[0][~bad], s1[0][~bad])
