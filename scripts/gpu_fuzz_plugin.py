@@ -1,0 +1,241 @@
+"""Randomised parity sweep at the PLUGIN boundary (test infrastructure; the oracle is the checker): simulators that walk.
+
+Every trial builds a scene of RIR wav files on tmpfs (float32 files of ragged lengths, one int16 file, one empty file, one file
+that is not a wav), a bank of sounds (1-s and multi-second clips) and E stand-in simulators (`tests/fakes.py::FakeSim`: the
+attributes SoundSpacesSim._compute_audiogoal reads, simulator.py:608-666) that walk for a number of steps - receiver / source
+moves, rotations, new episodes (another sound, `_audio_index` back to 0, a short `_duration` so that the episode turns silent,
+:610-612), with or without a distractor (:649-664).  The same walk is served three ways and every observation of every step is
+compared with the oracle at the north-star tolerance:
+
+  eager     `sim_audio.attach` + the task sensors (`SpectrogramSensor` / `AudioGoalSensor`), one simulator at a time
+  deferred  `attach_deferred` on the worker side (requests pickled as through habitat.VectorEnv's pipe), `DeferredResolver` on
+            the trainer side (column path, misses served inside the step's C call), a store SMALLER than the scene
+  batched   `sim_audio.VectorAudioObserver` over the eager adapters (in-process vector envs)
+
+and `_audio_index` must have advanced exactly as the reference advances it (:634-635) - once per COMPUTATION: without a distractor
+the second sensor of a step hits the per-pose memo (:682-686), with HAS_DISTRACTOR_SOUND nothing is cached (:679-681) and the two
+sensors of a step hear consecutive seconds of a multi-second sound (eager and deferred: two sensor reads per step; the batched
+observer is ONE read per step by construction).
+
+    python scripts/gpu_fuzz_plugin.py --trials 40 --seed 1 [--out profiles/r6/fuzz/plugin_seed1.txt]
+"""
+import argparse
+import os
+import pickle
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+from scipy.io import wavfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "sound-spaces_amd"), os.path.join(ROOT, "tests")]
+
+from fakes import FakeSim, NS                          # noqa: E402
+from oracle import ss_oracle as O                      # noqa: E402
+from ss_amd import sensors, sim_audio                  # noqa: E402
+from ss_amd.deferred import DeferredResolver, attach_deferred   # noqa: E402
+from ss_amd.renderer import AudioEngine                # noqa: E402
+
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def build_scene(rng, sr, root, n_nodes):
+    """-> {path: [L, 2] float32 array or None (the reference's zero-RIR fallback, simulator.py:619-624)}"""
+    rirs = {}
+    odd = {(0, 0, 1): "i16", (90, 1, 0): "empty", (180, 1, 1): "junk"}
+    for az in (0, 90, 180, 270):
+        os.makedirs(os.path.join(root, str(az)))
+        for r in range(n_nodes):
+            for s in range(n_nodes):
+                p = os.path.join(root, str(az), f"{r}_{s}.wav")
+                kind = odd.get((az, r, s))
+                L = int(rng.uniform(0.03, 1.0) * sr) if rng.random() < 0.85 else int(rng.uniform(1.0, 1.5) * sr)
+                h = np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T).astype(np.float32)
+                if kind == "i16":
+                    q = (h * 20000).astype(np.int16)
+                    wavfile.write(p, sr, q)
+                    rirs[p] = q.astype(np.float32)
+                elif kind == "empty":
+                    wavfile.write(p, sr, np.zeros((0, 2), np.float32))
+                    rirs[p] = None
+                elif kind == "junk":
+                    open(p, "wb").write(b"RIFFthis is not a wav file")
+                    rirs[p] = None
+                else:
+                    wavfile.write(p, sr, h)
+                    rirs[p] = h
+    return rirs
+
+
+def make_sims(sr, sounds, root, n_env, has_distractor):
+    sims = []
+    for _ in range(n_env):
+        sim = FakeSim(sr, sounds, {}, has_distractor=has_distractor)
+        sim.binaural_rir_dir = root
+        sims.append(sim)
+    return sims
+
+
+def apply_state(sim, st):
+    (sim._current_sound, sim._audio_index, sim._episode_step_count, sim._duration, sim._receiver_position_index,
+     sim._source_position_index, sim._distractor_position_index, sim._rotation_angle, sim._current_distractor_sound) = st
+    sim._audiogoal_cache.clear()                       # (the memo caches have tests of their own: every step renders)
+    sim._spectrogram_cache.clear()
+
+
+def run_trial(rng, base):
+    sr = int(rng.choice([16000, 16000, 16000, 44100]))
+    n_nodes = int(rng.integers(2, 6 if sr == 16000 else 4))
+    n_env = int(rng.choice([1, 2, 3, 5, 8, 16] if sr == 16000 else [1, 2, 5]))
+    has_dis = bool(rng.random() < 0.35)
+    root = tempfile.mkdtemp(dir=base)
+    try:
+        rirs = build_scene(rng, sr, root, n_nodes)
+        sounds = {}
+        for k in range(int(rng.integers(2, 5))):
+            n = sr if rng.random() < 0.5 else int(rng.integers(2, 5)) * sr
+            sounds[f"s{k}.wav"] = (rng.standard_normal(n) * rng.uniform(0.05, 0.5)).astype(np.float32)
+        names = list(sounds)
+        one_s = [n_ for n_ in names if len(sounds[n_]) == sr] or names
+        n_files = len(rirs)
+        slots = int(rng.integers(max(4, 2 * n_env * (2 if has_dis else 1)), max(6, n_files) + 8))
+        sets = {m: make_sims(sr, sounds, root, n_env, has_dis) for m in ("eager", "deferred", "batched")}
+        eng_e = AudioEngine(sr, device=DEV, rir_slots=slots)
+        eng_d = AudioEngine(sr, device=DEV, rir_slots=slots)
+        eng_b = AudioEngine(sr, device=DEV, rir_slots=slots)
+        lazy = bool(rng.random() < 0.5)
+        for sim in sets["eager"]:
+            sim_audio.attach(sim, eng_e, lazy_audiogoal=lazy)
+        for sim in sets["batched"]:
+            sim_audio.attach(sim, eng_b)
+        for i, sim in enumerate(sets["deferred"]):
+            attach_deferred(sim, env_rank=i)
+        res = DeferredResolver(eng_d, fast=True, prefetch_azimuths=bool(rng.random() < 0.3))
+        sg_s = [sensors.SpectrogramSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
+        ag_s = [sensors.AudioGoalSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
+        observer = sim_audio.VectorAudioObserver(eng_b, [s_._ss_hip_audio for s_ in sets["batched"]], want_audiogoal=True)
+        # walk state per env: (sound, audio index, step count, duration, receiver, source, distractor node, rotation, distractor sound)
+        state = [[names[0], 0, 0, 500, 0, 1 % n_nodes, 0, 0, one_s[0] if has_dis else None] for _ in range(n_env)]
+        worst, n_obs = 0.0, 0
+        index = {m: [0] * n_env for m in sets}            # `_audio_index` per serving mode (they read a different number of times)
+        for step in range(int(rng.integers(4, 12))):
+            for e in range(n_env):
+                st = state[e]
+                if rng.random() < 0.15:                               # a new episode
+                    st[0], st[1], st[2] = str(rng.choice(names)), 0, 0
+                    for m in index:
+                        index[m][e] = 0
+                    st[3] = int(rng.choice([2, 3, 500]))
+                    if has_dis:
+                        st[8], st[6] = str(rng.choice(one_s)), int(rng.integers(0, n_nodes))
+                if rng.random() < 0.8:
+                    st[4] = int(rng.integers(0, n_nodes))
+                if rng.random() < 0.2:
+                    st[5] = int(rng.integers(0, n_nodes))
+                st[7] = int(rng.choice([0, 90, 180, 270]))
+                st[2] += 1
+            def reference(e, idx):
+                """(audiogoal, spectrogram, _audio_index afterwards) of ONE computation (simulator.py:608-666) from clip second idx"""
+                snd, _, cnt, dur, recv, src, dnode, rot, dsnd = state[e]
+                az = -(rot + 0) % 360
+                silent = cnt > dur
+                h = rirs[os.path.join(root, str(az), f"{recv}_{src}.wav")]
+                hd = rirs[os.path.join(root, str(az), f"{recv}_{dnode}.wav")] if has_dis else None
+                a = O.compute_audiogoal(sounds[snd], h if h is not None else O.zero_rir(sr), sr, idx, silent,
+                                        sounds[dsnd] if has_dis else None,
+                                        (hd if hd is not None else O.zero_rir(sr)) if has_dis else None)
+                a = np.asarray(a, np.float64)
+                nxt = idx if (silent or len(sounds[snd]) == sr) else (idx + 1) % (len(sounds[snd]) // sr)
+                return a, O.compute_spectrogram(a.astype(np.float32)), nxt
+
+            def expect(e, idx, reads):
+                """spectrogram read first, then (reads == 2) the audiogoal read: the memo serves it without a distractor"""
+                a1, s1, n1 = reference(e, idx)
+                if reads == 1 or not has_dis:
+                    return a1, s1, n1
+                a2, _, n2 = reference(e, n1)
+                return a2, s1, n2
+
+            got, want = {}, {}
+            # eager: two sensor reads per simulator
+            for e, sim in enumerate(sets["eager"]):
+                apply_state(sim, tuple(state[e][:1] + [index["eager"][e]] + state[e][2:]))
+            out = []
+            for e, sim in enumerate(sets["eager"]):
+                s_ = sg_s[e].get_observation(observations=None, episode=None)
+                a_ = ag_s[e].get_observation(observations=None, episode=None)
+                out.append((np.asarray(a_), np.asarray(s_), sim._audio_index))
+            got["eager"] = out
+            want["eager"] = [expect(e, index["eager"][e], 2) for e in range(n_env)]
+            # deferred: both sensors on the worker side, the dicts pickled as through the vector env's pipe
+            for e, sim in enumerate(sets["deferred"]):
+                apply_state(sim, tuple(state[e][:1] + [index["deferred"][e]] + state[e][2:]))
+            observations = [pickle.loads(pickle.dumps({"spectrogram": sim.get_current_spectrogram_observation(None),
+                                                       "audiogoal": sim.get_current_audiogoal_observation()}))
+                            for sim in sets["deferred"]]
+            o = res.resolve_observations(observations, replace=False)
+            ag, sg = o["audiogoal"].cpu().numpy(), o["spectrogram"].cpu().numpy()
+            got["deferred"] = [(ag[e], sg[e], sets["deferred"][e]._audio_index) for e in range(n_env)]
+            want["deferred"] = [expect(e, index["deferred"][e], 2) for e in range(n_env)]
+            # batched: one read per simulator and step
+            for e, sim in enumerate(sets["batched"]):
+                apply_state(sim, tuple(state[e][:1] + [index["batched"][e]] + state[e][2:]))
+            o = observer.observe()
+            ag, sg = o["audiogoal"].cpu().numpy(), o["spectrogram"].cpu().numpy()
+            got["batched"] = [(ag[e], sg[e], sets["batched"][e]._audio_index) for e in range(n_env)]
+            want["batched"] = [expect(e, index["batched"][e], 1) for e in range(n_env)]
+            for mode, outs in got.items():
+                for e, (a, s_, nxt) in enumerate(outs):
+                    ra, rs, rn = want[mode][e]
+                    assert nxt == rn, f"step {step} env {e} {mode}: _audio_index {nxt} != {rn} state={state[e]} from {index[mode][e]}"
+                    for g, r, what in ((a, ra, "audiogoal"), (s_, rs, "spectrogram")):
+                        assert g.shape == r.shape, f"{mode} {what} shape {g.shape} != {r.shape}"
+                        assert not np.isnan(g).any(), f"step {step} env {e} {mode} {what}: NaN"
+                        scale = np.abs(r).max()
+                        err = float(np.abs(g - r).max() / scale) if scale > 0 else float(np.abs(g).max())
+                        worst = max(worst, err)
+                        assert err <= TOL, f"step {step} env {e} {mode} {what}: {err:.3e} state={state[e]} from {index[mode][e]} sr={sr} slots={slots}"
+                    n_obs += 1
+                    index[mode][e] = rn
+        return sr, n_env, n_nodes, slots, has_dis, n_obs, worst
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=30)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    lines, fails, worst_all, n_all = [], 0, 0.0, 0
+    t_start = time.time()
+    for t in range(args.trials):
+        rng = np.random.default_rng([args.seed, t])
+        try:
+            sr, n_env, n_nodes, slots, dis, n_obs, worst = run_trial(rng, base)
+            worst_all, n_all = max(worst_all, worst), n_all + n_obs
+            lines.append(f"trial {t:4d} ok   sr={sr:5d} envs={n_env:2d} nodes={n_nodes} store={slots:3d} distractor={int(dis)} "
+                         f"observations={n_obs:4d} worst={worst:.2e}")
+        except Exception as e:                          # noqa: BLE001 - a sweep reports every failing trial
+            fails += 1
+            lines.append(f"trial {t:4d} FAIL {type(e).__name__}: {e}")
+        print(lines[-1], flush=True)
+    tail = f"# plugin boundary (eager / deferred / batched), {args.trials} trials, seed {args.seed}: {fails} failed, {n_all} observations, " \
+           f"worst relative error {worst_all:.2e} (tolerance {TOL:.0e}), {time.time() - t_start:.0f} s"
+    print(tail)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            f.write("\n".join(lines + [tail]) + "\n")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -134,16 +134,20 @@ class DeferredSimAudio:
         return np.ascontiguousarray(clip, dtype=np.float32)
 
     def request(self, kind: str) -> AudioRequest:
-        """One request per simulator state: the second sensor of a step (AudioGoalSensor + SpectrogramSensor are both
-        configured in savi) gets the SAME request back, so ``_audio_index`` advances once per step, as it does in the
-        reference where the second sensor hits the per-pose cache (simulator.py:678-701)."""
+        """One request per simulator state: the second sensor of a step (AudioGoalSensor + SpectrogramSensor both
+        configured) gets the SAME request back, so ``_audio_index`` advances once per step, as it does in the reference where
+        the second sensor hits the per-pose cache (simulator.py:682-686, 694-698).  With HAS_DISTRACTOR_SOUND the reference does
+        NOT cache (:679-681, :691-693): every sensor read computes again and advances ``_audio_index`` again - so does this
+        adapter (a new request per read; ``DeferredResolver.resolve_observations`` renders the two sensors' requests
+        separately when they name different clip windows)."""
         sim = self.sim
         if self.continuous:
             key = (sim._episode_step_count, int(sim._current_sample_index), id(sim._prev_sim_obs))
         else:
             key = (sim._episode_step_count, sim._receiver_position_index, sim._source_position_index,
                    sim.azimuth_angle, sim._current_sound)
-        if getattr(self, "_memo_key", None) == key:
+        uncached = not self.continuous and bool(sim.config.AUDIO.HAS_DISTRACTOR_SOUND)
+        if not uncached and getattr(self, "_memo_key", None) == key:
             return self._memo
         if self.pose_cache and not sim.config.AUDIO.HAS_DISTRACTOR_SOUND:
             cache = sim._spectrogram_cache                    # the simulator's own dict: reconfigure() replaces it (:395-397)
@@ -1003,8 +1007,22 @@ class DeferredResolver:
             return {}
         reqs = [obs[keys[0]] for obs in observations]
         slots = rollouts.next_observation_slots([k for k in keys if k in rollouts.observations]) if rollouts is not None else {}
-        out = self.resolve(reqs, want_audiogoal="audiogoal" in keys, want_spectrogram="spectrogram" in keys,
-                           spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
+        if len(keys) == 2 and any(obs["audiogoal"].t0 != obs["spectrogram"].t0 or obs["audiogoal"].silent != obs["spectrogram"].silent
+                                  for obs in observations):
+            # HAS_DISTRACTOR_SOUND: the reference computes per sensor read (simulator.py:679-681) - the two sensors of a step hear
+            # consecutive seconds of a multi-second sound.  One launch per sensor, each from its own requests.
+            # (the sensor that was read FIRST carries the clips a worker sends once: its requests are resolved first)
+            ag_reqs = [obs["audiogoal"] for obs in observations]
+            ag_first = any(q.clip is not None or q.dis_clip is not None for q in ag_reqs)
+            out = {}
+            for which in (("audiogoal", "spectrogram") if ag_first else ("spectrogram", "audiogoal")):
+                if which == "spectrogram":
+                    out.update(self.resolve(reqs, want_audiogoal=False, want_spectrogram=True, spectrogram_out=slots.get("spectrogram")))
+                else:
+                    out.update(self.resolve(ag_reqs, want_audiogoal=True, want_spectrogram=False, audiogoal_out=slots.get("audiogoal")))
+        else:
+            out = self.resolve(reqs, want_audiogoal="audiogoal" in keys, want_spectrogram="spectrogram" in keys,
+                               spectrogram_out=slots.get("spectrogram"), audiogoal_out=slots.get("audiogoal"))
         if replace:
             for k in keys:
                 for obs, row in zip(observations, out[k].unbind(0)):      # ONE call makes the N row views

@@ -1122,6 +1122,14 @@ class RirStore:
                 if too_long.any():
                     self._ensure_cap(int(self._kept_len(int(frames[too_long].max()))))
                     continue
+                # scipy's semantics for everything unusual (int16 / mono / extensible headers ...): read by `reader` here, so that a
+                # file longer than the rows grows them like a float32 file does (found by scripts/gpu_fuzz_plugin.py: an int16
+                # RIR of 1.5 s in whole-RIR mode raised instead)
+                by_reader = {f: _planar(reader(flat[f][1])) for f in np.flatnonzero(status == _lib.WAV_UNSUPPORTED)}
+                need = max([self._kept_len(r.shape[1]) for r in by_reader.values()] + [0])
+                if need > self.cap:
+                    self._ensure_cap(int(need))
+                    continue
                 break
             lens = np.zeros((n_rows,), np.int32)
             full = np.zeros((n_rows,), np.int32)
@@ -1131,11 +1139,9 @@ class RirStore:
                 st = int(status[f])
                 if st == _lib.WAV_MISSING and not missing_ok:
                     raise FileNotFoundError(pth)
-                if st == _lib.WAV_UNSUPPORTED:                    # scipy's semantics for everything unusual
-                    r = _planar(reader(pth))
+                if st == _lib.WAV_UNSUPPORTED:
+                    r = by_reader[f]
                     n = self._kept_len(r.shape[1])
-                    if n > self.cap:
-                        raise ValueError(f"load_files: {pth}: {n} frames after an unusual header; use slot()")
                     snp[row, :n, :] = r[:, :n].T
                     snp[row, n:, :] = 0.0
                     lens[row], full[row] = n, r.shape[1]

@@ -490,3 +490,19 @@ def test_in_call_loader_orders_its_scatter_behind_steps_in_flight(tmp_path):
     torch.cuda.synchronize()
     a = O.compute_audiogoal(clip, wav_rir_reader(paths[3]), sr)
     assert O.relerr(sg[0].cpu().numpy(), O.compute_spectrogram(a.astype(np.float32))) < 1e-4
+
+
+def test_a_long_file_that_only_scipy_reads_grows_the_rows(tmp_path):
+    """Whole-RIR mode (truncate_to=None): a float32 file longer than the rows grows them (WAV_TOO_LONG -> _ensure_cap); an int16
+    file - read by the Python reader, scipy's semantics - has to do the same (scripts/gpu_fuzz_plugin.py: it raised instead)."""
+    rng = np.random.default_rng(4)
+    long16 = str(tmp_path / "long16.wav")
+    wavfile.write(long16, 16000, (rng.standard_normal((23000, 2)) * 3000).astype(np.int16))
+    short = str(tmp_path / "short.wav")
+    wavfile.write(short, 16000, rng.standard_normal((500, 2)).astype(np.float32))
+    s1 = RirStore(8, 16000, "cpu", truncate_to=None)
+    a, b = s1.load_files([short, long16], [short, long16])
+    assert s1.cap >= 23000 and s1.host_len[b] == 23000 and s1.host_len[a] == 500
+    ref = wav_rir_reader(long16)
+    assert np.array_equal(s1.bank.data[b, :, :23000].numpy(), ref.T) and not s1.bank.data[b, :, 23000:].any()
+    assert np.array_equal(s1.bank.data[a, :, :500].numpy(), wav_rir_reader(short).T)
