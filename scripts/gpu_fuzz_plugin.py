@@ -81,11 +81,12 @@ def make_sims(sr, sounds, root, n_env, has_distractor):
     return sims
 
 
-def apply_state(sim, st):
+def apply_state(sim, st, keep_caches=False):
     (sim._current_sound, sim._audio_index, sim._episode_step_count, sim._duration, sim._receiver_position_index,
      sim._source_position_index, sim._distractor_position_index, sim._rotation_angle, sim._current_distractor_sound) = st
-    sim._audiogoal_cache.clear()                       # (the memo caches have tests of their own: every step renders)
-    sim._spectrogram_cache.clear()
+    if not keep_caches:                                # (memo trials keep them: the reference's per-pose caches, :678-701)
+        sim._audiogoal_cache.clear()
+        sim._spectrogram_cache.clear()
 
 
 def run_trial(rng, base):
@@ -103,18 +104,24 @@ def run_trial(rng, base):
         names = list(sounds)
         one_s = [n_ for n_ in names if len(sounds[n_]) == sr] or names
         n_files = len(rirs)
-        slots = int(rng.integers(max(4, 2 * n_env * (2 if has_dis else 1)), max(6, n_files) + 8))
+        lo = max(4, 2 * n_env * (2 if has_dis else 1))
+        slots = int(rng.integers(lo, max(lo + 1, n_files + 8)))
         sets = {m: make_sims(sr, sounds, root, n_env, has_dis) for m in ("eager", "deferred", "batched")}
         eng_e = AudioEngine(sr, device=DEV, rir_slots=slots)
         eng_d = AudioEngine(sr, device=DEV, rir_slots=slots)
         eng_b = AudioEngine(sr, device=DEV, rir_slots=slots)
         lazy = bool(rng.random() < 0.5)
+        # memo trials: the simulators keep their per-pose caches between steps (simulator.py:682-686, 694-698: a pose seen before
+        # returns what was first rendered there, `_audio_index` untouched; new dicts when an episode changes the sound, :395-397);
+        # eager mode uses the simulator's own dicts, deferred mode `pose_cache=True`; the batched observer renders every step
+        memo = (not has_dis) and bool(rng.random() < 0.5)
+        model = {m: [dict() for _ in range(n_env)] for m in ("eager", "deferred")}
         for sim in sets["eager"]:
             sim_audio.attach(sim, eng_e, lazy_audiogoal=lazy)
         for sim in sets["batched"]:
             sim_audio.attach(sim, eng_b)
         for i, sim in enumerate(sets["deferred"]):
-            attach_deferred(sim, env_rank=i)
+            attach_deferred(sim, env_rank=i, pose_cache=memo)
         res = DeferredResolver(eng_d, fast=True, prefetch_azimuths=bool(rng.random() < 0.3))
         sg_s = [sensors.SpectrogramSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
         ag_s = [sensors.AudioGoalSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
@@ -122,15 +129,24 @@ def run_trial(rng, base):
         # walk state per env: (sound, audio index, step count, duration, receiver, source, distractor node, rotation, distractor sound)
         state = [[names[0], 0, 0, 500, 0, 1 % n_nodes, 0, 0, one_s[0] if has_dis else None] for _ in range(n_env)]
         worst, n_obs = 0.0, 0
+        history = [[] for _ in range(n_env)]
         index = {m: [0] * n_env for m in sets}            # `_audio_index` per serving mode (they read a different number of times)
         for step in range(int(rng.integers(4, 12))):
             for e in range(n_env):
                 st = state[e]
                 if rng.random() < 0.15:                               # a new episode
-                    st[0], st[1], st[2] = str(rng.choice(names)), 0, 0
+                    prev = st[0]
+                    # (trials that clear the simulators' caches before every step - the cache-miss path - keep the step count
+                    #  running: a simulator never computes twice in one state, and the deferred adapter relies on that when it
+                    #  hands the second sensor of a step the first one's request)
+                    st[0], st[1], st[2] = str(rng.choice(names)), 0, 0 if memo else st[2]
                     for m in index:
                         index[m][e] = 0
-                    st[3] = int(rng.choice([2, 3, 500]))
+                    if memo and st[0] != prev:                        # another sound: the reference starts new caches (:395-397)
+                        for m in model:
+                            model[m][e] = dict()
+                            sets[m][e]._audiogoal_cache, sets[m][e]._spectrogram_cache = dict(), dict()
+                    st[3] = st[2] + int(rng.choice([2, 3, 500]))
                     if has_dis:
                         st[8], st[6] = str(rng.choice(one_s)), int(rng.integers(0, n_nodes))
                 if rng.random() < 0.8:
@@ -153,35 +169,44 @@ def run_trial(rng, base):
                 nxt = idx if (silent or len(sounds[snd]) == sr) else (idx + 1) % (len(sounds[snd]) // sr)
                 return a, O.compute_spectrogram(a.astype(np.float32)), nxt
 
-            def expect(e, idx, reads):
+            def expect(e, idx, reads, mode=None):
                 """spectrogram read first, then (reads == 2) the audiogoal read: the memo serves it without a distractor"""
+                if memo and mode in model:
+                    pose = (state[e][5], state[e][4], -(state[e][7] + 0) % 360)       # (source, receiver, azimuth), :683
+                    if pose not in model[mode][e]:
+                        a1, s1, n1 = reference(e, idx)
+                        model[mode][e][pose] = (a1, s1)
+                        return a1, s1, n1
+                    return model[mode][e][pose] + (idx,)
                 a1, s1, n1 = reference(e, idx)
                 if reads == 1 or not has_dis:
                     return a1, s1, n1
                 a2, _, n2 = reference(e, n1)
                 return a2, s1, n2
 
+            for e in range(n_env):
+                history[e].append(tuple(state[e][:1] + state[e][2:6] + state[e][7:8]))
             got, want = {}, {}
             # eager: two sensor reads per simulator
             for e, sim in enumerate(sets["eager"]):
-                apply_state(sim, tuple(state[e][:1] + [index["eager"][e]] + state[e][2:]))
+                apply_state(sim, tuple(state[e][:1] + [index["eager"][e]] + state[e][2:]), memo)
             out = []
             for e, sim in enumerate(sets["eager"]):
                 s_ = sg_s[e].get_observation(observations=None, episode=None)
                 a_ = ag_s[e].get_observation(observations=None, episode=None)
                 out.append((np.asarray(a_), np.asarray(s_), sim._audio_index))
             got["eager"] = out
-            want["eager"] = [expect(e, index["eager"][e], 2) for e in range(n_env)]
+            want["eager"] = [expect(e, index["eager"][e], 2, "eager") for e in range(n_env)]
             # deferred: both sensors on the worker side, the dicts pickled as through the vector env's pipe
             for e, sim in enumerate(sets["deferred"]):
-                apply_state(sim, tuple(state[e][:1] + [index["deferred"][e]] + state[e][2:]))
+                apply_state(sim, tuple(state[e][:1] + [index["deferred"][e]] + state[e][2:]), memo)
             observations = [pickle.loads(pickle.dumps({"spectrogram": sim.get_current_spectrogram_observation(None),
                                                        "audiogoal": sim.get_current_audiogoal_observation()}))
                             for sim in sets["deferred"]]
             o = res.resolve_observations(observations, replace=False)
             ag, sg = o["audiogoal"].cpu().numpy(), o["spectrogram"].cpu().numpy()
             got["deferred"] = [(ag[e], sg[e], sets["deferred"][e]._audio_index) for e in range(n_env)]
-            want["deferred"] = [expect(e, index["deferred"][e], 2) for e in range(n_env)]
+            want["deferred"] = [expect(e, index["deferred"][e], 2, "deferred") for e in range(n_env)]
             # batched: one read per simulator and step
             for e, sim in enumerate(sets["batched"]):
                 apply_state(sim, tuple(state[e][:1] + [index["batched"][e]] + state[e][2:]))
@@ -192,7 +217,8 @@ def run_trial(rng, base):
             for mode, outs in got.items():
                 for e, (a, s_, nxt) in enumerate(outs):
                     ra, rs, rn = want[mode][e]
-                    assert nxt == rn, f"step {step} env {e} {mode}: _audio_index {nxt} != {rn} state={state[e]} from {index[mode][e]}"
+                    assert nxt == rn, f"step {step} env {e} {mode}: _audio_index {nxt} != {rn} state={state[e]} from {index[mode][e]} memo={memo} " \
+                                      f"history={history[e]}"
                     for g, r, what in ((a, ra, "audiogoal"), (s_, rs, "spectrogram")):
                         assert g.shape == r.shape, f"{mode} {what} shape {g.shape} != {r.shape}"
                         assert not np.isnan(g).any(), f"step {step} env {e} {mode} {what}: NaN"
@@ -212,11 +238,12 @@ def main():
     ap.add_argument("--trials", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", type=int, default=-1, help="run this one trial (debugging)")
     args = ap.parse_args()
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     lines, fails, worst_all, n_all = [], 0, 0.0, 0
     t_start = time.time()
-    for t in range(args.trials):
+    for t in (range(args.trials) if args.only < 0 else [args.only]):
         rng = np.random.default_rng([args.seed, t])
         try:
             sr, n_env, n_nodes, slots, dis, n_obs, worst = run_trial(rng, base)
