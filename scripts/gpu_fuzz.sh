@@ -15,6 +15,7 @@ for k in 0 1; do s=$((s0 + k))
   timeout 900 python scripts/gpu_fuzz.py --mode engine --trials 300 --seed $s --out $out/engine_seed$s.txt 2>&1 | grep -v " ok " | tail -6
   timeout 900 python scripts/gpu_fuzz_features.py --trials 200 --seed $s --out $out/features_seed$s.txt 2>&1 | grep -v " ok " | tail -6
   timeout 900 python scripts/gpu_fuzz_plugin.py --trials 60 --seed $s --out $out/plugin_seed$s.txt 2>&1 | grep -v " ok \|WARNING" | tail -6
+  timeout 900 python scripts/gpu_fuzz_plugin.py --mode continuous --trials 40 --seed $s --out $out/plugin_continuous_seed$s.txt 2>&1 | grep -v " ok \|WARNING" | tail -6
 done
 grep -h "^#" $out/*_seed*.txt > $out/SUMMARY.txt
 cat $out/SUMMARY.txt

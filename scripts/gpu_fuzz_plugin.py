@@ -233,12 +233,97 @@ def run_trial(rng, base):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def run_continuous_trial(rng, base):
+    """SoundSpaces 2.0 simulators (continuous_simulator.py:370-462; `tests/fakes.py::FakeContinuousSim` steps them the way the
+    reference's `step` does, :384-390): a live RIR from the ray tracer every step (ragged lengths, also longer than a second), the
+    previous step's RIR for the cross-fade (:422-424), a sample index that wraps around the clip (:438-447), episodes that restart
+    (`_last_rir` None, a new random sample index, :341-342) or run past `_duration`.  Eager (`attach_continuous` + the task sensors),
+    deferred (`attach_deferred(continuous=True)`: numbered live RIRs through the pipe) and batched (`VectorAudioObserver`)."""
+    from fakes import FakeContinuousSim
+    sr = int(rng.choice([16000, 16000, 44100, 48000]))
+    step_time = float(rng.choice([0.25, 0.25, 0.1]))
+    crossfade = bool(rng.random() < 0.7)
+    n_env = int(rng.choice([1, 2, 3, 5, 8] if sr == 16000 else [1, 2, 4]))
+    sounds = {}
+    for k in range(int(rng.integers(1, 4))):
+        n = sr if rng.random() < 0.5 else int(rng.uniform(2.0, 4.0) * sr)
+        sounds[f"s{k}.wav"] = (rng.standard_normal(n) * rng.uniform(0.05, 0.5)).astype(np.float32)
+    names = list(sounds)
+    pools = []
+    for e in range(n_env):
+        pool = []
+        for _ in range(int(rng.integers(3, 7))):
+            L = int(rng.uniform(0.05, 1.0) * sr) if rng.random() < 0.85 else int(rng.uniform(1.0, 1.4) * sr)
+            pool.append(O.synth_rir(rng, sr, length=L, n=1)[0].astype(np.float64))          # [2, L], as the audio sensor returns it
+        pools.append(pool)
+    starts = [int(rng.integers(0, int(sr * step_time))) for _ in range(n_env)]
+
+    def make(e):
+        pool = pools[e]
+        return FakeContinuousSim(sr, sounds, lambda k, pool=pool: pool[(3 * k + 1) % len(pool)].tolist(), step_time=step_time,
+                                 crossfade=crossfade, start_index=starts[e])
+    modes = ("eager", "deferred", "batched")
+    sets = {m: [make(e) for e in range(n_env)] for m in modes}
+    engs = {m: AudioEngine(sr, device=DEV, rir_slots=2 * n_env + 4, step_time=step_time, wrap=True) for m in modes}
+    for sim in sets["eager"]:
+        sim_audio.attach_continuous(sim, engs["eager"])
+    for sim in sets["batched"]:
+        sim_audio.attach_continuous(sim, engs["batched"])
+    for i, sim in enumerate(sets["deferred"]):
+        attach_deferred(sim, env_rank=i, continuous=True)
+    res = DeferredResolver(engs["deferred"])
+    sg_s = [sensors.SpectrogramSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
+    ag_s = [sensors.AudioGoalSensor(sim=s_, config=NS()) for s_ in sets["eager"]]
+    observer = sim_audio.VectorAudioObserver(engs["batched"], [s_._ss_hip_audio for s_ in sets["batched"]], want_audiogoal=True)
+    worst, n_obs = 0.0, 0
+    for step in range(int(rng.integers(5, 14))):
+        refs = [sets["eager"][e].reference_audiogoal() for e in range(n_env)]
+        refs = [(np.asarray(a, np.float64), O.compute_spectrogram(np.asarray(a, np.float32))) for a in refs]
+        got = {}
+        got["eager"] = [(np.asarray(ag_s[e].get_observation(observations=None, episode=None)),
+                         np.asarray(sg_s[e].get_observation(observations=None, episode=None))) for e in range(n_env)]
+        observations = [pickle.loads(pickle.dumps({"spectrogram": sim.get_current_spectrogram_observation(None),
+                                                   "audiogoal": sim.get_current_audiogoal_observation()}))
+                        for sim in sets["deferred"]]
+        o = res.resolve_observations(observations, replace=False)
+        ag, sg = o["audiogoal"].cpu().numpy(), o["spectrogram"].cpu().numpy()
+        got["deferred"] = [(ag[e], sg[e]) for e in range(n_env)]
+        o = observer.observe()
+        ag, sg = o["audiogoal"].cpu().numpy(), o["spectrogram"].cpu().numpy()
+        got["batched"] = [(ag[e], sg[e]) for e in range(n_env)]
+        for mode, outs in got.items():
+            for e, (a, s_) in enumerate(outs):
+                for g, r, what in ((a, refs[e][0], "audiogoal"), (s_, refs[e][1], "spectrogram")):
+                    assert g.shape == r.shape, f"{mode} {what} shape {g.shape} != {r.shape}"
+                    assert not np.isnan(g).any(), f"step {step} env {e} {mode} {what}: NaN"
+                    scale = np.abs(r).max()
+                    err = float(np.abs(g - r).max() / scale) if scale > 0 else float(np.abs(g).max())
+                    worst = max(worst, err)
+                    sim = sets[mode][e]
+                    assert err <= TOL, f"step {step} env {e} {mode} {what}: {err:.3e} sr={sr} step_time={step_time} crossfade={crossfade} " \
+                                       f"index={sim._current_sample_index} clip={sim.current_source_sound.shape[0]} count={sim._episode_step_count}"
+                n_obs += 1
+        for e in range(n_env):                                    # the same transition on the three twins
+            restart = rng.random() < 0.12
+            snd = str(rng.choice(names))
+            idx = int(rng.integers(0, int(sr * step_time)))
+            dur = int(rng.choice([1, 2, 500]))
+            for m in modes:
+                sim = sets[m][e]
+                sim.step()
+                if restart:                                       # reconfigure (:336-346): new episode
+                    sim._current_sound, sim._last_rir, sim._current_sample_index = snd, None, idx
+                    sim._episode_step_count, sim._duration = 0, dur
+    return sr, n_env, 0, 2 * n_env + 4, crossfade, n_obs, worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", type=int, default=-1, help="run this one trial (debugging)")
+    ap.add_argument("--mode", choices=["sim", "continuous"], default="sim", help="SoundSpacesSim walks / SoundSpaces 2.0 walks")
     args = ap.parse_args()
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     lines, fails, worst_all, n_all = [], 0, 0.0, 0
@@ -246,7 +331,7 @@ def main():
     for t in (range(args.trials) if args.only < 0 else [args.only]):
         rng = np.random.default_rng([args.seed, t])
         try:
-            sr, n_env, n_nodes, slots, dis, n_obs, worst = run_trial(rng, base)
+            sr, n_env, n_nodes, slots, dis, n_obs, worst = (run_trial if args.mode == 'sim' else run_continuous_trial)(rng, base)
             worst_all, n_all = max(worst_all, worst), n_all + n_obs
             lines.append(f"trial {t:4d} ok   sr={sr:5d} envs={n_env:2d} nodes={n_nodes} store={slots:3d} distractor={int(dis)} "
                          f"observations={n_obs:4d} worst={worst:.2e}")
@@ -254,7 +339,7 @@ def main():
             fails += 1
             lines.append(f"trial {t:4d} FAIL {type(e).__name__}: {e}")
         print(lines[-1], flush=True)
-    tail = f"# plugin boundary (eager / deferred / batched), {args.trials} trials, seed {args.seed}: {fails} failed, {n_all} observations, " \
+    tail = f"# plugin boundary, {args.mode} (eager / deferred / batched), {args.trials} trials, seed {args.seed}: {fails} failed, {n_all} observations, " \
            f"worst relative error {worst_all:.2e} (tolerance {TOL:.0e}), {time.time() - t_start:.0f} s"
     print(tail)
     if args.out:
