@@ -186,7 +186,7 @@ int ss_intensity_f32(const float* audiogoal, float* out, int n_units, int len, i
  * x [n_units, 2, len] -> out [n_units, n_mels, 1 + len/160, 2] (channel-last, no pooling):
  *   out = log( sum_k W[j][k] * |STFT(x)[k]|^2 + eps ), STFT framing exactly as ss_spectrogram_f32.
  * The filter bank is band-sparse: band j covers bins mel_start[j] .. mel_start[j] + max_len - 1 with weights
- * mel_w[j*max_len + i] (zero padded).  n_mels <= 128; max_len a multiple of 4, <= 60; n_mels*max_len <= 4096;
+ * mel_w[j*max_len + i] (zero padded).  n_mels <= 128; max_len a multiple of 4, <= 64 (32 bands at 48 kHz; 20-band banks are wider); n_mels*max_len <= 4096;
  * mel_start[j] a multiple of 4 in [0, 256] (pad the band with leading zero weights; the kernel reads 16 bytes at a
  * time and sees zeros beyond bin 256); mel_w 16-byte aligned.  mel_start's range is the caller's responsibility. */
 int ss_logmel_f32(const float* x, float* out, int n_units, int len, int pad_mode, const int* mel_start,

@@ -23,7 +23,7 @@
 
 namespace ssk {
 
-constexpr int kFeatMaxMels = 64, kFeatMaxLen = 60;          // more bands / wider filters take the stand-alone k_logmel
+constexpr int kFeatMaxMels = 64, kFeatMaxLen = 64;          // more bands take the stand-alone k_logmel (start <= 256: start + 64 <= kPowStride)
 constexpr int kFeatMelTable = 3072;                         // floats: n_mels * max_len (64 x 36, 40 x 52, 32 x 64 ... fit); 12 KiB
 static_assert(kGccMaxLag <= 32, "k_features extracts lags from output slots 0, 1 and 15 only");
 constexpr int kGccResStride = kSegFrames + 1;

@@ -512,7 +512,7 @@ struct MelParams {
     int n_mels, max_len;
     float eps;
 };
-constexpr int kPowStride = 320, kMelMaxLen = 60, kMelMaxBands = 128;   // start <= 256, start + max_len <= 316 < 320
+constexpr int kPowStride = 320, kMelMaxLen = 64, kMelMaxBands = 128;   // start <= 256 (a multiple of 4): start + max_len <= 320
 constexpr int kMelTableFloats = 4096;   // LDS copy of w (n_mels * max_len <= 4096)
 
 // first half of stft_block: 256-point FFT of the packed frame, then the power spectrum |X[k]|^2, k = 0..256, of this

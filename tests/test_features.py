@@ -27,7 +27,7 @@ def binaural(rng, n_units, n, quiet_head=True):
 
 
 @pytest.mark.parametrize("n,sr,n_mels,gpw", [(16000, 16000, 64, 1), (16000, 16000, 40, 7), (4000, 16000, 64, 2),
-                                             (44100, 44100, 64, 5), (15999, 16000, 64, 3)])
+                                             (44100, 44100, 64, 5), (15999, 16000, 64, 3), (9000, 48000, 32, 2)])
 def test_hostsim_features_vs_oracle(n, sr, n_mels, gpw):
     from hostsim import hs
     rng = np.random.default_rng(n + n_mels)

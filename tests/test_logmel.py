@@ -38,7 +38,7 @@ def test_mel_scale_round_trip_and_known_points():
 
 
 @pytest.mark.parametrize("n,sr,n_mels,gpw", [(16000, 16000, 64, 1), (16000, 16000, 64, 7), (4000, 16000, 40, 2),
-                                             (44100, 44100, 64, 5), (15999, 16000, 128, 3)])
+                                             (44100, 44100, 64, 5), (15999, 16000, 128, 3), (9000, 48000, 32, 2)])
 def test_hostsim_kernel_vs_oracle(n, sr, n_mels, gpw):
     from hostsim import hs
     rng = np.random.default_rng(n + n_mels)
