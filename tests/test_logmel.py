@@ -70,4 +70,4 @@ def test_gpu_kernel_vs_oracle(sr, n_units, n_mels):
     for k in list(range(min(n_units, 6))) + [n_units - 1]:
         check(got[k], O.compute_logmel(x[k], sr, n_mels=n_mels))
     with pytest.raises(Exception):
-        ops.logmel(xd, ms, torch.zeros((n_mels, 64), device=dev))    # max_len > 60 -> SS_EINVAL
+        ops.logmel(xd, ms, torch.zeros((n_mels, 68), device=dev))    # max_len > 64 -> SS_EINVAL
