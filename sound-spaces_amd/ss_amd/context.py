@@ -154,8 +154,9 @@ class AudioContext:
         load phase of step k+1 overlaps the STFT phase of step k; 3 pays for steps that fill at most half the chip (<= 64 envs),
         4 only with more than the runtime's default four hardware queues (GPU_MAX_HW_QUEUES=8).  Results are visible to a stream
         after ``join()``; steps in flight must write disjoint output rows, and bank rows that steps in flight may read must not
-        be rewritten before a ``join()`` on the stream that carries the rewrite (the stores of ``ss_amd.renderer`` upload on the
-        current stream: join before a step that may evict; the library's in-call loaders order themselves)."""
+        be rewritten before a ``join()`` on the stream that carries the rewrite (an ``AudioEngine``'s stores do that themselves
+        before every device write once the engine has handed out its context, and so do the library's in-call loaders; callers
+        that write bank rows of their own join first)."""
         _lib.check(self.lib.ss_ctx_set_overlap(self._h, int(n_streams)), "ss_ctx_set_overlap")
         self.overlap = int(n_streams)
 

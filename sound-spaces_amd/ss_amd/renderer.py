@@ -458,6 +458,9 @@ class RirStore:
                             torch.zeros((slots,), dtype=torch.int32, device=self.device))
         self.slots, self.cap, self.group = slots, cap, group
         self.truncate_to, self.max_cap, self.on_grow = truncate_to, max_cap, on_grow
+        # called before ANYTHING this store writes to the bank on the device (rows, lengths, block spectra, a reallocation): the
+        # engine orders the write behind its context's overlap lanes there (a step in flight may still read the entry)
+        self.before_device_write = None
         self.on_evict = None                                   # on_evict(key, slot): the entry of `key` is about to be reused
         self._evict_hooks: List = []                           # ... and the same for any number of listeners (add_evict_hook)
         self.defer_uploads = False                             # True (AudioEngine): single-row uploads queue up for flush_uploads()
@@ -538,12 +541,17 @@ class RirStore:
     def _kept_len(self, n: int) -> int:
         return n if self.truncate_to is None else min(n, self.truncate_to)
 
+    def _about_to_write(self) -> None:
+        if self.before_device_write is not None:
+            self.before_device_write()
+
     def _ensure_cap(self, n: int) -> None:
         """Make rows at least n samples long (n = what will be stored, i.e. already clipped by truncate_to)."""
         if n <= self.cap:
             return
         if n > self.max_cap:
             raise ValueError(f"RIR of {n} samples exceeds RirStore.max_cap = {self.max_cap}")
+        self._about_to_write()
         new_cap = min(self.max_cap + (self.max_cap & 1), -(-n // 2048) * 2048)
         data = torch.zeros((self.slots, 2, new_cap), dtype=torch.float32, device=self.device)
         data[:, :, :self.cap] = self.bank.data
@@ -590,6 +598,7 @@ class RirStore:
         row_t, row, k = self._stage_row()
         row[:, :n] = r[:, :n]
         row[:, n:] = 0.0
+        self._about_to_write()
         self.bank.data[slot].copy_(row_t, non_blocking=True)
         if k >= 0:
             ev = torch.cuda.Event()
@@ -608,6 +617,7 @@ class RirStore:
         72 KB per step was most of the trainer half of SoundSpaces 2.0's deferred mode.  Returns the rows uploaded."""
         if not self._pending:
             return 0
+        self._about_to_write()
         slots = sorted(self._pending)
         rows = [self._pending[sl] for sl in slots]
         self._pending = {}
@@ -688,6 +698,7 @@ class RirStore:
         k = len(slots)
         if k == 0:
             return
+        self._about_to_write()
         ok = all(r.strides == (8, 4) and r.dtype.char == "f" for r in rows)      # float32 [L, 2], C-contiguous
         if not ok:
             for sl, r in zip(slots, rows):
@@ -736,6 +747,7 @@ class RirStore:
         self.flush_uploads()
         if not self.spectral or self.bank.spectra is None or not self._stale.any():
             return 0
+        self._about_to_write()
         idx = np.flatnonzero(self._stale)
         run_start = prev = int(idx[0])
         for i in list(idx[1:]) + [None]:
@@ -1006,6 +1018,7 @@ class RirStore:
                     stage_np[j * G + g, :, :n] = r[:, :n]
                     slots.append(sl + g)
             idx = torch.as_tensor(slots, dtype=torch.long, device=self.device)
+            self._about_to_write()
             self.bank.data.index_copy_(0, idx, stage.to(self.device, non_blocking=True))
             self.bank.lengths.index_copy_(0, idx, torch.from_numpy(lens).to(self.device))
             self._dev_len[np.asarray(slots)] = lens
@@ -1029,6 +1042,7 @@ class RirStore:
         (ss_bank_scatter_rows_f32 - it reads block, slots and lengths from the pinned memory itself, transposes into the
         planar rows and writes the length table); returns the event behind it (the block may be refilled after it).
         Host stores (tests without a GPU): the same scatter in torch."""
+        self._about_to_write()
         if self.device.type != "cuda":
             idx = pidx[:n_rows].long()
             self.bank.data.index_copy_(0, idx, stage[:n_rows].permute(0, 2, 1))
@@ -1502,6 +1516,10 @@ class AudioEngine:
                     grow(bank)
                 self._ctx_bank = None
             self.store.on_grow = on_grow
+            # overlap mode (ctx.set_overlap): whatever the store writes to the bank goes behind the steps in flight on the lanes
+            # (AudioContext.join is a no-op on a single-stream context: one attribute test per write)
+            for st in getattr(self.store, "stores", [self.store]):
+                st.before_device_write = ctx.join
         return self._ctx
 
     def _sync_context_bank(self, n_units: int = 0, distractor: bool = True):

@@ -506,3 +506,44 @@ def test_a_long_file_that_only_scipy_reads_grows_the_rows(tmp_path):
     ref = wav_rir_reader(long16)
     assert np.array_equal(s1.bank.data[b, :, :23000].numpy(), ref.T) and not s1.bank.data[b, :, 23000:].any()
     assert np.array_equal(s1.bank.data[a, :, :500].numpy(), wav_rir_reader(short).T)
+
+
+@pytest.mark.gpu
+def test_store_writes_go_behind_steps_in_flight_in_overlap_mode():
+    """The same hazard through the PYTHON store (`eng.rir_slot(key, loader)`: an upload on the current stream into the least
+    recently used entry): once the engine's context runs on overlap lanes, every device write of the engine's store joins the
+    lanes first (`RirStore.before_device_write`)."""
+    import torch
+    from oracle import ss_oracle as O
+    from ss_amd.renderer import AudioEngine
+    sr, n_units, n_steps = 16000, 512, 30
+    rng = np.random.default_rng(22)
+    rirs = [np.ascontiguousarray(O.synth_rir(rng, sr, length=16000, n=1)[0].T) for _ in range(4)]
+    clip = O.synth_sources(rng, sr, k=1)[0]
+    eng = AudioEngine(sr, device="cuda:0", rir_slots=3)
+    sid = eng.source_id("s", clip)
+    slots = []
+    for k in range(3):
+        eng.begin_batch()
+        slots.append(eng.rir_slot(("pose", k), lambda k=k: rirs[k]))
+    ctx = eng.context()
+    cols = dict(sound=np.full(n_units, sid), t0=np.zeros(n_units, np.int64), rir=np.full(n_units, slots[0]))
+    ref = torch.empty((n_units, 65, 26, 2), device="cuda:0")
+    eng.observe_columns(cols, spectrogram_out=ref)
+    torch.cuda.synchronize()
+    ctx.set_overlap(2)
+    out = torch.zeros((n_steps, n_units, 65, 26, 2), device="cuda:0")
+    torch.cuda.synchronize()
+    for k in range(n_steps):
+        eng.observe_columns(cols, spectrogram_out=out[k])
+    eng.begin_batch()
+    new = eng.rir_slot(("pose", 3), lambda: rirs[3])                # evicts pose 0's entry while the steps are still queued
+    assert new == slots[0]
+    sg = torch.empty((1, 65, 26, 2), device="cuda:0")
+    eng.observe_columns(dict(sound=np.array([sid]), t0=np.zeros(1, np.int64), rir=np.array([new])), spectrogram_out=sg)
+    ctx.join()
+    torch.cuda.synchronize()
+    for k in range(n_steps):
+        assert torch.equal(out[k], ref), k
+    a = O.compute_audiogoal(clip, rirs[3], sr)
+    assert O.relerr(sg[0].cpu().numpy(), O.compute_spectrogram(a.astype(np.float32))) < 1e-4
