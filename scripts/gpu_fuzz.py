@@ -168,15 +168,14 @@ def run_engine(rng, dev):
     sids = [eng.source_id(f"s{i}", s) for i, s in enumerate(srcs)]
     worst, n_total = 0.0, 0
     # overlap mode (ss_ctx_set_overlap): the steps alternate between 2-3 internal streams and NOTHING is read back before the last
-    # step was issued; the store uploads rows on the caller's stream, so - as include/ss_hip.h asks - the caller joins before a
-    # step that may rewrite entries (the lanes' fences, the shared window-spectra pool and the descriptor ring are what this covers)
+    # step was issued; entries are evicted and rewritten while earlier steps are still in flight - the engine's stores order their
+    # device writes behind the lanes themselves (RirStore.before_device_write); the lanes' fences, the shared window-spectra pool
+    # and the descriptor ring are covered as well
     lanes = int(rng.choice([2, 3])) if rng.random() < 0.4 else 1
     if lanes > 1:
         eng.context().set_overlap(lanes)
     pending = []
     for step in range(int(rng.integers(3, 9))):
-        if lanes > 1:
-            eng.context().join()
         n = int(rng.integers(1, per_step + 1))
         picks = rng.choice(pool, size=min(n, slots // (2 if with_dis else 1), pool), replace=False)
         eng.begin_batch()
