@@ -867,6 +867,9 @@ class DeferredResolver:
         # a hit renders nothing: it rides through the launch as a silent unit (exact zeros, then overwritten)
         reqs = [AudioRequest(env=q.env, kind=q.kind, silent=True, rec=_silent_rec(q.env)) if q.cache_hit else q for q in requests]
         out = self._resolve(reqs, want_audiogoal, want_spectrogram, spectrogram_out, audiogoal_out)
+        ctx = getattr(self.engine, "_ctx", None)
+        if ctx is not None:
+            ctx.join()                                        # (overlap lanes: the pool copies below READ and WRITE the step's rows)
         dev = next(iter(out.values())).device
         maps = self._pose_maps
         miss_rows, miss_slots = [], []

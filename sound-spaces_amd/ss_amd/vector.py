@@ -407,6 +407,8 @@ class FastVectorAudioObserver:
         self.pose_hits += len(hit_rows)
         self.pose_misses += len(miss_rows)
         self.ctx.observe(spectrogram_out=spectrogram_out, audiogoal_out=audiogoal_out, **self.columns(hold=hold))
+        if (miss_rows or hit_rows) and hasattr(self.ctx, "join"):
+            self.ctx.join()                                   # (overlap lanes: the pool copies below READ and WRITE the step's rows)
         dev = next(iter(outs.values())).device
         if miss_rows:                                         # store what was rendered (silent rows included: the
             slots = self._pool_rows(outs, len(miss_rows))     # reference caches its zeros under the pose as well)
