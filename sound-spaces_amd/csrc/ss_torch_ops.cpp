@@ -241,6 +241,7 @@ void eager_obs(int64_t handle, int64_t sound, int64_t t0, int64_t rir, int64_t d
     TORCH_CHECK(want_audiogoal || want_spectrogram, "eager_obs: nothing to compute");
     check_rc(ss_ctx_observe(ctx_of(handle), &u, 1, want_audiogoal ? d : nullptr, want_spectrogram ? d + n_ag : nullptr, st),
              "ss_ctx_observe");
+    check_rc(ss_ctx_join(ctx_of(handle), st), "ss_ctx_join");    // (a context on overlap lanes: the read-back waits for the lane)
     hipError_t e = hipSuccess;
     if (!direct) {
         const int64_t lo = want_audiogoal ? 0 : n_ag;
