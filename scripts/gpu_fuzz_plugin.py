@@ -57,7 +57,10 @@ def build_scene(rng, sr, root, n_nodes):
                 L = int(rng.uniform(0.03, 1.0) * sr) if rng.random() < 0.85 else int(rng.uniform(1.0, 1.5) * sr)
                 h = np.ascontiguousarray(O.synth_rir(rng, sr, length=L, n=1)[0].T).astype(np.float32)
                 if kind == "i16":
-                    q = (h * 20000).astype(np.int16)
+                    # (integer PCM is convolved as it is, simulator.py:615-618.  A modest scale: at 20000 x the spectrogram's log1p
+                    #  turns logarithmic in the quiet frames of a decaying RIR and shows the float32 convolution floor - 1e-6 of the
+                    #  row's peak, the reference's own scipy float32 path has the same - as 1.4e-4 of the spectrogram's peak)
+                    q = (h * 300).astype(np.int16)
                     wavfile.write(p, sr, q)
                     rirs[p] = q.astype(np.float32)
                 elif kind == "empty":
