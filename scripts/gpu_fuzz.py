@@ -51,10 +51,10 @@ def draw_trial(rng):
             continue
         h = O.synth_rir(rng, sr, length=L, n=1)[0]             # [2, L]
         rirs.append(np.ascontiguousarray(h.T).astype(np.float32))
-    n_units = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 31, 32, 33, 42, 43, 64, 96, 97, 128, 150, 257, 400],
+    n_units = int(rng.choice([1, 2, 3, 5, 7, 10, 16, 31, 32, 33, 42, 43, 64, 96, 97, 128, 150, 257, 400, 700, 1100],
                              p=None))
     if sr >= 32000:
-        n_units = min(n_units, 160)
+        n_units = min(n_units, 300 if rng.random() < 0.1 else 160)
     with_dis = rng.random() < 0.4
     units, keys = [], []
     for _ in range(n_units):
@@ -230,16 +230,17 @@ def run_engine(rng, dev):
 
 def run_trial(rng, dev):
     sr, srcs, rirs, units, keys = draw_trial(rng)
+    pad = "reflect" if rng.random() < 0.7 else "constant"      # librosa < 0.10 (the reference's era) / >= 0.10 centre padding
     refs = {}
     for k in set(keys):
         s, idx, h, silent, ds, dh = k
         a = O.compute_audiogoal(srcs[s], rirs[h], sr, idx, silent, srcs[ds] if ds >= 0 else None,
                                 rirs[dh] if ds >= 0 else None)
         a = np.asarray(a, np.float64)
-        refs[k] = (a, O.compute_spectrogram(a.astype(np.float32)))
+        refs[k] = (a, O.compute_spectrogram(a.astype(np.float32), pad_mode=pad))
     worst = 0.0
     for spectral in (False, True):
-        r = BatchedAudioRenderer(sr, device=dev)
+        r = BatchedAudioRenderer(sr, device=dev, pad_mode=pad)
         for i, s in enumerate(srcs):
             r.add_source(f"s{i}", s)
         r.set_rir_bank(RirBank.from_arrays(rirs, dev))
